@@ -1,0 +1,119 @@
+/*
+ * vmlmf_hip.h - C ABI of the MI355X (gfx950) VMLMF compressed-LSTM hot path.
+ *
+ * The reference (snudm-starlab/VMLMF) has no FFI: its hot path is Python over ATen.  The functions below
+ * are what a binding for that path would call; each one names the reference code it replaces
+ * (V/ = rnn_compression_factorization_vmlmf/).  Everything is plain pointers + sizes: no torch types.
+ * All pointers are DEVICE pointers (fp32) unless stated; all work is enqueued on `stream` (a hipStream_t
+ * passed as void*), nothing synchronises.  Return value: 0 = ok, <0 = VMLMF_E_*, >0 = hipError_t.
+ */
+#ifndef VMLMF_HIP_H
+#define VMLMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VMLMF_ABI_VERSION 1
+#define VMLMF_MAX_G 2
+
+/* cell variants */
+#define VMLMF_V1_CELL 1       /* MyVMLMFCell       V/src/models/vmlmf.py:38-125        */
+#define VMLMF_V2_GROUP_CELL 2 /* MyVMLMFCellg2     V/src/models/vmlmf_group.py:37-155  */
+#define VMLMF_V3_LM 3         /* MyVMLSTM          V/src/models/vmlmf_lm.py:178-280    */
+#define VMLMF_V4_LM_GROUP 4   /* MyVMLSTMGroup     V/src/models/vmlmf_lm.py:53-174     */
+
+#define VMLMF_E_BADARG (-1)      /* null pointer / inconsistent descriptor                          */
+#define VMLMF_E_SHAPE (-2)       /* shape the reference itself rejects (I > H, I != H for LM, H % g) */
+#define VMLMF_E_UNSUPPORTED (-3) /* valid for the reference, not yet covered by the HIP kernels       */
+#define VMLMF_E_WORKSPACE (-4)   /* workspace / reserve smaller than vmlmf_query() asked for          */
+
+/* One layer's problem description.  x is (T,B,I) when time_major else (B,T,I); y likewise with H. */
+typedef struct vmlmf_desc {
+  int32_t variant;           /* VMLMF_V*                                                        */
+  int32_t B, T, I, H;        /* batch, time steps, input_size, hidden_size                      */
+  int32_t w_rank;            /* rank of the input->hidden factorisation  (u_x: I x w_rank)      */
+  int32_t g;                 /* groups of the hidden->hidden path (1 for V1/V3, 2 for V2/V4)    */
+  int32_t u_ranks[VMLMF_MAX_G]; /* rank per shift s (V1/V3: only [0])                           */
+  int32_t time_major;        /* 1: (T,B,*)  LM layers;  0: (B,T,*)  MyLSTM batch_first          */
+  int32_t training;          /* 1: forward fills `reserve` for backward; 0: inference            */
+} vmlmf_desc;
+
+/* Parameters in the REFERENCE's own layouts (so a state_dict's tensors are passed as they are):
+ *   V1: u_x (I,rw) v_x (4H,rw) u_h[0] (H,ru) v_h[0] (4H,ru) b_x b_h (4H) dia_x (1,I) dia_h (1,H)     vmlmf.py:56-69
+ *   V2: u_x v_x as V1; u_h[s] (g,H/g,ru_s) v_h[s] (g,ru_s,4H/g); b_x=bias_x b_h=bias_h (1,4H)        vmlmf_group.py:61-79
+ *   V3: as V1 with v_x=w_x, v_h[0]=w_h                                                               vmlmf_lm.py:200-213
+ *   V4: as V2 with v_x=w_x, b_x/b_h (4H)                                                             vmlmf_lm.py:77-91
+ * The same struct (non-const view) receives the gradients in the same layouts. */
+typedef struct vmlmf_params {
+  const float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h;
+  const float *u_h[VMLMF_MAX_G];
+  const float *v_h[VMLMF_MAX_G];
+} vmlmf_params;
+
+typedef struct vmlmf_grads {
+  float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h;
+  float *u_h[VMLMF_MAX_G];
+  float *v_h[VMLMF_MAX_G];
+} vmlmf_grads;
+
+typedef struct vmlmf_sizes {
+  size_t workspace_bytes; /* scratch, may be reused by the next call on the same stream            */
+  size_t reserve_bytes;   /* written by forward(training=1), read by backward                      */
+  int32_t rows_per_wg;    /* batch rows one persistent workgroup owns                              */
+  int32_t threads_per_wg; /* = groups * waves_per_group * 64                                       */
+  int32_t workgroups;     /* grid of the two recurrent kernels                                     */
+  int32_t kx, kh;         /* padded rank widths held in registers                                  */
+} vmlmf_sizes;
+
+/* ABI / build identification. */
+int vmlmf_abi_version(void);
+const char *vmlmf_build_info(void);
+/* Text of the last error raised on this host thread (never NULL). */
+const char *vmlmf_last_error(void);
+
+/* Validate `d` and report buffer sizes + launch geometry.  Host only, no GPU call. */
+int vmlmf_query(const vmlmf_desc *d, vmlmf_sizes *out);
+
+/*
+ * Sequence forward of one layer: replaces the Python time loop + cell
+ *   MyLSTM.forward             V/src/models/vmlmf.py:300-314   (h0 = c0 = NULL -> zeros, 302-303)
+ *   MyVMLSTM[Group].forward    V/src/models/vmlmf_lm.py:272-280, 166-174  (states passed in)
+ * T = 1 is the bare cell call  MyVMLMFCell.forward vmlmf.py:78-125 / lstm_step vmlmf_lm.py:222-269.
+ * y: all hidden states; hT,cT: (B,H) final state (may be NULL).  reserve may be NULL iff !training.
+ */
+int vmlmf_seq_forward(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                      const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,
+                      size_t workspace_bytes, void *stream);
+
+/*
+ * Sequence backward: replaces autograd's replay of the ~75 ATen ops per timestep.
+ * dy: upstream gradient of y (same layout as y, may be NULL = zeros); dhT,dcT (B,H) may be NULL.
+ * Outputs: dx (layout of x, may be NULL), dh0,dc0 (B,H, may be NULL), and every parameter gradient in
+ * `g` (overwritten, reference layouts; deterministic summation order).  `reserve` and `y` must be the
+ * ones the matching forward produced; `workspace` may be a different buffer.
+ */
+int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                       const float *c0, const float *y, const void *reserve, const float *dy,
+                       const float *dhT, const float *dcT, float *dx, float *dh0, float *dc0,
+                       const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream);
+
+/*
+ * Instrumentation for bench.py (roofline leg).  While enabled, every internal kernel launch is bracketed
+ * by a HIP event pair recorded on the SAME stream the kernel is launched on.  vmlmf_profile_read()
+ * synchronises the recorded events and returns, per internal kernel, the summed duration in microseconds
+ * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 wgrad_x,
+ * 5 wgrad_h, 6 reduce, 7 finish (vmlmf_kernel_name(i) gives the symbol name rocprofv3 reports).
+ */
+#define VMLMF_NKERNELS 8
+int vmlmf_profile_enable(int enable);
+int vmlmf_profile_read(float *usec_sum, int32_t *count, int reset);
+const char *vmlmf_kernel_name(int k);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VMLMF_HIP_H */

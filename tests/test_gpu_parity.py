@@ -1,0 +1,140 @@
+"""GPU parity: the HIP path (through the C ABI) against (a) the golden vectors captured from the imported
+reference and (b) the oracle on the same seeded inputs.  Tolerances: tests/hip_util.py."""
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_oracle as O
+from conftest import load_golden
+from hip_util import run_hip, run_literal, compare_all, assert_out, assert_grad
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["cell_v1", "cell_v1_b1", "cell_v1_ieqh", "cell_v2", "cell_v3", "cell_v4"])
+def test_bare_cell_vs_reference_golden(name):
+    d = load_golden(name)
+    variant = int(d["meta"][0])
+    tm = variant in (O.V3, O.V4)
+    x = d["x"][None] if tm else d["x"][:, None]
+    got = run_hip(variant, d["P"], x, d["h0"], d["c0"], None, d["dh"], d["dc"], time_major=tm)
+    ref = {"hT": d["h1"], "cT": d["c1"], "dx": d["dx"][None] if tm else d["dx"][:, None],
+           "dh0": d["dh0"], "dc0": d["dc0"], "G": d["G"]}
+    compare_all(got, ref, name)
+
+
+@pytest.mark.parametrize("name", ["seq_v1", "seq_v1_wide", "seq_v2", "seq_v2_demo", "seq_v1_demo"])
+def test_har_sequence_vs_reference_golden(name):
+    d = load_golden(name)
+    variant = int(d["meta"][0])
+    got = run_hip(variant, d["P"], d["x"], None, None, d["dy"], d["dhT"], None, time_major=False)
+    compare_all(got, {"y": d["y"], "hT": d["hT"], "dx": d["dx"], "G": d["G"]}, name)
+
+
+@pytest.mark.parametrize("name", ["seq_v3", "seq_v4"])
+def test_lm_sequence_vs_reference_golden(name):
+    d = load_golden(name)
+    variant = int(d["meta"][0])
+    got = run_hip(variant, d["P"], d["x"], d["h0"], d["c0"], d["dy"], d["dhT"], d["dcT"], time_major=True)
+    compare_all(got, {k: d[k] for k in ("y", "hT", "cT", "dx", "dh0", "dc0", "G")}, name)
+
+
+def test_config_a_full_size_vs_reference_golden():
+    """BASELINE config A/B: B=64 T=128 I=9 H=180 rank 16 (the bench workload)."""
+    d = load_golden("cfgA_v1_uci")
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    P = O.make_params(O.V1, I, H, rw, ru, seed=int(d["seeds"][0]))
+    x, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][2]))).standard_normal((B, T, H)).astype(np.float32)
+    got = run_hip(O.V1, P, x, None, None, dy, None, None)
+    assert_out(got["y"][:, ::16], d["y_s"], "y")
+    assert_out(got["hT"], d["hT"], "hT")
+    assert_grad(got["dx"], d["dx"], "dx")
+    for k, v in d["G"].items():
+        assert_grad(got["G"][k], v, "G." + k)
+
+
+def test_config_a_group_full_size_vs_reference_golden():
+    d = load_golden("cfgA_v2_uci")
+    meta = [int(v) for v in d["meta"]]
+    _, B, T, I, H, rw = meta[:6]
+    ru = meta[6:]
+    P = O.make_params(O.V2, I, H, rw, ru, seed=int(d["seeds"][0]))
+    x, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][2]))).standard_normal((B, T, H)).astype(np.float32)
+    got = run_hip(O.V2, P, x, None, None, dy, None, None)
+    assert_out(got["y"][:, ::16], d["y_s"], "y")
+    assert_out(got["hT"], d["hT"], "hT")
+    assert_grad(got["dx"], d["dx"], "dx")
+    for k, v in d["G"].items():
+        assert_grad(got["G"][k], v, "G." + k)
+
+
+CASES = [
+    # variant, B, T, I, H, rw, ru, time_major, with_state
+    (O.V1, 3, 5, 4, 16, 2, [3], False, False),
+    (O.V1, 7, 9, 16, 64, 8, [8], False, True),       # exactly one full wave
+    (O.V1, 5, 4, 9, 65, 5, [11], True, True),        # one unit into the second wave, odd ranks
+    (O.V1, 2, 3, 30, 200, 16, [24], False, False),   # rank 24 (pass of 16 + half pass)
+    (O.V1, 3, 4, 12, 130, 32, [32], False, True),    # rank 32
+    (O.V1, 300, 3, 6, 40, 4, [4], False, False),     # B > 256: two rows per workgroup, odd tail
+    (O.V1, 513, 2, 6, 40, 4, [4], False, True),      # odd batch with R = 2
+    (O.V2, 4, 5, 6, 20, 3, [2, 5], False, False),
+    (O.V2, 3, 4, 10, 136, 8, [16, 8], False, True),  # two waves per group, second one ragged
+    (O.V2, 260, 2, 5, 24, 3, [4, 4], False, False),  # group cell with R = 2
+    (O.V3, 6, 5, 24, 24, 4, [6], True, True),
+    (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),     # batch != 40 (the reference cannot run this)
+    (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"v{c[0]}_B{c[1]}_T{c[2]}_I{c[3]}_H{c[4]}_r{c[5]}_{'x'.join(map(str, c[6]))}")
+def test_seeded_shapes_vs_oracle(case):
+    variant, B, T, I, H, rw, ru, tm, with_state = case
+    rng = np.random.Generator(np.random.PCG64(1000 + B + 7 * T + 13 * H))
+    P = O.make_params(variant, I, H, rw, ru if variant in (O.V2, O.V4) else ru[0], seed=H + rw)
+    shp = (T, B, I) if tm else (B, T, I)
+    x = rng.standard_normal(shp).astype(np.float32)
+    h0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    c0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    dcT = rng.standard_normal((B, H)).astype(np.float32)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
+    compare_all(got, ref, "case")
+
+
+def test_inference_mode_matches_training_forward():
+    P = O.make_params(O.V1, 9, 180, 16, 16, seed=3)
+    x, _ = O.synthetic_batch(16, 12, 9, seed=5)
+    a = run_hip(O.V1, P, x, None, None, np.ones((16, 12, 180), np.float32))
+    with torch.no_grad():
+        b = run_hip(O.V1, P, x)
+    assert np.array_equal(a["y"], b["y"])          # same kernels, bitwise
+
+
+def test_backward_is_deterministic():
+    P = O.make_params(O.V1, 9, 180, 16, 16, seed=3)
+    x, _ = O.synthetic_batch(64, 32, 9, seed=5)
+    dy = np.random.Generator(np.random.PCG64(9)).standard_normal((64, 32, 180)).astype(np.float32)
+    a = run_hip(O.V1, P, x, None, None, dy)
+    b = run_hip(O.V1, P, x, None, None, dy)
+    for k in a["G"]:
+        assert np.array_equal(a["G"][k], b["G"][k]), k
+    assert np.array_equal(a["dx"], b["dx"])
+
+
+def test_linearity_of_backward_in_upstream_gradient():
+    """Size-independent property at the full bench size: backward is linear in dy."""
+    P = O.make_params(O.V1, 9, 180, 16, 16, seed=3)
+    x, _ = O.synthetic_batch(64, 128, 9, seed=1234)
+    rng = np.random.Generator(np.random.PCG64(77))
+    d1 = rng.standard_normal((64, 128, 180)).astype(np.float32)
+    d2 = rng.standard_normal((64, 128, 180)).astype(np.float32)
+    g1 = run_hip(O.V1, P, x, None, None, d1)
+    g2 = run_hip(O.V1, P, x, None, None, d2)
+    g3 = run_hip(O.V1, P, x, None, None, d1 + 2 * d2)
+    for k in g1["G"]:
+        assert_grad(g1["G"][k] + 2 * g2["G"][k], g3["G"][k], "lin." + k, rel=2e-4)
+    assert_grad(g1["dx"] + 2 * g2["dx"], g3["dx"], "lin.dx", rel=2e-4)

@@ -1,0 +1,12 @@
+"""vmlmf_amd: the VMLMF compressed-LSTM forward/backward hot path as hand-written HIP kernels for
+MI355X (gfx950), behind the reference's own nn.Module API.
+
+    from vmlmf_amd import MyVMLMFCell, MyVMLMFCellg2, MyLSTM, Net      # HAR   (models/vmlmf*.py)
+    from vmlmf_amd import MyVMLSTM, MyVMLSTMGroup                      # LM    (models/vmlmf_lm.py)
+"""
+from .cells import MyVMLMFCell, MyVMLMFCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
+from .lm import MyVMLSTM, MyVMLSTMGroup
+from .functional import vmlmf_sequence
+
+__all__ = ["MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
+           "vmlmf_sequence"]

@@ -1,0 +1,113 @@
+"""ctypes binding of the C ABI in include/vmlmf_hip.h (libvmlmf_hip.so, built in-tree by csrc/Makefile).
+
+There is no CPU fallback: if the library is missing, or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvmlmf_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+MAX_G = 2
+NKERNELS = 8
+V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP = 1, 2, 3, 4
+E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
+
+_fp = ctypes.POINTER(ctypes.c_float)
+
+
+class Desc(ctypes.Structure):
+    _fields_ = [("variant", ctypes.c_int32), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
+                ("I", ctypes.c_int32), ("H", ctypes.c_int32), ("w_rank", ctypes.c_int32),
+                ("g", ctypes.c_int32), ("u_ranks", ctypes.c_int32 * MAX_G),
+                ("time_major", ctypes.c_int32), ("training", ctypes.c_int32)]
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("dia_x", ctypes.c_void_p), ("dia_h", ctypes.c_void_p), ("u_x", ctypes.c_void_p),
+                ("v_x", ctypes.c_void_p), ("b_x", ctypes.c_void_p), ("b_h", ctypes.c_void_p),
+                ("u_h", ctypes.c_void_p * MAX_G), ("v_h", ctypes.c_void_p * MAX_G)]
+
+
+class Sizes(ctypes.Structure):
+    _fields_ = [("workspace_bytes", ctypes.c_size_t), ("reserve_bytes", ctypes.c_size_t),
+                ("rows_per_wg", ctypes.c_int32), ("threads_per_wg", ctypes.c_int32),
+                ("workgroups", ctypes.c_int32), ("kx", ctypes.c_int32), ("kh", ctypes.c_int32)]
+
+
+# every symbol include/vmlmf_hip.h declares: (restype, argtypes)
+_vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+SYMBOLS = {
+    "vmlmf_abi_version": (_i, []),
+    "vmlmf_build_info": (ctypes.c_char_p, []),
+    "vmlmf_last_error": (ctypes.c_char_p, []),
+    "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),
+    "vmlmf_seq_forward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                               _vp, _vp, _sz, _vp]),
+    "vmlmf_seq_backward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                                _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp]),
+    "vmlmf_profile_enable": (_i, [_i]),
+    "vmlmf_profile_read": (_i, [_fp, ctypes.POINTER(ctypes.c_int32), _i]),
+    "vmlmf_kernel_name": (ctypes.c_char_p, [_i]),
+}
+
+_lib = None
+
+
+class VmlmfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"vmlmf_hip error {code}: {msg}")
+        self.code = code
+
+
+def build(force=False, jobs=8):
+    """Compile every HIP source for gfx950 into vmlmf_amd/lib/libvmlmf_hip.so (hipcc cross-compiles)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    subprocess.run(["make", "-C", CSRC, f"-j{jobs}"], check=True, stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    """The loaded shared library.  Raises if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+                "vmlmf_amd has no CPU / PyTorch fallback for the hot path.")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)  # AttributeError if the export is missing
+            fn.restype, fn.argtypes = res, args
+        if handle.vmlmf_abi_version() != 1:
+            raise RuntimeError("libvmlmf_hip.so ABI version mismatch: rebuild")
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise VmlmfError(rc, lib().vmlmf_last_error().decode())
+
+
+def make_desc(variant, B, T, I, H, w_rank, u_ranks, g=1, time_major=False, training=True):
+    d = Desc()
+    d.variant, d.B, d.T, d.I, d.H, d.w_rank = variant, B, T, I, H, w_rank
+    d.g = g
+    ur = list(u_ranks) if isinstance(u_ranks, (list, tuple)) else [u_ranks]
+    for i in range(MAX_G):
+        d.u_ranks[i] = int(ur[i]) if i < len(ur) else 0
+    d.time_major = 1 if time_major else 0
+    d.training = 1 if training else 0
+    return d
+
+
+def query(desc):
+    s = Sizes()
+    check(lib().vmlmf_query(ctypes.byref(desc), ctypes.byref(s)))
+    return s

@@ -1,0 +1,244 @@
+"""Drop-in counterparts of the reference's HAR modules, backed by the HIP kernels.
+
+Same constructor signatures, forward signatures, attribute names and parameter names/shapes as
+  MyVMLMFCell    V/src/models/vmlmf.py:38-125
+  MyVMLMFCellg2  V/src/models/vmlmf_group.py:37-155
+  MyLSTMCell     V/src/models/vmlmf.py:127-238   (baseline cell: stock GEMMs, not the hot path)
+  MyLSTM         V/src/models/vmlmf.py:241-316
+  Net            V/src/models/vmlmf.py:319-355
+so a reference checkpoint loads with load_state_dict and train.py / test.py run unchanged.
+What differs is how forward is evaluated: a VMLMF layer is ONE sequence-level kernel pipeline
+(vmlmf_amd.functional.vmlmf_sequence) instead of T cell calls of ~75 ATen ops each.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from . import _lib
+from .functional import vmlmf_sequence
+
+TIME_STEPS = 128
+RECURRENT_MAX = pow(2, 1 / TIME_STEPS)
+RECURRENT_MIN = pow(1 / 2, 1 / TIME_STEPS)
+
+
+def _delist(u_ranks):
+    return u_ranks[-1] if isinstance(u_ranks, list) and len(u_ranks) < 2 else u_ranks
+
+
+class MyVMLMFCell(nn.Module):
+    """VMLMF LSTM cell: diag(d) + (U V^T with its diagonal removed), shared d across the four gates."""
+
+    variant = _lib.V1_CELL
+
+    def __init__(self, input_size, hidden_size, w_rank=None, u_ranks=None):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.w_rank = w_rank
+        self.u_ranks = _delist(u_ranks)
+        r = self.u_ranks
+        # creation order == the reference's, so a seeded construction draws identical values
+        self.u_x = nn.Parameter(0.1 * torch.randn([input_size, w_rank]))
+        self.u_h = nn.Parameter(0.1 * torch.randn([hidden_size, r]))
+        self.v_x = nn.Parameter(0.1 * torch.randn([4 * hidden_size, w_rank]))
+        self.v_h = nn.Parameter(0.1 * torch.randn([4 * hidden_size, r]))
+        self.b_x = nn.Parameter(0.1 * torch.randn([4 * hidden_size]))
+        self.b_h = nn.Parameter(0.1 * torch.randn([4 * hidden_size]))
+        self.dia_x = nn.Parameter(0.1 * torch.randn([1, input_size]))
+        self.dia_h = nn.Parameter(0.1 * torch.randn([1, hidden_size]))
+        self.cnt = 0
+
+    def __repr__(self):
+        return (f"LSTM_FINAL(input: {self.input_size}, hidden: {self.hidden_size}, "
+                f"w_rank: {self.w_rank}, u_ranks: {self.u_ranks})")
+
+    # kernel-facing view of the parameters (order fixed by functional.py)
+    def kernel_params(self):
+        return (self.dia_x, self.dia_h, self.u_x, self.v_x, self.b_x, self.b_h, self.u_h, self.v_h)
+
+    def kernel_cfg(self):
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1)
+
+    def sequence(self, x, h0=None, c0=None, time_major=False):
+        """Whole-sequence evaluation: (y, hT, cT)."""
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+                              **self.kernel_cfg())
+
+    def forward(self, x, hidden_states):
+        """One step: x (B, I), (h, c) each (B, H) -> (h_next, c_next).  T = 1 of the same kernels."""
+        (h, c) = hidden_states
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        _, h_next, c_next = self.sequence(x.unsqueeze(1), h, c)
+        return h_next, c_next
+
+
+class MyVMLMFCellg2(nn.Module):
+    """Group-low-rank VMLMF cell (g groups, shift s couples group j to group (j+s) mod g)."""
+
+    variant = _lib.V2_GROUP_CELL
+
+    def __init__(self, input_size, hidden_size, w_rank=None, u_ranks=None, g=2,
+                 recurrent_init=None, hidden_init=None):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.recurrent_init = recurrent_init
+        self.hidden_init = hidden_init
+        self.w_rank = w_rank
+        self.u_ranks = u_ranks
+        self.g = g
+        self.layers = nn.ParameterDict()
+        self.layers['dia_x'] = nn.Parameter(0.1 * torch.randn([1, input_size]))
+        self.layers['dia_h'] = nn.Parameter(0.1 * torch.randn([1, hidden_size]))
+        self.layers['u_x'] = nn.Parameter(0.1 * torch.randn([input_size, w_rank]))
+        self.layers['v_x'] = nn.Parameter(0.1 * torch.randn([4 * hidden_size, w_rank]))
+        for s in range(self.g):
+            self.layers[f'u_h_{s}'] = nn.Parameter(0.1 * torch.randn([g, int(hidden_size / g), u_ranks[s]]))
+            self.layers[f'v_h_{s}'] = nn.Parameter(0.1 * torch.randn([g, u_ranks[s], 4 * int(hidden_size / g)]))
+        for vec in ['x', 'h']:
+            self.layers[f'bias_{vec}'] = nn.Parameter(torch.ones([1, 4 * hidden_size]))
+
+    def __repr__(self):
+        return (f"LSTM VM Group (input:{self.input_size}, hidden:{self.hidden_size}, "
+                f"w_rank:{self.w_rank}, u_ranks:{self.u_ranks}")
+
+    def kernel_params(self):
+        L = self.layers
+        out = [L['dia_x'], L['dia_h'], L['u_x'], L['v_x'], L['bias_x'], L['bias_h']]
+        for s in range(self.g):
+            out += [L[f'u_h_{s}'], L[f'v_h_{s}']]
+        return tuple(out)
+
+    def kernel_cfg(self):
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g)
+
+    def sequence(self, x, h0=None, c0=None, time_major=False):
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+                              **self.kernel_cfg())
+
+    def forward(self, x, hidden_states):
+        (h, c) = hidden_states
+        if x.dim() == 1:
+            x = x.unsqueeze(0)
+        _, h_next, c_next = self.sequence(x.unsqueeze(1), h, c)
+        return h_next, c_next
+
+
+class MyLSTMCell(nn.Module):
+    """Vanilla / plain low-rank LSTM cell of the reference (baseline, dense GEMMs through rocBLAS).
+    Outside the VMLMF hot path; kept so that MyLSTM(cell=MyLSTMCell) and Net's default keep working."""
+
+    def __init__(self, input_size, hidden_size, w_rank=None, u_ranks=None,
+                 recurrent_init=None, hidden_init=None):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.recurrent_init = recurrent_init
+        self.hidden_init = hidden_init
+        self.w_rank = w_rank
+        self.u_ranks = u_ranks[0] if isinstance(u_ranks, list) else u_ranks
+        I, H = input_size, hidden_size
+
+        def mk(*shape):
+            return nn.Parameter(0.1 * torch.randn(list(shape)))
+
+        if w_rank is None:
+            self.w1, self.w2, self.w3, self.w4 = mk(I, H), mk(I, H), mk(I, H), mk(I, H)
+        else:
+            self.w = mk(I, w_rank)
+            self.w1, self.w2, self.w3, self.w4 = mk(w_rank, H), mk(w_rank, H), mk(w_rank, H), mk(w_rank, H)
+        if u_ranks is None:
+            self.u1, self.u2, self.u3, self.u4 = mk(H, H), mk(H, H), mk(H, H), mk(H, H)
+        else:
+            r = self.u_ranks
+            self.u = mk(H, r)
+            self.u1, self.u2, self.u3, self.u4 = mk(r, H), mk(r, H), mk(r, H), mk(r, H)
+        self.bias_f = nn.Parameter(torch.ones([1, H]))
+        self.bias_i = nn.Parameter(torch.ones([1, H]))
+        self.bias_c = nn.Parameter(torch.ones([1, H]))
+        self.bias_o = nn.Parameter(torch.ones([1, H]))
+
+    def forward(self, x, hidden_states):
+        (h, c) = hidden_states
+        xin = x if self.w_rank is None else torch.matmul(x, self.w)
+        hin = h if self.u_ranks is None else torch.matmul(h, self.u)
+        pre = [torch.matmul(xin, w) + torch.matmul(hin, u)
+               for w, u in ((self.w1, self.u1), (self.w2, self.u2), (self.w3, self.u3), (self.w4, self.u4))]
+        i = torch.sigmoid(pre[0] + self.bias_i)
+        f = torch.sigmoid(pre[1] + self.bias_f)
+        o = torch.sigmoid(pre[2] + self.bias_o)
+        c_tilda = torch.tanh(pre[3] + self.bias_c)
+        c_next = f * c + i * c_tilda
+        return o * torch.tanh(c_next), c_next
+
+
+class MyLSTM(nn.Module):
+    """Stack of layers over a sequence.  VMLMF cells run one fused sequence pipeline per layer; any other
+    cell class falls back to the reference's per-timestep loop over that cell's own forward."""
+
+    def __init__(self, input_size, hidden_layer_sizes=None, batch_first=True,
+                 recurrent_inits=None, hidden_inits=None, w_rank=None, u_ranks=None,
+                 cell=MyLSTMCell, **kwargs):
+        super().__init__()
+        if hidden_layer_sizes is None:
+            hidden_layer_sizes = [32, 32]
+        self.input_size = input_size
+        self.hidden_layer_sizes = hidden_layer_sizes
+        self.batch_first = batch_first
+        self.w_rank = w_rank
+        self.drop = nn.Dropout(p=0.5)   # defined, never applied (vmlmf.py:268)
+        self.cell = cell
+        self.u_ranks = u_ranks[0] if isinstance(u_ranks, list) and len(u_ranks) < 2 else u_ranks
+        self.time_index, self.batch_index = (1, 0) if batch_first else (0, 1)
+        cells = []
+        in_size = input_size
+        for i, hidden_size in enumerate(hidden_layer_sizes):
+            if recurrent_inits is not None:
+                kwargs["recurrent_init"] = recurrent_inits[i]
+            if hidden_inits is not None:
+                kwargs["hidden_init"] = hidden_inits[i]
+            cells.append(self.cell(in_size, hidden_size, w_rank=self.w_rank, u_ranks=self.u_ranks, **kwargs))
+            in_size = hidden_size
+        self.rnncells = nn.ModuleList(cells)
+
+    def forward(self, x):
+        hiddens = []
+        for i, cell in enumerate(self.rnncells):
+            if hasattr(cell, "sequence"):
+                x, h, _ = cell.sequence(x, None, None, time_major=not self.batch_first)
+            else:
+                B = x.size(self.batch_index)
+                h = torch.zeros(B, self.hidden_layer_sizes[i], device=x.device)
+                c = torch.zeros(B, self.hidden_layer_sizes[i], device=x.device)
+                outs = []
+                for x_t in torch.unbind(x, self.time_index):
+                    h, c = cell(x_t, (h, c))
+                    outs.append(h)
+                x = torch.stack(outs, self.time_index)
+            hiddens.append(h)
+        return x, torch.cat(hiddens, -1)
+
+
+class Net(nn.Module):
+    """MyLSTM + Linear(H, 18) classifier on the last timestep (18 classes hard-coded, vmlmf.py:345)."""
+
+    def __init__(self, input_size, layer_sizes=None, w_rank=None, u_rank=None, model=MyLSTM, cell=MyLSTMCell):
+        super().__init__()
+        if layer_sizes is None:
+            layer_sizes = [32, 32]
+        self.rnn = model(input_size, hidden_layer_sizes=layer_sizes, batch_first=True,
+                         w_rank=w_rank, u_ranks=u_rank, cell=cell)
+        self.lin = nn.Linear(layer_sizes[-1], 18)
+        self.lin.bias.data.fill_(.1)
+        self.lin.weight.data.normal_(0, .01)
+        # the reference keeps an extra, never-trained cell "for unit_test" (vmlmf.py:349-350); its
+        # parameters are part of every reference checkpoint, so it is kept for state_dict compatibility
+        u = u_rank[-1] if cell == MyVMLMFCell else u_rank
+        self.cell = cell(input_size, layer_sizes[-1], w_rank=w_rank, u_ranks=u)
+
+    def forward(self, x):
+        y, _ = self.rnn(x)
+        return self.lin(y[:, -1]).squeeze(1)

@@ -1,0 +1,342 @@
+// Host side of the C ABI (include/vmlmf_hip.h): descriptor validation, launch geometry, buffer layout,
+// and the kernel sequences of one layer's forward / backward.  No torch, no allocation, no sync.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/vmlmf_hip.h"
+#include "vmlmf_launch.h"
+
+namespace {
+
+thread_local std::string g_err = "";
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+// ---- profiling (bench.py): HIP event pairs around every internal launch, on the launch stream ----
+constexpr int NKERN = 8;
+struct Prof {
+  std::mutex mu;
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NKERN];
+} g_prof;
+
+struct Scope {
+  int k;
+  hipStream_t s;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  Scope(int which, hipStream_t st) : k(which), s(st) {
+    if (g_prof.on) {
+      hipEventCreate(&e0);
+      hipEventCreate(&e1);
+      hipEventRecord(e0, s);
+    }
+  }
+  ~Scope() {
+    if (e0 != nullptr) {
+      hipEventRecord(e1, s);
+      std::lock_guard<std::mutex> lk(g_prof.mu);
+      g_prof.ev[k].push_back({e0, e1});
+    }
+  }
+};
+
+long long align64(long long v) { return (v + 63) / 64 * 64; }
+
+// ---- geometry ----
+int make_geo(const vmlmf_desc* d, VGeo* out) {
+  if (d == nullptr) return fail(VMLMF_E_BADARG, "null descriptor");
+  VGeo g;
+  memset(&g, 0, sizeof(g));
+  g.variant = d->variant;
+  g.B = d->B;
+  g.T = d->T;
+  g.I = d->I;
+  g.H = d->H;
+  g.rw = d->w_rank;
+  if (g.variant < 1 || g.variant > 4) return fail(VMLMF_E_BADARG, "variant must be 1..4");
+  if (g.B < 1 || g.T < 1 || g.I < 1 || g.H < 1 || g.rw < 1)
+    return fail(VMLMF_E_BADARG, "B, T, I, H, w_rank must be positive");
+  const bool grouped = g.variant == VMLMF_V2_GROUP_CELL || g.variant == VMLMF_V4_LM_GROUP;
+  const bool lm = g.variant == VMLMF_V3_LM || g.variant == VMLMF_V4_LM_GROUP;
+  g.G = grouped ? d->g : 1;
+  if (grouped && g.G < 1) return fail(VMLMF_E_BADARG, "g must be positive");
+  if (g.G > VMLMF_MAX_G)
+    return fail(VMLMF_E_UNSUPPORTED, "g > 2 is not covered by the HIP kernels (the reference never builds it)");
+  if (g.H % g.G != 0) return fail(VMLMF_E_SHAPE, "hidden_size must be divisible by g (vmlmf_group.py:73)");
+  // the reference fails on these shapes too (vmlmf.py:94 / vmlmf_lm.py:243)
+  if (!lm && g.I > g.H) return fail(VMLMF_E_SHAPE, "input_size > hidden_size: the reference cell raises (vmlmf.py:94,103)");
+  if (lm && g.I != g.H) return fail(VMLMF_E_SHAPE, "LM layers need input_size == hidden_size (vmlmf_lm.py:243)");
+  g.ru0 = d->u_ranks[0];
+  g.ru1 = g.G == 2 ? d->u_ranks[1] : 0;
+  if (g.ru0 < 1 || (g.G == 2 && g.ru1 < 1)) return fail(VMLMF_E_BADARG, "u_ranks must be positive");
+  g.Hg = g.H / g.G;
+  g.W = (g.Hg + 63) / 64;
+  g.NW = g.G * g.W;
+  g.NT = g.NW * 64;
+  g.off1 = vg_pad8(g.ru0);
+  g.KH = g.off1 + (g.G == 2 ? vg_pad8(g.ru1) : 0);
+  g.KX = vg_pad8(g.rw);
+  g.NP = (g.KH + 15) / 16;
+  g.KQ = g.NP * 16;
+  g.NPX = (g.KX + 15) / 16;
+  g.KQX = g.NPX * 16;
+  g.flat = g.variant == VMLMF_V4_LM_GROUP ? 1 : 0;
+  g.hperm = g.variant == VMLMF_V2_GROUP_CELL ? 1 : 0;
+  g.time_major = d->time_major ? 1 : 0;
+  g.training = d->training ? 1 : 0;
+  if (g.time_major) {
+    g.sxT = (long long)g.B * g.I;
+    g.sxB = g.I;
+    g.syT = (long long)g.B * g.H;
+    g.syB = g.H;
+  } else {
+    g.sxT = g.I;
+    g.sxB = (long long)g.T * g.I;
+    g.syT = g.H;
+    g.syB = (long long)g.T * g.H;
+  }
+  if (g.KH > 32 || g.KX > 32)
+    return fail(VMLMF_E_UNSUPPORTED, "padded rank > 32: the register-resident kernels hold at most 32 ranks per path");
+  if (g.NT > 512)
+    return fail(VMLMF_E_UNSUPPORTED, "hidden_size needs > 512 threads per workgroup: not instantiated yet");
+  // rows per workgroup: one row per CU while the batch fits the chip once, then two
+  g.R = (g.B <= 256 || g.flat) ? 1 : 2;
+  g.nwg = (g.B + g.R - 1) / g.R;
+  // wgrad chunking: about one workgroup per CU, LDS partials <= 48 KiB
+  const int TB = g.T * g.B;
+  int rc = (TB + 255) / 256;
+  if (rc < 8) rc = 8;
+  const int rc_lds = (48 * 1024) / (4 * g.NW * g.KQX);
+  if (rc > rc_lds) rc = rc_lds;
+  g.RC = rc;
+  g.nblk = (TB + rc - 1) / rc;
+  g.NA = 5 * g.KX + 5 * g.KH + 12;
+  *out = g;
+  return 0;
+}
+
+// ---- buffer layouts (float offsets) ----
+struct Layout {
+  // reserve (training) : PACK | qx | gates | cs | Qs
+  long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
+  // forward workspace  : PACK (inference only) | gx
+  long long f_pack, f_gx, f_total;
+  // backward workspace : dpre | dQs | wpart | cgrad
+  long long b_dpre, b_dQs, b_wpart, b_cgrad, b_total;
+};
+
+Layout make_layout(const VGeo& g, const VPack& P) {
+  Layout L;
+  const long long TB = (long long)g.T * g.B;
+  long long o = 0;
+  L.r_pack = o, o += align64(P.total);
+  L.r_qx = o, o += align64(TB * g.KX);
+  L.r_gates = o, o += align64(TB * g.H * 4);
+  L.r_cs = o, o += align64(TB * g.H);
+  L.r_Qs = o, o += align64(TB * g.G * g.KH);
+  L.r_total = o;
+  o = 0;
+  L.f_pack = o, o += align64(P.total);
+  L.f_gx = o, o += align64(TB * g.H * 4);
+  L.f_total = o;
+  o = 0;
+  L.b_dpre = o, o += align64(TB * g.H * 4);
+  L.b_dQs = o, o += align64(TB * g.G * g.KH);
+  L.b_wpart = o, o += align64((long long)g.nblk * g.NA * g.NT);
+  L.b_cgrad = o, o += align64((long long)g.NA * g.NT);
+  L.b_total = o;
+  return L;
+}
+
+RefP to_refp(const vmlmf_params* p) {
+  RefP r;
+  r.dia_x = p->dia_x, r.dia_h = p->dia_h, r.u_x = p->u_x, r.v_x = p->v_x, r.b_x = p->b_x, r.b_h = p->b_h;
+  r.u_h0 = p->u_h[0], r.u_h1 = p->u_h[1], r.v_h0 = p->v_h[0], r.v_h1 = p->v_h[1];
+  return r;
+}
+
+int check_params(const VGeo& g, const vmlmf_params* p) {
+  if (p == nullptr) return fail(VMLMF_E_BADARG, "null params");
+  if (!p->dia_x || !p->dia_h || !p->u_x || !p->v_x || !p->b_x || !p->b_h || !p->u_h[0] || !p->v_h[0])
+    return fail(VMLMF_E_BADARG, "null parameter pointer");
+  if (g.G == 2 && (!p->u_h[1] || !p->v_h[1])) return fail(VMLMF_E_BADARG, "group variant needs u_h[1], v_h[1]");
+  return 0;
+}
+
+int hip_fail(int rc, const char* what) {
+  if (rc == 0) return 0;
+  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, std::string(what) + ": no kernel instantiation for this geometry");
+  return fail(rc, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmlmf_abi_version(void) { return VMLMF_ABI_VERSION; }
+
+const char* vmlmf_build_info(void) { return "vmlmf_hip gfx950 fp32 persistent-rnn (register-resident U/V, DPP rank reduce)"; }
+
+const char* vmlmf_last_error(void) { return g_err.c_str(); }
+
+int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
+  if (out == nullptr) return fail(VMLMF_E_BADARG, "null sizes");
+  VGeo g;
+  const int rc = make_geo(d, &g);
+  if (rc != 0) return rc;
+  const VPack P = vg_pack_layout(g);
+  const Layout L = make_layout(g, P);
+  const long long ws = L.f_total > L.b_total ? L.f_total : L.b_total;
+  out->workspace_bytes = (size_t)ws * sizeof(float);
+  out->reserve_bytes = (size_t)L.r_total * sizeof(float);
+  out->rows_per_wg = g.R;
+  out->threads_per_wg = g.NT;
+  out->workgroups = g.nwg;
+  out->kx = g.KX;
+  out->kh = g.KH;
+  return 0;
+}
+
+int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                      const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
+                      size_t workspace_bytes, void* stream) {
+  VGeo g;
+  int rc = make_geo(d, &g);
+  if (rc != 0) return rc;
+  if ((rc = check_params(g, p)) != 0) return rc;
+  if (x == nullptr || y == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "null x / y / workspace");
+  if (g.training && reserve == nullptr) return fail(VMLMF_E_BADARG, "training forward needs a reserve buffer");
+  const VPack P = vg_pack_layout(g);
+  const Layout L = make_layout(g, P);
+  if (workspace_bytes < (size_t)L.f_total * sizeof(float))
+    return fail(VMLMF_E_WORKSPACE, "workspace smaller than vmlmf_query() reported");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  float* rs = (float*)reserve;
+  float* pack = g.training ? rs + L.r_pack : ws + L.f_pack;
+  float* gx = ws + L.f_gx;
+  const RefP rp = to_refp(p);
+  {
+    Scope sc(0, s);
+    if ((rc = hip_fail(launch_pack(g, rp, P, pack, s), "pack")) != 0) return rc;
+  }
+  {
+    Scope sc(1, s);
+    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : nullptr, s), "xproj")) != 0)
+      return rc;
+  }
+  FwdArgs a;
+  a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
+  a.y = y, a.hT = hT, a.cT = cT;
+  a.gates = g.training ? rs + L.r_gates : nullptr;
+  a.cs = g.training ? rs + L.r_cs : nullptr;
+  a.Qs = g.training ? rs + L.r_Qs : nullptr;
+  {
+    Scope sc(2, s);
+    if ((rc = hip_fail(launch_rec_fwd(g, a, s), "rec_fwd")) != 0) return rc;
+  }
+  return 0;
+}
+
+int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                       const float* c0, const float* y, const void* reserve, const float* dy,
+                       const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
+                       const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream) {
+  VGeo g;
+  int rc = make_geo(d, &g);
+  if (rc != 0) return rc;
+  if ((rc = check_params(g, p)) != 0) return rc;
+  if (x == nullptr || y == nullptr || reserve == nullptr || workspace == nullptr || gr == nullptr)
+    return fail(VMLMF_E_BADARG, "null x / y / reserve / workspace / grads");
+  if (!gr->dia_x || !gr->dia_h || !gr->u_x || !gr->v_x || !gr->b_x || !gr->b_h || !gr->u_h[0] || !gr->v_h[0] ||
+      (g.G == 2 && (!gr->u_h[1] || !gr->v_h[1])))
+    return fail(VMLMF_E_BADARG, "null gradient pointer");
+  const VPack P = vg_pack_layout(g);
+  const Layout L = make_layout(g, P);
+  if (workspace_bytes < (size_t)L.b_total * sizeof(float))
+    return fail(VMLMF_E_WORKSPACE, "workspace smaller than vmlmf_query() reported");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const float* rs = (const float*)reserve;
+  const float* pack = rs + L.r_pack;
+  BwdArgs a;
+  a.gates = rs + L.r_gates, a.cs = rs + L.r_cs, a.c0 = c0, a.dy = dy, a.dhT = dhT, a.dcT = dcT;
+  a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
+  a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0;
+  {
+    Scope sc(3, s);
+    if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
+  }
+  WgxArgs wx;
+  wx.dpre = ws + L.b_dpre, wx.x = x, wx.qx = rs + L.r_qx;
+  wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
+  wx.dx = dx, wx.wpart = ws + L.b_wpart;
+  {
+    Scope sc(4, s);
+    if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "wgrad_x")) != 0) return rc;
+  }
+  WghArgs wh;
+  wh.dpre = ws + L.b_dpre, wh.y = y, wh.h0 = h0, wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs;
+  wh.wpart = ws + L.b_wpart;
+  {
+    Scope sc(5, s);
+    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad_h")) != 0) return rc;
+  }
+  {
+    Scope sc(6, s);
+    if ((rc = hip_fail(launch_reduce(g, ws + L.b_wpart, ws + L.b_cgrad, s), "reduce")) != 0) return rc;
+  }
+  RefG og;
+  og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
+  og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+  {
+    Scope sc(7, s);
+    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, s), "finish")) != 0) return rc;
+  }
+  return 0;
+}
+
+int vmlmf_profile_enable(int enable) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  g_prof.on = enable != 0;
+  return 0;
+}
+
+int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
+  std::lock_guard<std::mutex> lk(g_prof.mu);
+  for (int k = 0; k < NKERN; ++k) {
+    float sum = 0.f;
+    for (auto& pr : g_prof.ev[k]) {
+      hipEventSynchronize(pr.second);
+      float ms = 0.f;
+      hipEventElapsedTime(&ms, pr.first, pr.second);
+      sum += ms * 1000.f;
+    }
+    if (usec_sum != nullptr) usec_sum[k] = sum;
+    if (count != nullptr) count[k] = (int32_t)g_prof.ev[k].size();
+    if (reset) {
+      for (auto& pr : g_prof.ev[k]) {
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+      }
+      g_prof.ev[k].clear();
+    }
+  }
+  return 0;
+}
+
+const char* vmlmf_kernel_name(int k) {
+  static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
+                                     "wgrad_x_kernel", "wgrad_h_kernel", "reduce_kernel",  "finish_kernel"};
+  return (k >= 0 && k < NKERN) ? names[k] : "";
+}
+
+}  // extern "C"

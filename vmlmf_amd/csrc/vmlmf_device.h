@@ -1,0 +1,131 @@
+// Device-side helpers: reference-layout accessors, DPP row rotation, wave reductions, fast gates.
+// gfx950 (CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <utility>
+#include "vmlmf_geo.h"
+
+// Parameter pointers in the reference's layouts (include/vmlmf_hip.h: vmlmf_params).
+struct RefP {
+  const float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h, *u_h0, *u_h1, *v_h0, *v_h1;
+};
+struct RefG {
+  float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h, *u_h0, *u_h1, *v_h0, *v_h1;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// compile-time loops (DPP controls must be immediates)
+// ---------------------------------------------------------------------------------------------------
+template <class F, int... Is>
+__device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void sfor(F&& f) {
+  sfor_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Rotate a value by K lanes inside each 16-lane DPP row (row_ror:K).  Which neighbour a lane receives
+// from is calibrated at pack time by applying the same instruction to lane ids (pack_kernel), so the
+// register images match the hardware's direction by construction.
+template <int K>
+__device__ __forceinline__ float ror16(float v) {
+  if constexpr (K == 0) {
+    return v;
+  } else {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + K, 0xf, 0xf, true));
+  }
+}
+
+// Sum over the four 16-lane rows of a wave: every lane i ends with v[i] + v[i+16] + v[i+32] + v[i+48].
+__device__ __forceinline__ float rowsum4(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+
+// v_exp_f32 / v_rcp_f32 based gates (about 2 ulp; the parity tests bound the end-to-end error).
+__device__ __forceinline__ float fast_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float fast_tanh(float x) {
+  // tanh(x) = 1 - 2 / (1 + exp(2x)); saturates cleanly for large |x|
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) {
+  return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// canonical element <- reference layouts (oracle/vmlmf_oracle.py: canonicalize)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int vg_hchunk(const VGeo& g, int k) { return g.hperm ? (k ^ 1) : k; }
+
+__device__ inline float ref_ux(const VGeo& g, const RefP& p, int m, int r) {
+  return r < g.rw ? p.u_x[(size_t)m * g.rw + r] : 0.f;
+}
+__device__ inline float ref_vx(const VGeo& g, const RefP& p, int n, int k, int r) {
+  return r < g.rw ? p.v_x[((size_t)k * g.H + n) * g.rw + r] : 0.f;
+}
+// unit n's contribution weight to rank rr of the concatenated rank space
+__device__ inline float ref_uc(const VGeo& g, const RefP& p, int n, int rr) {
+  const int s = (g.G == 2 && rr >= g.off1) ? 1 : 0;
+  const int r = rr - (s ? g.off1 : 0);
+  const int rus = s ? g.ru1 : g.ru0;
+  if (r >= rus) return 0.f;
+  const float* u = s ? p.u_h1 : p.u_h0;
+  if (g.G == 1) return u[(size_t)n * rus + r];
+  const int grp = n / g.Hg, m = n - grp * g.Hg;
+  const int j = (grp - s + g.G) % g.G;  // destination group of shift s
+  return u[((size_t)j * g.Hg + m) * rus + r];
+}
+// (Q vector, column) that gate k of unit n reads in the (g, r, 4Hg) matrices
+__device__ inline void vg_vc_loc(const VGeo& g, int n, int k, int& q, int& col) {
+  if (g.flat) {
+    const int f = k * g.H + n;
+    q = f / (4 * g.Hg);
+    col = f - q * 4 * g.Hg;
+  } else {
+    q = n / g.Hg;
+    col = vg_hchunk(g, k) * g.Hg + (n - q * g.Hg);
+  }
+}
+__device__ inline float ref_vc(const VGeo& g, const RefP& p, int n, int k, int rr) {
+  const int s = (g.G == 2 && rr >= g.off1) ? 1 : 0;
+  const int r = rr - (s ? g.off1 : 0);
+  const int rus = s ? g.ru1 : g.ru0;
+  if (r >= rus) return 0.f;
+  const float* v = s ? p.v_h1 : p.v_h0;
+  if (g.G == 1) return v[((size_t)k * g.H + n) * rus + r];
+  int q, col;
+  vg_vc_loc(g, n, k, q, col);
+  return v[((size_t)q * rus + r) * (4 * g.Hg) + col];
+}
+__device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
+  return p.b_x[k * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
+}
+// hoisted diagonal-removal vectors (vmlmf.py:102-106 recomputes them every timestep)
+__device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
+  float acc = 0.f;
+  for (int r = 0; r < g.ru0; ++r) acc = fmaf(ref_uc(g, p, n, r), ref_vc(g, p, n, k, r), acc);
+  return p.dia_h[n] - acc;
+}
+__device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {
+  if (n >= g.I) return 0.f;
+  float acc = 0.f;
+  for (int r = 0; r < g.rw; ++r) acc = fmaf(ref_ux(g, p, n, r), ref_vx(g, p, n, k, r), acc);
+  return p.dia_x[n] - acc;
+}
+
+// thread slot -> unit
+__device__ __forceinline__ bool vg_slot_unit(const VGeo& g, int slot, int& n) {
+  const int grp = slot / (64 * g.W);
+  const int m = slot - grp * 64 * g.W;
+  n = grp * g.Hg + m;
+  return m < g.Hg;
+}

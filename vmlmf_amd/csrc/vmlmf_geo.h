@@ -1,0 +1,75 @@
+// Geometry shared by host launch code and device kernels (gfx950 only; wave = 64 lanes).
+//
+// Thread <-> hidden-unit map of the persistent kernels.  A workgroup has NT = G * W * 64 threads; the G
+// groups of the hidden->hidden path are wave-aligned (W waves each), so that a wave's rank-space partial
+// sums belong to exactly one source group:
+//     grp = tid / (64 W),  m = tid % (64 W),  unit n = grp * Hg + m  (valid iff m < Hg).
+//
+// Rank space.  Shift s of the group path has rank ru[s]; blocks are padded to multiples of 8 and
+// concatenated: block 0 = [0, off1), block 1 = [off1, KH).  KX = pad8(w_rank).  The reductions run in
+// passes of 16 ranks (one rank per lane of a 16-lane DPP row): NP = ceil(KH/16), KQ = 16 NP.
+#pragma once
+#include <stdint.h>
+
+struct VGeo {
+  int variant, B, T, I, H, rw, G, Hg, W, NT, NW;
+  int ru0, ru1, off1;
+  int KX, KH, NP, KQ, NPX, KQX;
+  int flat;   // V4: [B, g*4Hg] flattened then chunked (vmlmf_lm.py:135,155): gate k picks Q[k / 2]
+  int hperm;  // V2: h-side chunks are (f,i,n,o) (vmlmf_group.py:134,149-152)
+  int R;      // batch rows per workgroup
+  int nwg;    // workgroups of the recurrent kernels
+  int RC;     // (t,b) rows per wgrad workgroup
+  int nblk;   // wgrad workgroups
+  int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12
+  long long sxT, sxB, syT, syB;  // element strides of x/dx and y/dy
+  int time_major, training;
+};
+
+// float offsets inside the PACK region (parameter images, produced by pack_kernel)
+struct VPack {
+  long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT, total;
+};
+
+#ifdef __HIPCC__
+#define VG_HD __host__ __device__ inline
+#else
+#define VG_HD inline
+#endif
+
+VG_HD int vg_pad8(int v) { return (v + 7) / 8 * 8; }
+
+VG_HD VPack vg_pack_layout(const VGeo& g) {
+  VPack p;
+  long long o = 0;
+  auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
+  p.VE = take(4LL * g.KH * g.NT);
+  p.UR = take(1LL * g.KQ * g.NT);
+  p.VR = take(4LL * g.KQ * g.NT);
+  p.UE = take(1LL * g.KH * g.NT);
+  p.EH = take(4LL * g.NT);
+  p.VRX = take(4LL * g.KQX * g.NT);
+  p.UXO = take(1LL * g.KX * g.NT);
+  p.EXI = take(4LL * g.NT);
+  p.UXP = take(1LL * g.I * g.KX);
+  p.VXT = take(4LL * g.KX * g.H);
+  p.EXT = take(4LL * g.H);
+  p.BBT = take(4LL * g.H);
+  p.total = o;
+  return p;
+}
+
+// wgrad accumulator indices (per thread slot)
+VG_HD int va_vx(const VGeo& g, int k, int r) { return k * g.KX + r; }
+VG_HD int va_vc(const VGeo& g, int k, int rr) { return 4 * g.KX + k * g.KH + rr; }
+VG_HD int va_uc(const VGeo& g, int rr) { return 4 * g.KX + 4 * g.KH + rr; }
+VG_HD int va_ux(const VGeo& g, int r) { return 4 * g.KX + 5 * g.KH + r; }
+VG_HD int va_eh(const VGeo& g, int k) { return 5 * g.KX + 5 * g.KH + k; }
+VG_HD int va_ex(const VGeo& g, int k) { return 5 * g.KX + 5 * g.KH + 4 + k; }
+VG_HD int va_b(const VGeo& g, int k) { return 5 * g.KX + 5 * g.KH + 8 + k; }
+
+// thread slot of hidden unit n
+VG_HD int vg_slot(const VGeo& g, int n) {
+  int grp = n / g.Hg;
+  return grp * 64 * g.W + (n - grp * g.Hg);
+}

@@ -1,0 +1,36 @@
+// Internal launcher interface between the API translation unit and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vmlmf_device.h"
+
+struct FwdArgs {
+  const float *gx, *VE, *UR, *EH, *h0, *c0;
+  float *y, *hT, *cT, *gates, *cs, *Qs;
+};
+struct BwdArgs {
+  const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
+  float *dpre, *dQs, *dh0, *dc0;
+};
+struct WgxArgs {
+  const float *dpre, *x, *qx, *VRX, *UXO, *EXI;
+  float *dx, *wpart;
+};
+struct WghArgs {
+  const float *dpre, *y, *h0, *Qs, *dQs;
+  float* wpart;
+};
+
+// every launcher returns hipGetLastError() of its launch, or VMLMF_E_UNSUPPORTED (-3) when no
+// instantiation covers the geometry
+int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s);
+int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
+                 hipStream_t s);
+int launch_rec_fwd(const VGeo& g, const FwdArgs& a, hipStream_t s);
+int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
+int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
+int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s);
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s);
+
+// register budget of the persistent kernels: which (KH, NT) pairs are instantiated
+bool rec_supported(const VGeo& g);

@@ -1,0 +1,334 @@
+// Parameter-side and fully-parallel kernels of the VMLMF hot path (gfx950):
+//   pack_kernel    reference-layout parameters -> per-thread register images (+ hoisted ex/eh vectors)
+//   xproj_kernel   gx[t,b,n,k] = (x_t U_x) V_x^T + x .* ex + (b_x + b_h)   for all (t,b) at once
+//   reduce_kernel  deterministic sum of the wgrad workgroups' partial accumulators
+//   finish_kernel  canonical gradients -> reference-layout gradients (folds d(ex), d(eh) into dia/U/V)
+#include "vmlmf_launch.h"
+
+// ---------------------------------------------------------------------------------------------------
+// pack
+// ---------------------------------------------------------------------------------------------------
+// Image element (j, slot) is register j of the thread in slot `slot`.  Rotated images serve the DPP
+// reductions: in pass p, step kk, lane i of a 16-lane row multiplies the value it RECEIVES from lane
+// src = i + sgn*kk (mod 16) with the weight that couples that source unit to rank p*16 + i.
+__global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
+  const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
+  const int NT = g.NT;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < L.total; e += stride) {
+    float v = 0.f;
+    if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
+      const long long le = e - L.VE;
+      if (le < 4LL * g.KH * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KH, rr = j % g.KH;
+        int n;
+        if (vg_slot_unit(g, slot, n)) v = ref_vc(g, p, n, k, rr);
+      }
+    } else if (e < L.VR) {  // UR[(p*16+kk)][slot] = uc(n(src), p*16+i)
+      const long long le = e - L.UR;
+      if (le < 1LL * g.KQ * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), pp = j / 16, kk = j % 16, i = slot & 15;
+        const int src = (slot & ~15) | ((i + sgn * kk) & 15);
+        int n;
+        if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_uc(g, p, n, pp * 16 + i);
+      }
+    } else if (e < L.UE) {  // VR[(k*KQ + p*16+kk)][slot] = vc(n(src), k, p*16+i)
+      const long long le = e - L.VR;
+      if (le < 4LL * g.KQ * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KQ, jj = j % g.KQ;
+        const int pp = jj / 16, kk = jj % 16, i = slot & 15;
+        const int src = (slot & ~15) | ((i + sgn * kk) & 15);
+        int n;
+        if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_vc(g, p, n, k, pp * 16 + i);
+      }
+    } else if (e < L.EH) {  // UE[rr][slot] = uc(n, rr)
+      const long long le = e - L.UE;
+      if (le < 1LL * g.KH * NT) {
+        const int rr = (int)(le / NT), slot = (int)(le % NT);
+        int n;
+        if (vg_slot_unit(g, slot, n)) v = ref_uc(g, p, n, rr);
+      }
+    } else if (e < L.VRX) {  // EH[k][slot]
+      const long long le = e - L.EH;
+      if (le < 4LL * NT) {
+        const int k = (int)(le / NT), slot = (int)(le % NT);
+        int n;
+        if (vg_slot_unit(g, slot, n)) v = ref_eh(g, p, n, k);
+      }
+    } else if (e < L.UXO) {  // VRX[(k*KQX + p*16+kk)][slot] = vx(n(src), k, p*16+i)
+      const long long le = e - L.VRX;
+      if (le < 4LL * g.KQX * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KQX, jj = j % g.KQX;
+        const int pp = jj / 16, kk = jj % 16, i = slot & 15;
+        const int src = (slot & ~15) | ((i + sgn * kk) & 15);
+        int n;
+        if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KX) v = ref_vx(g, p, n, k, pp * 16 + i);
+      }
+    } else if (e < L.EXI) {  // UXO[r][slot] = ux(n, r) for x-units
+      const long long le = e - L.UXO;
+      if (le < 1LL * g.KX * NT) {
+        const int r = (int)(le / NT), slot = (int)(le % NT);
+        int n;
+        if (vg_slot_unit(g, slot, n) && n < g.I) v = ref_ux(g, p, n, r);
+      }
+    } else if (e < L.UXP) {  // EXI[k][slot]
+      const long long le = e - L.EXI;
+      if (le < 4LL * NT) {
+        const int k = (int)(le / NT), slot = (int)(le % NT);
+        int n;
+        if (vg_slot_unit(g, slot, n)) v = ref_ex(g, p, n, k);
+      }
+    } else if (e < L.VXT) {  // UXP[m][r]  row-major, rank padded
+      const long long le = e - L.UXP;
+      if (le < 1LL * g.I * g.KX) v = ref_ux(g, p, (int)(le / g.KX), (int)(le % g.KX));
+    } else if (e < L.EXT) {  // VXT[(k*KX+r)][n]
+      const long long le = e - L.VXT;
+      if (le < 4LL * g.KX * g.H) {
+        const int j = (int)(le / g.H), n = (int)(le % g.H);
+        v = ref_vx(g, p, n, j / g.KX, j % g.KX);
+      }
+    } else if (e < L.BBT) {  // EXT[k][n]
+      const long long le = e - L.EXT;
+      if (le < 4LL * g.H) v = ref_ex(g, p, (int)(le % g.H), (int)(le / g.H));
+    } else {  // BBT[k][n]
+      const long long le = e - L.BBT;
+      if (le < 4LL * g.H) v = ref_bb(g, p, (int)(le % g.H), (int)(le / g.H));
+    }
+    out[e] = v;
+  }
+}
+
+int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s) {
+  const int blocks = (int)((L.total + 255) / 256);
+  hipLaunchKernelGGL(pack_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, g, p, L, pack);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// xproj: the non-recurrent half of the gate pre-activations for every (t,b) row
+// ---------------------------------------------------------------------------------------------------
+constexpr int XR = 16;  // rows per workgroup
+
+template <int KX>
+__global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restrict__ x,
+                                                    const float* __restrict__ uxp,
+                                                    const float* __restrict__ vxt,
+                                                    const float* __restrict__ ext,
+                                                    const float* __restrict__ bbt, float* __restrict__ gx,
+                                                    float* __restrict__ qx) {
+  extern __shared__ float4 smem4[];
+  float* xs = reinterpret_cast<float*>(smem4);  // [XR][I]
+  float* qs = xs + XR * g.I;                    // [XR][KX]
+  const int tid = threadIdx.x;
+  const int TB = g.T * g.B, I = g.I, H = g.H;
+  const int row0 = blockIdx.x * XR;
+  for (int idx = tid; idx < XR * I; idx += 256) {
+    const int r = idx / I, m = idx - r * I, row = row0 + r;
+    float v = 0.f;
+    if (row < TB) {
+      const int t = row / g.B, b = row - t * g.B;
+      v = x[t * g.sxT + b * g.sxB + m];
+    }
+    xs[idx] = v;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < XR * KX; idx += 256) {
+    const int r = idx / KX, j = idx - r * KX;
+    float acc = 0.f;
+    for (int m = 0; m < I; ++m) acc = fmaf(xs[r * I + m], uxp[m * KX + j], acc);
+    qs[idx] = acc;
+    if (qx != nullptr && row0 + r < TB) qx[(size_t)(row0 + r) * KX + j] = acc;
+  }
+  __syncthreads();
+  for (int n = tid; n < H; n += 256) {
+    float v[4][KX], e[4], bb[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int r = 0; r < KX; ++r) v[k][r] = vxt[(size_t)(k * KX + r) * H + n];
+      e[k] = ext[k * H + n];
+      bb[k] = bbt[k * H + n];
+    }
+    for (int r = 0; r < XR; ++r) {
+      const int row = row0 + r;
+      if (row >= TB) break;
+      const float xv = (n < I) ? xs[r * I + n] : 0.f;
+      float pre[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) pre[k] = fmaf(xv, e[k], bb[k]);
+#pragma unroll
+      for (int j4 = 0; j4 < KX / 4; ++j4) {
+        const float4 q = ld4(qs + r * KX + 4 * j4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          pre[k] = fmaf(q.x, v[k][4 * j4 + 0], pre[k]);
+          pre[k] = fmaf(q.y, v[k][4 * j4 + 1], pre[k]);
+          pre[k] = fmaf(q.z, v[k][4 * j4 + 2], pre[k]);
+          pre[k] = fmaf(q.w, v[k][4 * j4 + 3], pre[k]);
+        }
+      }
+      st4(gx + ((size_t)row * H + n) * 4, make_float4(pre[0], pre[1], pre[2], pre[3]));
+    }
+  }
+}
+
+int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
+                 hipStream_t s) {
+  const int TB = g.T * g.B;
+  const dim3 grid((TB + XR - 1) / XR), block(256);
+  const size_t lds = sizeof(float) * (size_t)(XR * g.I + XR * g.KX);
+  const float *uxp = pack + L.UXP, *vxt = pack + L.VXT, *ext = pack + L.EXT, *bbt = pack + L.BBT;
+#define VX_CASE(K)                                                                                     \
+  case K:                                                                                              \
+    hipLaunchKernelGGL(xproj_kernel<K>, grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);        \
+    break;
+  switch (g.KX) {
+    VX_CASE(8)
+    VX_CASE(16)
+    VX_CASE(24)
+    VX_CASE(32)
+    default:
+      return -3;
+  }
+#undef VX_CASE
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// reduce: cgrad[a][slot] = sum over wgrad workgroups, fixed order (deterministic)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) reduce_kernel(int NA, int NT, int nblk,
+                                                     const float* __restrict__ wpart,
+                                                     float* __restrict__ cgrad) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)NA * NT;
+  if (e >= n) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblk; b += 4) {
+    s0 += wpart[(long long)(b + 0) * n + e];
+    s1 += wpart[(long long)(b + 1) * n + e];
+    s2 += wpart[(long long)(b + 2) * n + e];
+    s3 += wpart[(long long)(b + 3) * n + e];
+  }
+  for (; b < nblk; ++b) s0 += wpart[(long long)b * n + e];
+  cgrad[e] = (s0 + s1) + (s2 + s3);
+}
+
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s) {
+  const long long n = (long long)g.NA * g.NT;
+  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.NA, g.NT, g.nblk,
+                     wpart, cgrad);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// finish: canonical gradients -> reference layouts (oracle: uncanonicalize_grads)
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o) {
+  const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
+  auto CG = [&](int a, int n) { return cg[(size_t)a * NT + vg_slot(g, n)]; };
+  const long long n_ux = (long long)I * rw, n_vx = 4LL * H * rw, n_dx = I, n_dh = H, n_b = 4LL * H;
+  const long long n_uh0 = (long long)H * g.ru0, n_vh0 = 4LL * H * g.ru0;
+  const long long n_uh1 = g.G == 2 ? (long long)H * g.ru1 : 0, n_vh1 = g.G == 2 ? 4LL * H * g.ru1 : 0;
+  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ux) {  // du_x[m][r]
+    const int m = (int)(e / rw), r = (int)(e % rw);
+    float v = CG(va_ux(g, r), m);
+    for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
+    o.u_x[e] = v;
+    return;
+  }
+  e -= n_ux;
+  if (e < n_vx) {  // dv_x[k*H+n][r]
+    const int row = (int)(e / rw), r = (int)(e % rw), k = row / H, n = row % H;
+    float v = CG(va_vx(g, k, r), n);
+    if (n < I) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
+    o.v_x[e] = v;
+    return;
+  }
+  e -= n_vx;
+  if (e < n_dx) {
+    const int m = (int)e;
+    o.dia_x[m] = (CG(va_ex(g, 0), m) + CG(va_ex(g, 1), m)) + (CG(va_ex(g, 2), m) + CG(va_ex(g, 3), m));
+    return;
+  }
+  e -= n_dx;
+  if (e < n_dh) {
+    const int n = (int)e;
+    o.dia_h[n] = (CG(va_eh(g, 0), n) + CG(va_eh(g, 1), n)) + (CG(va_eh(g, 2), n) + CG(va_eh(g, 3), n));
+    return;
+  }
+  e -= n_dh;
+  if (e < n_b) {
+    const int k = (int)(e / H), n = (int)(e % H);
+    const float v = CG(va_b(g, k), n);
+    o.b_x[k * H + n] = v;
+    o.b_h[vg_hchunk(g, k) * H + n] = v;
+    return;
+  }
+  e -= n_b;
+  for (int s = 0; s < g.G; ++s) {
+    const int rus = s ? g.ru1 : g.ru0, base = s ? g.off1 : 0;
+    const long long n_u = s ? n_uh1 : n_uh0, n_v = s ? n_vh1 : n_vh0;
+    float* ou = s ? o.u_h1 : o.u_h0;
+    float* ov = s ? o.v_h1 : o.v_h0;
+    if (e < n_u) {
+      int n, r;
+      if (g.G == 1) {
+        n = (int)(e / rus);
+        r = (int)(e % rus);
+      } else {  // u_h[s][j][m][r]: the unit that feeds destination j through shift s
+        const int j = (int)(e / ((long long)Hg * rus));
+        const int rem = (int)(e % ((long long)Hg * rus));
+        const int m = rem / rus;
+        r = rem % rus;
+        n = ((j + s) % g.G) * Hg + m;
+      }
+      float v = CG(va_uc(g, base + r), n);
+      if (s == 0)
+        for (int k = 0; k < 4; ++k) v -= CG(va_eh(g, k), n) * ref_vc(g, p, n, k, r);
+      ou[e] = v;
+      return;
+    }
+    e -= n_u;
+    if (e < n_v) {
+      int n, k, r;
+      if (g.G == 1) {
+        const int row = (int)(e / rus);
+        r = (int)(e % rus);
+        k = row / H;
+        n = row % H;
+      } else {  // v_h[s][q][r][col]
+        const int q = (int)(e / ((long long)rus * 4 * Hg));
+        const int rem = (int)(e % ((long long)rus * 4 * Hg));
+        r = rem / (4 * Hg);
+        const int col = rem % (4 * Hg);
+        if (g.flat) {
+          const int f = q * 4 * Hg + col;
+          k = f / H;
+          n = f % H;
+        } else {
+          const int c = col / Hg;
+          k = g.hperm ? (c ^ 1) : c;
+          n = q * Hg + (col % Hg);
+        }
+      }
+      float v = CG(va_vc(g, k, base + r), n);
+      if (s == 0) v -= CG(va_eh(g, k), n) * ref_uc(g, p, n, r);
+      ov[e] = v;
+      return;
+    }
+    e -= n_v;
+  }
+}
+
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s) {
+  long long n = (long long)g.I * g.rw + 4LL * g.H * g.rw + g.I + g.H + 4LL * g.H;
+  n += (long long)g.H * g.ru0 + 4LL * g.H * g.ru0;
+  if (g.G == 2) n += (long long)g.H * g.ru1 + 4LL * g.H * g.ru1;
+  hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out);
+  return (int)hipGetLastError();
+}

@@ -1,0 +1,127 @@
+"""torch.autograd bridge over the C ABI: one call = one layer over the whole sequence.
+
+PyTorch supplies device memory (caching allocator), the current HIP stream and autograd bookkeeping; all
+arithmetic of the hot path happens in libvmlmf_hip.so.  Tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+# order in which parameter tensors are passed to VmlmfSeqFn (and gradients come back)
+#   dia_x dia_h u_x v_x b_x b_h u_h[0] v_h[0] (u_h[1] v_h[1])
+N_FIXED = 6
+
+
+def _ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _params_struct(tensors, g):
+    p = _lib.Params()
+    names = ["dia_x", "dia_h", "u_x", "v_x", "b_x", "b_h"]
+    for name, t in zip(names, tensors[:N_FIXED]):
+        setattr(p, name, t.data_ptr())
+    for s in range(g):
+        p.u_h[s] = tensors[N_FIXED + 2 * s].data_ptr()
+        p.v_h[s] = tensors[N_FIXED + 2 * s + 1].data_ptr()
+    return p
+
+
+def _require_hip(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"vmlmf_amd: {what} is on {t.device}; the VMLMF hot path runs only as HIP kernels on an MI355X "
+            "(no CPU fallback). Move the module and inputs to 'cuda'.")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"vmlmf_amd: {what} must be float32, got {t.dtype}")
+
+
+class VmlmfSeqFn(torch.autograd.Function):
+    """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major)."""
+
+    @staticmethod
+    def forward(ctx, cfg, x, h0, c0, *params):
+        variant, g, w_rank, u_ranks, time_major = cfg
+        ctx.set_materialize_grads(False)
+        _require_hip(x, "input")
+        for p in params:
+            _require_hip(p, "parameter")
+        x = x.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        if time_major:
+            T, B, I = x.shape
+        else:
+            B, T, I = x.shape
+        H = params[1].shape[-1]
+        need_grad = any(t is not None and t.requires_grad for t in (x, h0, c0) + params)
+        training = bool(need_grad and torch.is_grad_enabled())
+        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major,
+                              training=training)
+        sizes = _lib.query(desc)
+        dev = x.device
+        y = torch.empty((T, B, H) if time_major else (B, T, H), device=dev, dtype=torch.float32)
+        hT = torch.empty((B, H), device=dev, dtype=torch.float32)
+        cT = torch.empty((B, H), device=dev, dtype=torch.float32)
+        ws = torch.empty(sizes.workspace_bytes, device=dev, dtype=torch.uint8)
+        reserve = torch.empty(sizes.reserve_bytes, device=dev, dtype=torch.uint8) if training else None
+        h0c = None if h0 is None else h0.contiguous()
+        c0c = None if c0 is None else c0.contiguous()
+        ps = _params_struct(params, g)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().vmlmf_seq_forward(
+                ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
+                _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream))
+        if training:
+            ctx.cfg, ctx.desc, ctx.sizes = cfg, desc, sizes
+            ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
+            ctx.save_for_backward(x, y, reserve, *params, *([h0c] if h0 is not None else []),
+                                  *([c0c] if c0 is not None else []))
+            ctx.nparams = len(params)
+        return y, hT, cT
+
+    @staticmethod
+    def backward(ctx, dy, dhT, dcT):
+        variant, g, w_rank, u_ranks, time_major = ctx.cfg
+        saved = ctx.saved_tensors
+        x, y, reserve = saved[0], saved[1], saved[2]
+        params = saved[3:3 + ctx.nparams]
+        rest = list(saved[3 + ctx.nparams:])
+        h0 = rest.pop(0) if ctx.has_h0 else None
+        c0 = rest.pop(0) if ctx.has_c0 else None
+        dev = x.device
+        desc, sizes = ctx.desc, ctx.sizes
+        dy = None if dy is None else dy.contiguous()
+        dhT = None if dhT is None else dhT.contiguous()
+        dcT = None if dcT is None else dcT.contiguous()
+        need_dx = ctx.needs_input_grad[1]
+        dx = torch.empty_like(x) if need_dx else None
+        B, H = y.shape[1 if time_major else 0], y.shape[2]
+        dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
+        dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_c0 else None
+        grads = tuple(torch.empty_like(p) for p in params)
+        ws = torch.empty(sizes.workspace_bytes, device=dev, dtype=torch.uint8)
+        ps = _params_struct(params, g)
+        gs = _params_struct(grads, g)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().vmlmf_seq_backward(
+                ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
+                _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
+                _ptr(ws), sizes.workspace_bytes, stream))
+        return (None, dx, dh0, dc0) + grads
+
+
+def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False):
+    """Run one VMLMF layer over a whole sequence on the GPU.
+
+    params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
+    each in the reference's layout.  Returns (y, hT, cT).
+    """
+    ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
+    cfg = (variant, g, int(w_rank), ur, bool(time_major))
+    return VmlmfSeqFn.apply(cfg, x, h0, c0, *params)
