@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py - the headline metric of BASELINE.json on MI355X.
+
+Metric: RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16 (UCI-HAR shape, MyVMLMFCell, fp32).
+A "step" is one pass of the hot path over one synthetic batch:
+    zero_grad -> Net.forward (MyLSTM over T=128 + Linear) -> cross-entropy -> backward
+    (+ ONE flat RCCL all-reduce of the gradients when N > 1).  The optimizer is outside the timed region and
+reported separately (`adam_ms`).  Inputs are resident in HBM before the timed region starts.
+value = (N ranks x T timesteps per step) / step time: weak scaling, per-GPU batch fixed at 64
+(N = 8 is BASELINE config D: global batch 512).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, HIP events on the launch stream,
+inside the timed region) and, at N = 1, "cpu_baseline" (the oracle's op-for-op PyTorch-CPU port of the
+reference cell + time loop, timed on this box's host cores).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU, T, I, H, RW, RU, CLASSES = 64, 128, 9, 180, 16, 16, 6
+F32_MATRIX_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+# algorithmic flops per sample-timestep, forward
+F_X = 2 * I * RW + 8 * H * RW        # input -> hidden  (xproj)
+F_H = 10 * H * RU                    # hidden -> hidden (the serial recurrent kernels)
+F_FWD = F_X + F_H                    # 52 128
+F_STEP = 3 * F_FWD                   # fwd + bwd = 156 384
+
+
+def numpy_params(seed):
+    """Seeded numpy-PCG64 parameters/inputs: identical on the CPU leg and on every GPU box."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    shapes = {"u_x": (I, RW), "u_h": (H, RU), "v_x": (4 * H, RW), "v_h": (4 * H, RU),
+              "b_x": (4 * H,), "b_h": (4 * H,), "dia_x": (1, I), "dia_h": (1, H)}
+    return {k: (0.1 * rng.standard_normal(s)).astype(np.float32) for k, s in shapes.items()}
+
+
+def synthetic_batch(rank):
+    rng = np.random.Generator(np.random.PCG64(1234 + rank))
+    x = rng.standard_normal((B_PER_GPU, T, I)).astype(np.float32)
+    tgt = rng.integers(0, CLASSES, size=(B_PER_GPU,)).astype(np.int64)
+    return x, tgt
+
+
+def cpu_baseline(steps=3, warmup=1):
+    """Reference CPU path (port): oracle.literal_* on the host cores, same shapes, same step definition."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import vmlmf_oracle as O   # checker/baseline only; never on the product path
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = O.to_torch(numpy_params(3), requires_grad=True)
+    g = torch.Generator().manual_seed(0)
+    lw = (0.01 * torch.randn(18, H, generator=g)).requires_grad_(True)
+    lb = torch.full((18,), 0.1, requires_grad=True)
+    x, tgt = synthetic_batch(0)
+    xt, tt = torch.tensor(x), torch.tensor(tgt)
+    times = []
+    for it in range(warmup + steps):
+        t0 = time.perf_counter()
+        for p in list(P.values()) + [lw, lb]:
+            p.grad = None
+        loss, _ = O.literal_train_step_har(P, lw, lb, xt, tt)
+        loss.backward()
+        dt = time.perf_counter() - t0
+        if it >= warmup:
+            times.append(dt)
+    med = float(np.median(times))
+    return {"value": T / med, "unit": "RNN timesteps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} full steps (B={B_PER_GPU} T={T} I={I} H={H} r={RU}) after {warmup} warm-up, median; "
+                      f"op-for-op PyTorch-CPU restatement of vmlmf.py:78-125 + 300-314 with autograd backward",
+            "s_per_step": med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from vmlmf_amd import MyLSTM, MyVMLMFCell, Net, _lib
+    from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters
+
+    torch.manual_seed(0)
+    net = Net(I, layer_sizes=[H], w_rank=RW, u_rank=[RU], model=MyLSTM, cell=MyVMLMFCell)
+    P = numpy_params(3)
+    with torch.no_grad():
+        for k, v in P.items():
+            getattr(net.rnn.rnncells[0], k).copy_(torch.tensor(v))
+    net = net.to(dev)
+    broadcast_parameters(net)
+    x_np, tgt_np = synthetic_batch(rank)
+    x = torch.tensor(x_np, device=dev)
+    tgt = torch.tensor(tgt_np, device=dev)
+    reducer = FlatGradAllReduce(net.parameters(), op="avg")
+    lib = _lib.lib()
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        out = net(x)
+        loss = torch.nn.functional.cross_entropy(out, tgt)
+        loss.backward()
+        if world > 1:
+            reducer.reduce()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    # HIP event pairs around the two serial recurrent kernels only (rocprof names them
+    # rec_fwd_kernel / rec_bwd_kernel), recorded on the stream they are launched on
+    lib.vmlmf_profile_enable((1 << 2) | (1 << 3))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    usec = (ctypes.c_float * _lib.NKERNELS)()
+    cnt = (ctypes.c_int32 * _lib.NKERNELS)()
+    lib.vmlmf_profile_read(usec, cnt, 1)
+    lib.vmlmf_profile_enable(0)
+    rec = {lib.vmlmf_kernel_name(k).decode(): usec[k] / max(cnt[k], 1) for k in (2, 3)}
+
+    # untimed extra pass: every internal kernel bracketed, for the breakdown
+    lib.vmlmf_profile_enable(0xff)
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    lib.vmlmf_profile_read(usec, cnt, 1)
+    lib.vmlmf_profile_enable(0)
+    kern = {lib.vmlmf_kernel_name(k).decode(): round(usec[k] / max(cnt[k], 1), 2) for k in range(_lib.NKERNELS)}
+
+    # optimizer, outside the metric (train.py:47,65)
+    opt = torch.optim.Adam(net.parameters(), lr=0.002)
+    step()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(20):
+        opt.step()
+    torch.cuda.synchronize()
+    adam_ms = (time.perf_counter() - t1) / 20 * 1e3
+
+    tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * T * args.steps / dt
+
+    if rank == 0:
+        dom = max(rec, key=rec.get)                      # dominant kernel by measured time
+        rows = B_PER_GPU * T                             # sample-timesteps one launch processes
+        flops = rows * F_H * (1 if dom == "rec_fwd_kernel" else 1)   # 10 H ru per sample-step either way
+        achieved = flops / (rec[dom] * 1e-6) / 1e12
+        out = {
+            "metric": "RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16; 1/2/4/8 GPU",
+            "value": round(value, 1), "unit": "RNN timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: UCI-HAR shape, Net(MyLSTM[MyVMLMFCell]) 1 layer, "
+                                   "B=64/GPU T=128 I=9 H=180 w_rank=16 u_rank=16, CE loss, fwd+bwd"
+                                   + (", flat RCCL all-reduce (AVG) of grads" if world > 1 else ""),
+                       "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}"},
+            "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
+            "step_flops": rows * F_STEP,
+            "step_tflops": round(rows * F_STEP / (ms_per_step * 1e-3) / 1e12, 3),
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3),
+                         "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
+                         "launch_us": round(rec[dom], 2), "flops_per_launch": flops,
+                         "note": "fp32: MFMA peak == vector peak on gfx950; the kernel is a 2T-long dependent "
+                                 "chain on 64 of 256 CUs (one batch row per CU), see DESIGN.md"},
+            "kernels_us": kern,
+            "adam_ms": round(adam_ms, 4),
+            "loss": round(float(loss.item()), 6),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -102,14 +102,15 @@ int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *
                        const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
- * Instrumentation for bench.py (roofline leg).  While enabled, every internal kernel launch is bracketed
- * by a HIP event pair recorded on the SAME stream the kernel is launched on.  vmlmf_profile_read()
+ * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel
+ * k with bit k set in `mask` is bracketed by a HIP event pair recorded on the SAME stream the kernel is
+ * launched on (mask 0 = off, 0xff = all).  vmlmf_profile_read()
  * synchronises the recorded events and returns, per internal kernel, the summed duration in microseconds
  * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 wgrad_x,
  * 5 wgrad_h, 6 reduce, 7 finish (vmlmf_kernel_name(i) gives the symbol name rocprofv3 reports).
  */
 #define VMLMF_NKERNELS 8
-int vmlmf_profile_enable(int enable);
+int vmlmf_profile_enable(int mask);
 int vmlmf_profile_read(float *usec_sum, int32_t *count, int reset);
 const char *vmlmf_kernel_name(int k);
 

@@ -61,7 +61,7 @@ if __name__ == "__main__":
         y.sum().backward()
     torch.cuda.synchronize()
     L = _lib.lib()
-    L.vmlmf_profile_enable(1)
+    L.vmlmf_profile_enable(0xff)
     t0 = time.perf_counter()
     n = 20
     for it in range(n):

@@ -24,7 +24,7 @@ int fail(int code, const std::string& msg) {
 constexpr int NKERN = 8;
 struct Prof {
   std::mutex mu;
-  bool on = false;
+  unsigned mask = 0;  // bit k: bracket kernel k with an event pair
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NKERN];
 } g_prof;
 
@@ -33,7 +33,7 @@ struct Scope {
   hipStream_t s;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   Scope(int which, hipStream_t st) : k(which), s(st) {
-    if (g_prof.on) {
+    if ((g_prof.mask >> which) & 1u) {
       hipEventCreate(&e0);
       hipEventCreate(&e1);
       hipEventRecord(e0, s);
@@ -304,9 +304,9 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   return 0;
 }
 
-int vmlmf_profile_enable(int enable) {
+int vmlmf_profile_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
-  g_prof.on = enable != 0;
+  g_prof.mask = (unsigned)mask;
   return 0;
 }
 

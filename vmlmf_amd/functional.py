@@ -57,8 +57,7 @@ class VmlmfSeqFn(torch.autograd.Function):
         else:
             B, T, I = x.shape
         H = params[1].shape[-1]
-        need_grad = any(t is not None and t.requires_grad for t in (x, h0, c0) + params)
-        training = bool(need_grad and torch.is_grad_enabled())
+        training = bool(any(ctx.needs_input_grad))   # False under torch.no_grad(): inference kernels
         desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major,
                               training=training)
         sizes = _lib.query(desc)
