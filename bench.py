@@ -54,33 +54,56 @@ def synthetic_batch(rank):
     return x, tgt
 
 
-def cpu_baseline(steps=3, warmup=1):
-    """Reference CPU path (port): oracle.literal_* on the host cores, same shapes, same step definition."""
+def usable_cores():
+    """Host cores this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(budget_s=25.0):
+    """Reference CPU path (port): oracle.literal_* (op-for-op PyTorch-CPU restatement of the reference cell
+    and time loop, autograd backward) on the host cores, same shapes, same step definition.  The workload is
+    dispatch-bound (~75 tiny ATen ops per timestep), so more threads are not faster: it is timed with 1
+    thread and with all usable cores (capped at 16) and the FASTER one is reported."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import vmlmf_oracle as O   # checker/baseline only; never on the product path
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     P = O.to_torch(numpy_params(3), requires_grad=True)
     g = torch.Generator().manual_seed(0)
     lw = (0.01 * torch.randn(18, H, generator=g)).requires_grad_(True)
     lb = torch.full((18,), 0.1, requires_grad=True)
     x, tgt = synthetic_batch(0)
     xt, tt = torch.tensor(x), torch.tensor(tgt)
-    times = []
-    for it in range(warmup + steps):
+
+    def one():
         t0 = time.perf_counter()
         for p in list(P.values()) + [lw, lb]:
             p.grad = None
         loss, _ = O.literal_train_step_har(P, lw, lb, xt, tt)
         loss.backward()
-        dt = time.perf_counter() - t0
-        if it >= warmup:
-            times.append(dt)
-    med = float(np.median(times))
-    return {"value": T / med, "unit": "RNN timesteps/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} full steps (B={B_PER_GPU} T={T} I={I} H={H} r={RU}) after {warmup} warm-up, median; "
-                      f"op-for-op PyTorch-CPU restatement of vmlmf.py:78-125 + 300-314 with autograd backward",
-            "s_per_step": med}
+        return time.perf_counter() - t0
+
+    cores = usable_cores()
+    results = {}
+    for nt in sorted({1, min(cores, 16)}):
+        torch.set_num_threads(nt)
+        one()                                   # warm-up
+        times, t_start = [], time.perf_counter()
+        while len(times) < 5 and (time.perf_counter() - t_start) < budget_s / 2:
+            times.append(one())
+        results[nt] = float(np.median(times))
+    best = min(results, key=results.get)
+    return {"value": T / results[best], "unit": "RNN timesteps/s", "cores": best, "kind": "port",
+            "sample": f"full steps of the bench workload (B={B_PER_GPU} T={T} I={I} H={H} r={RU}), 1 warm-up + up to 5 "
+                      f"timed per thread count, median; s/step by threads: "
+                      + ", ".join(f"{k}: {v:.3f}" for k, v in results.items())
+                      + f"; host has {cores} usable cores",
+            "s_per_step": results[best]}
 
 
 def main():
@@ -134,9 +157,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"world={world} device={torch.cuda.get_device_name(dev)}")
     for _ in range(args.warmup):
         step()
     barrier()
+    log("warm-up done")
     # HIP event pairs around the two serial recurrent kernels only (rocprof names them
     # rec_fwd_kernel / rec_bwd_kernel), recorded on the stream they are launched on
     lib.vmlmf_profile_enable((1 << 2) | (1 << 3))
@@ -146,6 +175,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt / args.steps * 1e3:.4f} ms/step")
     usec = (ctypes.c_float * _lib.NKERNELS)()
     cnt = (ctypes.c_int32 * _lib.NKERNELS)()
     lib.vmlmf_profile_read(usec, cnt, 1)
