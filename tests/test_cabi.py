@@ -1,0 +1,74 @@
+"""CPU: the C-ABI shared library loads without a GPU and exports every symbol include/vmlmf_hip.h declares;
+vmlmf_query (host-only) validates descriptors the way the reference's shapes demand."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from vmlmf_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "vmlmf_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(vmlmf_[a-z_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_header_and_binding_agree():
+    decl = declared_functions()
+    assert decl, "no functions parsed from the header"
+    assert sorted(_lib.SYMBOLS) == decl
+
+
+def test_library_loads_and_exports_every_symbol():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    handle = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared_functions():
+        assert hasattr(handle, name), f"missing export {name}"
+    lib = _lib.lib()
+    assert lib.vmlmf_abi_version() == 1
+    assert b"gfx950" in lib.vmlmf_build_info()
+    assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
+        "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "wgrad_x_kernel", "wgrad_h_kernel",
+        "reduce_kernel", "finish_kernel"]
+
+
+def test_query_headline_geometry():
+    s = _lib.query(_lib.make_desc(_lib.V1_CELL, 64, 128, 9, 180, 16, [16]))
+    assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kx, s.kh) == (1, 192, 64, 16, 16)
+    assert s.reserve_bytes > 64 * 128 * 180 * 5 * 4          # gates + c tape
+    s = _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 512, 128, 9, 180, 16, [16, 16], g=2))
+    assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kh) == (2, 256, 256, 32)   # 2 groups x 2 waves
+    s = _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 81, 24, 77, 180, 8, [2, 4], g=2))  # demo.sh:10
+    assert (s.kx, s.kh) == (8, 16)
+
+
+@pytest.mark.parametrize("desc,code", [
+    (dict(variant=_lib.V1_CELL, B=4, T=3, I=10, H=8, w_rank=3, u_ranks=[3]), _lib.E_SHAPE),        # vmlmf.py:94
+    (dict(variant=_lib.V3_LM, B=4, T=3, I=6, H=8, w_rank=3, u_ranks=[3]), _lib.E_SHAPE),          # vmlmf_lm.py:243
+    (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=9, w_rank=3, u_ranks=[2, 2], g=2), _lib.E_SHAPE),
+    (dict(variant=7, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
+    (dict(variant=_lib.V1_CELL, B=0, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
+    (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[0]), _lib.E_BADARG),
+    (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=12, w_rank=3, u_ranks=[2, 2, 2], g=3), _lib.E_UNSUPPORTED),
+    (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=64, w_rank=3, u_ranks=[40]), _lib.E_UNSUPPORTED),
+])
+def test_query_rejects_what_it_must(desc, code):
+    with pytest.raises(_lib.VmlmfError) as ei:
+        _lib.query(_lib.make_desc(**desc))
+    assert ei.value.code == code
+    assert len(str(ei.value)) > 20          # carries an explanation, like the reference's RuntimeError
+
+
+def test_forward_refuses_null_buffers_without_touching_the_gpu():
+    lib = _lib.lib()
+    d = _lib.make_desc(_lib.V1_CELL, 4, 3, 4, 8, 3, [3])
+    p = _lib.Params()
+    rc = lib.vmlmf_seq_forward(ctypes.byref(d), ctypes.byref(p), None, None, None, None, None, None, None, None,
+                               0, None)
+    assert rc == _lib.E_BADARG
+    assert b"null" in lib.vmlmf_last_error()

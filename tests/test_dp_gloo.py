@@ -1,0 +1,84 @@
+"""CPU, 2 processes over gloo: the flat-buffer gradient all-reduce reproduces single-process gradients
+(AVG for the HAR loss, SUM for the LM loss), tolerates parameters without a gradient
+(Net.cell, vmlmf.py:349-350), and batch sharding is a contiguous split."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class Toy(torch.nn.Module):
+    """Row-independent model: per-row loss, parameter gradients sum over rows (like the RNN)."""
+
+    def __init__(self):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.a = torch.nn.Parameter(torch.randn(6, 4, generator=g))
+        self.b = torch.nn.Parameter(torch.randn(4, generator=g))
+        self.unused = torch.nn.Parameter(torch.randn(3, generator=g))   # never receives a gradient
+
+    def forward(self, x):
+        return torch.tanh(x @ self.a + self.b)
+
+
+def _worker(rank, world, port, op, out):
+    sys.path.insert(0, ROOT)
+    from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters, shard_batch
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                 # replicas start different ...
+    m = Toy()
+    with torch.no_grad():
+        m.a.add_(rank)
+    broadcast_parameters(m)                       # ... and are made identical
+    x = torch.randn(10, 6, generator=torch.Generator().manual_seed(1))
+    xs = shard_batch(x, rank, world)
+    y = m(xs)
+    loss = y.mean(dim=1).mean() if op == "avg" else y.mean(dim=1).sum()
+    loss.backward()
+    red = FlatGradAllReduce(m.parameters(), op=op)
+    red.reduce()
+    if rank == 0:
+        torch.save({"a": m.a.grad, "b": m.b.grad, "n": red.numel(), "a0": m.a.detach()}, out)
+    dist.destroy_process_group()
+
+
+def _run(op, tmp_path):
+    out = str(tmp_path / f"dp_{op}.pt")
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, op, out), nprocs=2, join=True)
+    got = torch.load(out)
+    m = Toy()
+    x = torch.randn(10, 6, generator=torch.Generator().manual_seed(1))
+    y = m(x)
+    loss = y.mean(dim=1).mean() if op == "avg" else y.mean(dim=1).sum()
+    loss.backward()
+    assert torch.equal(got["a0"], m.a.detach())                    # rank 0's parameters won the broadcast
+    assert got["n"] == 6 * 4 + 4                                   # the unused parameter is not in the buffer
+    assert torch.allclose(got["a"], m.a.grad, atol=1e-6)
+    assert torch.allclose(got["b"], m.b.grad, atol=1e-6)
+
+
+def test_avg_matches_global_batch_mean_loss(tmp_path):
+    _run("avg", tmp_path)
+
+
+def test_sum_matches_global_batch_sum_loss(tmp_path):
+    _run("sum", tmp_path)
+
+
+def test_shard_batch_is_a_contiguous_partition():
+    sys.path.insert(0, ROOT)
+    from vmlmf_amd.dp import shard_batch
+    x = torch.arange(512 * 3).view(512, 3)
+    for world in (1, 2, 4, 8):
+        parts = [shard_batch(x, r, world) for r in range(world)]
+        assert all(p.shape[0] == 512 // world for p in parts)
+        assert torch.equal(torch.cat(parts), x)
+    parts = [shard_batch(x[:10], r, 4) for r in range(4)]           # ragged: 3,3,3,1
+    assert [p.shape[0] for p in parts] == [3, 3, 3, 1]

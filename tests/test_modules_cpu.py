@@ -1,0 +1,80 @@
+"""CPU: the nn.Module mirrors expose the reference's constructor signatures, attributes, parameter names and
+shapes (state_dict compatibility, save_load.py:47,64-65), and refuse to run without a HIP device."""
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_amd
+from vmlmf_amd import MyLSTM, MyLSTMCell, MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGroup, Net
+from conftest import load_golden
+
+
+def test_state_dict_names_and_shapes_match_reference():
+    ref = load_golden("state_dict_names")
+    nets = {
+        "net_v1": Net(77, layer_sizes=[180], w_rank=8, u_rank=[6], model=MyLSTM, cell=MyVMLMFCell),
+        "net_v2": Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFCellg2),
+        "lm_v3": MyVMLSTM(16, 16, w_rank=4, u_ranks=4),
+        "lm_v4": MyVMLSTMGroup(16, 16, w_rank=4, u_ranks=[2, 3]),
+    }
+    for tag, m in nets.items():
+        mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        theirs = {k: tuple(int(x) for x in v) for k, v in ref[tag].items()}
+        assert list(mine) == list(theirs), tag          # same names, same registration order
+        assert mine == theirs, tag
+
+
+def test_reference_unit_test_shape_assertions():
+    """The six shape checks of V/src/unittest/unit_test.py:63-93 on our modules."""
+    c = Net(77, layer_sizes=[180], w_rank=8, u_rank=[6], model=MyLSTM, cell=MyVMLMFCell)
+    g = Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFCellg2)
+    assert c.cell.dia_x.shape == (1, 77) and c.cell.dia_h.shape == (1, 180)
+    assert c.cell.u_x.shape == (77, 8) and c.cell.u_h.shape == (180, 6)
+    assert c.cell.v_x.shape == (720, 8) and c.cell.v_h.shape == (720, 6)
+    assert g.cell.layers['dia_x'].shape == (1, 77) and g.cell.layers['dia_h'].shape == (1, 180)
+    assert g.cell.layers['u_h_0'].shape == (2, 90, 2) and g.cell.layers['u_h_1'].shape == (2, 90, 4)
+    assert g.cell.layers['v_h_0'].shape == (2, 2, 360) and g.cell.layers['v_h_1'].shape == (2, 4, 360)
+
+
+def test_seeded_construction_draws_the_same_values_as_the_reference():
+    """Parameter creation order equals the reference's, so torch.manual_seed reproduces its init: the golden
+    Net fixture stores lin.weight drawn after the cells under seed 0."""
+    d = load_golden("cfgA_net_adam3")
+    torch.manual_seed(0)
+    net = Net(9, layer_sizes=[180], w_rank=16, u_rank=[16], model=MyLSTM, cell=MyVMLMFCell)
+    assert np.array_equal(net.lin.weight.detach().numpy(), d["lin_w"])
+
+
+def test_attributes_other_reference_code_reads():
+    net = Net(9, layer_sizes=[180], w_rank=16, u_rank=[16], model=MyLSTM, cell=MyVMLMFCell)
+    # compression_cal.py:128-132,144
+    assert (net.rnn.input_size, net.rnn.hidden_layer_sizes, net.rnn.w_rank, net.rnn.u_ranks) == (9, [180], 16, 16)
+    assert MyVMLSTM(8, 8, w_rank=2, u_ranks=2).hidden_size == 8     # vmlmf_lm.py:418
+
+
+def test_no_cpu_fallback():
+    cell = MyVMLMFCell(5, 8, w_rank=3, u_ranks=3)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cell(torch.randn(2, 5), (torch.zeros(2, 8), torch.zeros(2, 8)))
+    rnn = MyLSTM(5, hidden_layer_sizes=[8], w_rank=3, u_ranks=[3], cell=MyVMLMFCell)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rnn(torch.randn(2, 4, 5))
+    lm = MyVMLSTMGroup(8, 8, w_rank=2, u_ranks=[2, 2])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lm(torch.randn(3, 2, 8), (torch.zeros(2, 8), torch.zeros(2, 8)))
+
+
+def test_product_package_never_imports_the_oracle():
+    import os
+    root = os.path.dirname(vmlmf_amd.__file__)
+    for fn in os.listdir(root):
+        if fn.endswith(".py"):
+            src = open(os.path.join(root, fn)).read()
+            assert "vmlmf_oracle" not in src and "oracle" not in src.replace("# oracle", ""), fn
+
+
+def test_baseline_cell_still_runs_inside_mylstm_on_cpu():
+    """MyLSTMCell is not the hot path (stock GEMMs): it keeps the reference's Python loop."""
+    rnn = MyLSTM(5, hidden_layer_sizes=[8, 8], w_rank=3, u_ranks=[3], cell=MyLSTMCell)
+    y, hc = rnn(torch.randn(2, 4, 5))
+    assert y.shape == (2, 4, 8) and hc.shape == (2, 16)
