@@ -128,9 +128,9 @@ struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
   long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
   // forward workspace  : PACK (inference only) | gx
-  long long f_pack, f_gx, f_total;
+  long long f_pack, f_gx, f_trash, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_wpart, b_cgrad, b_total;
+  long long b_dpre, b_dQs, b_wpart, b_cgrad, b_trash, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P) {
@@ -146,12 +146,14 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   o = 0;
   L.f_pack = o, o += align64(P.total);
   L.f_gx = o, o += align64(TB * g.H * 4);
+  L.f_trash = o, o += 64;
   L.f_total = o;
   o = 0;
   L.b_dpre = o, o += align64(TB * g.H * 4);
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
   L.b_wpart = o, o += align64((long long)g.nblk * g.NA * g.NT);
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT);
+  L.b_trash = o, o += 64;
   L.b_total = o;
   return L;
 }
@@ -235,7 +237,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
   }
   FwdArgs a;
   a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
-  a.y = y, a.hT = hT, a.cT = cT;
+  a.y = y, a.hT = hT, a.cT = cT, a.trash = ws + L.f_trash;
   a.gates = g.training ? rs + L.r_gates : nullptr;
   a.cs = g.training ? rs + L.r_cs : nullptr;
   a.Qs = g.training ? rs + L.r_Qs : nullptr;
@@ -270,7 +272,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   BwdArgs a;
   a.gates = rs + L.r_gates, a.cs = rs + L.r_cs, a.c0 = c0, a.dy = dy, a.dhT = dhT, a.dcT = dcT;
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
-  a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0;
+  a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
   {
     Scope sc(3, s);
     if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;

@@ -37,6 +37,20 @@ __device__ __forceinline__ float ror16(float v) {
   }
 }
 
+// acc += (value received through row_ror:K) * w   as ONE instruction (v_fmac_f32 with a DPP source operand).
+// hipcc does not fold update_dpp into the FMA (it emits v_mov_dpp + s_nop + v_fmac), so this is inline asm.
+// DPP hazard (VALU write of `src` -> DPP read needs 2 wait states): callers pass `src` through dpp_fence()
+// once before a block of these, which also orders the block after the producer of `src`.
+template <int K>
+__device__ __forceinline__ void fmac_ror(float& acc, float src, float w) {
+  if constexpr (K == 0) {
+    acc = fmaf(src, w, acc);
+  } else {
+    asm("v_fmac_f32_dpp %0, %1, %2 row_ror:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(K));
+  }
+}
+__device__ __forceinline__ void dpp_fence(float& src) { asm volatile("s_nop 1" : "+v"(src)); }
+
 // Sum over the four 16-lane rows of a wave: every lane i ends with v[i] + v[i+16] + v[i+32] + v[i+48].
 __device__ __forceinline__ float rowsum4(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
@@ -53,6 +67,29 @@ __device__ __forceinline__ float fast_tanh(float x) {
   // tanh(x) = 1 - 2 / (1 + exp(2x)); saturates cleanly for large |x|
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
+
+// Select between two addresses WITHOUT letting the compiler turn it into two branch-guarded memory ops
+// (a memory op under a branch wrecks the counted s_waitcnt vmcnt(N) of the software-pipelined loops).
+// The pointer stays in the GLOBAL address space: a generic pointer would become flat_load/flat_store,
+// which also tick lgkmcnt and would be drained by the LDS-only barrier wait.
+typedef __attribute__((address_space(1))) float gf32;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) f32x4 gf32x4;
+__device__ __forceinline__ gf32* sel_g(bool c, float* a, float* b) {
+  gf32* p = c ? (gf32*)a : (gf32*)b;
+  asm("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ const gf32* sel_g(bool c, const float* a, const float* b) {
+  const gf32* p = c ? (const gf32*)a : (const gf32*)b;
+  asm("" : "+v"(p));
+  return p;
+}
+__device__ __forceinline__ void st4g(gf32* p, float4 v) {
+  *reinterpret_cast<gf32x4*>(p) = f32x4{v.x, v.y, v.z, v.w};
+}
+// explicit s_waitcnt vmcnt(0) that hipcc's waitcnt pass understands (expcnt/lgkmcnt left at max)
+__device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }

@@ -6,10 +6,12 @@
 struct FwdArgs {
   const float *gx, *VE, *UR, *EH, *h0, *c0;
   float *y, *hT, *cT, *gates, *cs, *Qs;
+  float* trash;  // >= 64 floats: target of the redirected stores of inactive lanes (keeps stores unconditional)
 };
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
   float *dpre, *dQs, *dh0, *dc0;
+  float* trash;
 };
 struct WgxArgs {
   const float *dpre, *x, *qx, *VRX, *UXO, *EXI;
