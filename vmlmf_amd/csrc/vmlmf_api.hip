@@ -110,6 +110,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // rows per workgroup: one row per CU while the batch fits the chip once, then two
   g.R = (g.B <= 256 || g.flat) ? 1 : 2;
   g.nwg = (g.B + g.R - 1) / g.R;
+  g.Bp = g.nwg * g.R;
+  if ((long long)g.T * g.Bp * g.NT * 4 >= (1LL << 31) || (long long)g.T * g.B * g.H >= (1LL << 31))
+    return fail(VMLMF_E_UNSUPPORTED, "T*B*H too large for the 32-bit element offsets of the kernels");
   // wgrad chunking: about one workgroup per CU, LDS partials <= 48 KiB
   const int TB = g.T * g.B;
   int rc = (TB + 255) / 256;
@@ -136,20 +139,21 @@ struct Layout {
 Layout make_layout(const VGeo& g, const VPack& P) {
   Layout L;
   const long long TB = (long long)g.T * g.B;
+  const long long TS = (long long)g.T * g.Bp * g.NT;   // (t, padded row, thread slot)
   long long o = 0;
   L.r_pack = o, o += align64(P.total);
   L.r_qx = o, o += align64(TB * g.KX);
-  L.r_gates = o, o += align64(TB * g.H * 4);
-  L.r_cs = o, o += align64(TB * g.H);
+  L.r_gates = o, o += align64(TS * 4);
+  L.r_cs = o, o += align64(TS + (long long)g.Bp * g.NT);   // slice 0 = c0, slice t+1 = c_t
   L.r_Qs = o, o += align64(TB * g.G * g.KH);
   L.r_total = o;
   o = 0;
   L.f_pack = o, o += align64(P.total);
-  L.f_gx = o, o += align64(TB * g.H * 4);
+  L.f_gx = o, o += align64(TS * 4);
   L.f_trash = o, o += 64;
   L.f_total = o;
   o = 0;
-  L.b_dpre = o, o += align64(TB * g.H * 4);
+  L.b_dpre = o, o += align64(TS * 4);
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
   L.b_wpart = o, o += align64((long long)g.nblk * g.NA * g.NT);
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT);

@@ -91,6 +91,12 @@ __device__ __forceinline__ void st4g(gf32* p, float4 v) {
 // explicit s_waitcnt vmcnt(0) that hipcc's waitcnt pass understands (expcnt/lgkmcnt left at max)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+// packed fp32 math: v_pk_fma_f32 does two FMAs per issue slot; with one wave per SIMD the kernels are
+// issue-bound (one instruction per ~4 cycles per wave), so packing halves the cost of the FMA blocks.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.f, 0.f, 0.f, 0.f); }

@@ -19,6 +19,7 @@ struct VGeo {
   int hperm;  // V2: h-side chunks are (f,i,n,o) (vmlmf_group.py:134,149-152)
   int R;      // batch rows per workgroup
   int nwg;    // workgroups of the recurrent kernels
+  int Bp;     // nwg * R: batch rows of the internal (slot-padded) buffers [T][Bp][NT]
   int RC;     // (t,b) rows per wgrad workgroup
   int nblk;   // wgrad workgroups
   int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12

@@ -118,66 +118,79 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
                                                     const float* __restrict__ ext,
                                                     const float* __restrict__ bbt, float* __restrict__ gx,
                                                     float* __restrict__ qx) {
+  // Rows are enumerated in the PADDED space rp = t*Bp + b; gx is slot-padded [T][Bp][NT][4].  Pad rows
+  // (b >= B) and pad slots (lanes without a hidden unit) are written as zeros: the recurrent kernels read
+  // every slot unconditionally and must only ever see finite values there.
   extern __shared__ float4 smem4[];
   float* xs = reinterpret_cast<float*>(smem4);  // [XR][I]
   float* qs = xs + XR * g.I;                    // [XR][KX]
   const int tid = threadIdx.x;
-  const int TB = g.T * g.B, I = g.I, H = g.H;
+  const int TBp = g.T * g.Bp, I = g.I, H = g.H, NT = g.NT;
   const int row0 = blockIdx.x * XR;
   for (int idx = tid; idx < XR * I; idx += 256) {
-    const int r = idx / I, m = idx - r * I, row = row0 + r;
+    const int r = idx / I, m = idx - r * I, rp = row0 + r;
     float v = 0.f;
-    if (row < TB) {
-      const int t = row / g.B, b = row - t * g.B;
-      v = x[t * g.sxT + b * g.sxB + m];
+    if (rp < TBp) {
+      const int t = rp / g.Bp, b = rp - t * g.Bp;
+      if (b < g.B) v = x[t * g.sxT + b * g.sxB + m];
     }
     xs[idx] = v;
   }
   __syncthreads();
   for (int idx = tid; idx < XR * KX; idx += 256) {
-    const int r = idx / KX, j = idx - r * KX;
+    const int r = idx / KX, j = idx - r * KX, rp = row0 + r;
     float acc = 0.f;
     for (int m = 0; m < I; ++m) acc = fmaf(xs[r * I + m], uxp[m * KX + j], acc);
     qs[idx] = acc;
-    if (qx != nullptr && row0 + r < TB) qx[(size_t)(row0 + r) * KX + j] = acc;
+    if (qx != nullptr && rp < TBp) {
+      const int t = rp / g.Bp, b = rp - t * g.Bp;
+      if (b < g.B) qx[(size_t)(t * g.B + b) * KX + j] = acc;
+    }
   }
   __syncthreads();
-  for (int n = tid; n < H; n += 256) {
+  for (int slot = tid; slot < NT; slot += 256) {
+    int n;
+    const bool valid = vg_slot_unit(g, slot, n);
     float v[4][KX], e[4], bb[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
-      for (int r = 0; r < KX; ++r) v[k][r] = vxt[(size_t)(k * KX + r) * H + n];
-      e[k] = ext[k * H + n];
-      bb[k] = bbt[k * H + n];
+      for (int r = 0; r < KX; ++r) v[k][r] = valid ? vxt[(size_t)(k * KX + r) * H + n] : 0.f;
+      e[k] = valid ? ext[k * H + n] : 0.f;
+      bb[k] = valid ? bbt[k * H + n] : 0.f;
     }
     for (int r = 0; r < XR; ++r) {
-      const int row = row0 + r;
-      if (row >= TB) break;
-      const float xv = (n < I) ? xs[r * I + n] : 0.f;
-      float pre[4];
+      const int rp = row0 + r;
+      if (rp >= TBp) break;
+      const int b = rp % g.Bp;
+      float4 out = f4zero();
+      if (valid && b < g.B) {
+        const float xv = (n < I) ? xs[r * I + n] : 0.f;
+        float pre[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) pre[k] = fmaf(xv, e[k], bb[k]);
+        for (int k = 0; k < 4; ++k) pre[k] = fmaf(xv, e[k], bb[k]);
 #pragma unroll
-      for (int j4 = 0; j4 < KX / 4; ++j4) {
-        const float4 q = ld4(qs + r * KX + 4 * j4);
+        for (int j4 = 0; j4 < KX / 4; ++j4) {
+          const float4 q = ld4(qs + r * KX + 4 * j4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          pre[k] = fmaf(q.x, v[k][4 * j4 + 0], pre[k]);
-          pre[k] = fmaf(q.y, v[k][4 * j4 + 1], pre[k]);
-          pre[k] = fmaf(q.z, v[k][4 * j4 + 2], pre[k]);
-          pre[k] = fmaf(q.w, v[k][4 * j4 + 3], pre[k]);
+          for (int k = 0; k < 4; ++k) {
+            pre[k] = fmaf(q.x, v[k][4 * j4 + 0], pre[k]);
+            pre[k] = fmaf(q.y, v[k][4 * j4 + 1], pre[k]);
+            pre[k] = fmaf(q.z, v[k][4 * j4 + 2], pre[k]);
+            pre[k] = fmaf(q.w, v[k][4 * j4 + 3], pre[k]);
+          }
         }
+        out = make_float4(pre[0], pre[1], pre[2], pre[3]);
       }
-      st4(gx + ((size_t)row * H + n) * 4, make_float4(pre[0], pre[1], pre[2], pre[3]));
+      st4(gx + ((size_t)rp * NT + slot) * 4, out);
     }
   }
 }
 
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
                  hipStream_t s) {
-  const int TB = g.T * g.B;
-  const dim3 grid((TB + XR - 1) / XR), block(256);
+  const int TBp = g.T * g.Bp;
+  const dim3 grid((TBp + XR - 1) / XR), block(256);
   const size_t lds = sizeof(float) * (size_t)(XR * g.I + XR * g.KX);
   const float *uxp = pack + L.UXP, *vxt = pack + L.VXT, *ext = pack + L.EXT, *bbt = pack + L.BBT;
 #define VX_CASE(K)                                                                                     \

@@ -35,7 +35,8 @@ __global__ void __launch_bounds__(MAXT) wgrad_x_kernel(VGeo g, WgxArgs a) {
 #pragma unroll
       for (int j = 0; j < KQX; ++j) vrx[k][j] = a.VRX[(size_t)(k * KQX + j) * NT + tid];
     for (int rl = 0; rl < nrows; ++rl) {
-      const float4 d = valid ? ld4(a.dpre + ((size_t)(row0 + rl) * H + n) * 4) : f4zero();
+      const int row = row0 + rl, t = row / B, b = row - t * B;
+      const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);   // slot-padded, zeros in pad slots
       const float dp[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
       for (int p = 0; p < NPX; ++p) {
@@ -68,7 +69,7 @@ __global__ void __launch_bounds__(MAXT) wgrad_x_kernel(VGeo g, WgxArgs a) {
   for (int rl = 0; rl < nrows; ++rl) {
     const int row = row0 + rl;
     const int t = row / B, b = row - t * B;
-    const float4 d = valid ? ld4(a.dpre + ((size_t)row * H + n) * 4) : f4zero();
+    const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);
     const float dp[4] = {d.x, d.y, d.z, d.w};
     const float* qxr = a.qx + (size_t)row * KX;
 #pragma unroll
@@ -147,7 +148,7 @@ __global__ void __launch_bounds__(MAXT) wgrad_h_kernel(VGeo g, WghArgs a) {
   for (int rl = 0; rl < nrows; ++rl) {
     const int row = row0 + rl;
     const int t = row / B, b = row - t * B;
-    const float4 d = valid ? ld4(a.dpre + ((size_t)row * H + n) * 4) : f4zero();
+    const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);
     const float dp[4] = {d.x, d.y, d.z, d.w};
     float hp = 0.f;
     if (valid) {
