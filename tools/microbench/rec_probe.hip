@@ -1,0 +1,75 @@
+// Ablation probe for rec_fwd_kernel at the bench shape (B=64 T=128 H=180 rank 16): which part of the
+// per-timestep chain costs what.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vmlmf_amd/csrc
+//   tools/microbench/rec_probe.hip -o gpurun_out/rec_probe ; run on the GPU box.  Not part of the library.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "vmlmf_rec_fwd.inc"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+
+template <int ABL>
+float run(const VGeo& g, const FwdArgs& a, int iters) {
+  constexpr int KQ = 16;
+  const size_t lds = sizeof(float) * 2 * 1 * g.NW * KQ;
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT), lds, 0, g, a);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT), lds, 0, g, a);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+int main() {
+  VGeo g = {};
+  g.variant = 1, g.B = 64, g.T = 128, g.I = 9, g.H = 180, g.rw = 16, g.G = 1, g.Hg = 180, g.W = 3, g.NT = 192,
+  g.NW = 3, g.ru0 = 16, g.off1 = 16, g.KX = 16, g.KH = 16, g.NP = 1, g.KQ = 16, g.NPX = 1, g.KQX = 16, g.R = 1,
+  g.nwg = 64, g.Bp = 64, g.syT = 180, g.syB = 128 * 180, g.sxT = 9, g.sxB = 128 * 9;
+  const size_t TS = (size_t)g.T * g.Bp * g.NT;
+  auto dalloc = [&](size_t n, float scale) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((float)rand() / RAND_MAX - 0.5f);
+    float* d;
+    CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+  };
+  FwdArgs a = {};
+  a.gx = dalloc(TS * 4, 1.0f);
+  a.VE = dalloc((size_t)4 * 16 * g.NT, 0.2f);
+  a.UR = dalloc((size_t)16 * g.NT, 0.2f);
+  a.EH = dalloc((size_t)4 * g.NT, 0.2f);
+  a.h0 = nullptr, a.c0 = nullptr;
+  a.y = dalloc((size_t)g.B * g.T * g.H, 0.f);
+  a.hT = dalloc((size_t)g.B * g.H, 0.f);
+  a.cT = dalloc((size_t)g.B * g.H, 0.f);
+  a.gates = dalloc(TS * 4, 0.f);
+  a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
+  a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
+  a.trash = dalloc(64, 0.f);
+  const int it = 50;
+  printf("full                         %8.2f us\n", run<0>(g, a, it));
+  printf("no tape stores        (1)    %8.2f us\n", run<1>(g, a, it));
+  printf("no stores at all      (3)    %8.2f us\n", run<3>(g, a, it));
+  printf("no stores, no prefetch (7)   %8.2f us\n", run<7>(g, a, it));
+  printf("+ cheap gates         (15)   %8.2f us\n", run<15>(g, a, it));
+  printf("+ no expansion FMAs   (31)   %8.2f us\n", run<31>(g, a, it));
+  printf("+ no x-wave LDS reads (63)   %8.2f us\n", run<63>(g, a, it));
+  printf("+ no barrier          (127)  %8.2f us\n", run<127>(g, a, it));
+  printf("+ no DPP reduce       (255)  %8.2f us\n", run<255>(g, a, it));
+  printf("only: cheap gates     (8)    %8.2f us\n", run<8>(g, a, it));
+  printf("only: no expansion    (16)   %8.2f us\n", run<16>(g, a, it));
+  printf("only: no LDS reads    (32)   %8.2f us\n", run<32>(g, a, it));
+  printf("only: no barrier      (64)   %8.2f us\n", run<64>(g, a, it));
+  printf("only: no DPP          (128)  %8.2f us\n", run<128>(g, a, it));
+  printf("only: no prefetch     (4)    %8.2f us\n", run<4>(g, a, it));
+  return 0;
+}
