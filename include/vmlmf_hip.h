@@ -106,8 +106,8 @@ int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *
  * k with bit k set in `mask` is bracketed by a HIP event pair recorded on the SAME stream the kernel is
  * launched on (mask 0 = off, 0xff = all).  vmlmf_profile_read()
  * synchronises the recorded events and returns, per internal kernel, the summed duration in microseconds
- * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 wgrad_x,
- * 5 wgrad_h, 6 reduce, 7 finish (vmlmf_kernel_name(i) gives the symbol name rocprofv3 reports).
+ * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 dqx_dx,
+ * 5 wgrad, 6 reduce, 7 finish (vmlmf_kernel_name(i) gives the symbol name rocprofv3 reports).
  */
 #define VMLMF_NKERNELS 8
 int vmlmf_profile_enable(int mask);

@@ -33,8 +33,8 @@ def test_library_loads_and_exports_every_symbol():
     assert lib.vmlmf_abi_version() == 1
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
-        "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "wgrad_x_kernel", "wgrad_h_kernel",
-        "reduce_kernel", "finish_kernel"]
+        "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",
+        "finish_kernel"]
 
 
 def test_query_headline_geometry():

@@ -113,15 +113,24 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.Bp = g.nwg * g.R;
   if ((long long)g.T * g.Bp * g.NT * 4 >= (1LL << 31) || (long long)g.T * g.B * g.H >= (1LL << 31))
     return fail(VMLMF_E_UNSUPPORTED, "T*B*H too large for the 32-bit element offsets of the kernels");
-  // wgrad chunking: about one workgroup per CU, LDS partials <= 48 KiB
+  // backward, parallel part: dqx_dx works on RC rows per workgroup (groups of 8 per barrier); wgrad keeps
+  // register accumulators over RC2 rows per chunk, 5 parts per chunk
   const int TB = g.T * g.B;
-  int rc = (TB + 255) / 256;
+  int rc = ((TB + 255) / 256 + 7) / 8 * 8;
   if (rc < 8) rc = 8;
-  const int rc_lds = (48 * 1024) / (4 * g.NW * g.KQX);
-  if (rc > rc_lds) rc = rc_lds;
   g.RC = rc;
   g.nblk = (TB + rc - 1) / rc;
+  int rc2 = (TB + 63) / 64;
+  if (rc2 < 32) rc2 = 32;
+  g.RC2 = rc2;
+  g.nchunk = (TB + rc2 - 1) / rc2;
   g.NA = 5 * g.KX + 5 * g.KH + 12;
+  {
+    const long long GK = (long long)g.G * g.KH;
+    const long long nb1 = (g.KX + GK + 31) / 32 * 32, nb2 = (GK + 31) / 32 * 32, nb3 = (g.KX + 31) / 32 * 32;
+    g.PCH = (long long)g.NT * 4 * nb1 + (long long)((g.H + 31) / 32) * 32 * nb2 +
+            (long long)((g.I + 31) / 32) * 32 * nb3 + 3LL * g.NT * 4;
+  }
   *out = g;
   return 0;
 }
@@ -133,7 +142,7 @@ struct Layout {
   // forward workspace  : PACK (inference only) | gx
   long long f_pack, f_gx, f_trash, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_wpart, b_cgrad, b_trash, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P) {
@@ -155,7 +164,8 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   o = 0;
   L.b_dpre = o, o += align64(TS * 4);
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
-  L.b_wpart = o, o += align64((long long)g.nblk * g.NA * g.NT);
+  L.b_dqx = o, o += align64(TB * g.KX);
+  L.b_wpart = o, o += align64((long long)g.nchunk * g.PCH);
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT);
   L.b_trash = o, o += 64;
   L.b_total = o;
@@ -282,19 +292,18 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
     if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
   }
   WgxArgs wx;
-  wx.dpre = ws + L.b_dpre, wx.x = x, wx.qx = rs + L.r_qx;
-  wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
-  wx.dx = dx, wx.wpart = ws + L.b_wpart;
+  wx.dpre = ws + L.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
+  wx.dx = dx, wx.dqx = ws + L.b_dqx;
   {
     Scope sc(4, s);
-    if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "wgrad_x")) != 0) return rc;
+    if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   WghArgs wh;
-  wh.dpre = ws + L.b_dpre, wh.y = y, wh.h0 = h0, wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs;
-  wh.wpart = ws + L.b_wpart;
+  wh.dpre = ws + L.b_dpre, wh.x = x, wh.y = y, wh.h0 = h0, wh.qx = rs + L.r_qx, wh.dqx = ws + L.b_dqx;
+  wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs, wh.wpart = ws + L.b_wpart;
   {
     Scope sc(5, s);
-    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad_h")) != 0) return rc;
+    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
   }
   {
     Scope sc(6, s);
@@ -341,7 +350,7 @@ int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
 
 const char* vmlmf_kernel_name(int k) {
   static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
-                                     "wgrad_x_kernel", "wgrad_h_kernel", "reduce_kernel",  "finish_kernel"};
+                                     "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel"};
   return (k >= 0 && k < NKERN) ? names[k] : "";
 }
 

@@ -152,16 +152,32 @@ __device__ inline float ref_vc(const VGeo& g, const RefP& p, int n, int k, int r
 __device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
   return p.b_x[k * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
 }
-// hoisted diagonal-removal vectors (vmlmf.py:102-106 recomputes them every timestep)
+// hoisted diagonal-removal vectors (vmlmf.py:102-106 recomputes them every timestep).
+// All loads are issued before the first FMA (fixed trip count 32 = the rank limit, predicated): a
+// run-time-bounded loop would serialise 2 dependent global loads per rank (~1 us each) in pack_kernel.
 __device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
+  float u[32], v[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    u[r] = r < g.ru0 ? ref_uc(g, p, n, r) : 0.f;
+    v[r] = r < g.ru0 ? ref_vc(g, p, n, k, r) : 0.f;
+  }
   float acc = 0.f;
-  for (int r = 0; r < g.ru0; ++r) acc = fmaf(ref_uc(g, p, n, r), ref_vc(g, p, n, k, r), acc);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
   return p.dia_h[n] - acc;
 }
 __device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {
   if (n >= g.I) return 0.f;
+  float u[32], v[32];
+#pragma unroll
+  for (int r = 0; r < 32; ++r) {
+    u[r] = r < g.rw ? p.u_x[(size_t)n * g.rw + r] : 0.f;
+    v[r] = r < g.rw ? p.v_x[((size_t)k * g.H + n) * g.rw + r] : 0.f;
+  }
   float acc = 0.f;
-  for (int r = 0; r < g.rw; ++r) acc = fmaf(ref_ux(g, p, n, r), ref_vx(g, p, n, k, r), acc);
+#pragma unroll
+  for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
   return p.dia_x[n] - acc;
 }
 

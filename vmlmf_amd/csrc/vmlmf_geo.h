@@ -20,8 +20,11 @@ struct VGeo {
   int R;      // batch rows per workgroup
   int nwg;    // workgroups of the recurrent kernels
   int Bp;     // nwg * R: batch rows of the internal (slot-padded) buffers [T][Bp][NT]
-  int RC;     // (t,b) rows per wgrad workgroup
-  int nblk;   // wgrad workgroups
+  int RC;     // (t,b) rows per dqx_dx workgroup
+  int nblk;   // dqx_dx workgroups
+  int RC2;    // (t,b) rows per wgrad chunk
+  int nchunk; // wgrad chunks (grid.y)
+  long long PCH;  // floats of partial products per chunk (wgrad_mfma_kernel)
   int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12
   long long sxT, sxB, syT, syB;  // element strides of x/dx and y/dy
   int time_major, training;

@@ -14,11 +14,11 @@ struct BwdArgs {
   float* trash;
 };
 struct WgxArgs {
-  const float *dpre, *x, *qx, *VRX, *UXO, *EXI;
-  float *dx, *wpart;
+  const float *dpre, *VRX, *UXO, *EXI;
+  float *dx, *dqx;
 };
 struct WghArgs {
-  const float *dpre, *y, *h0, *Qs, *dQs;
+  const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
   float* wpart;
 };
 

@@ -210,34 +210,6 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// reduce: cgrad[a][slot] = sum over wgrad workgroups, fixed order (deterministic)
-// ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) reduce_kernel(int NA, int NT, int nblk,
-                                                     const float* __restrict__ wpart,
-                                                     float* __restrict__ cgrad) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const long long n = (long long)NA * NT;
-  if (e >= n) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblk; b += 4) {
-    s0 += wpart[(long long)(b + 0) * n + e];
-    s1 += wpart[(long long)(b + 1) * n + e];
-    s2 += wpart[(long long)(b + 2) * n + e];
-    s3 += wpart[(long long)(b + 3) * n + e];
-  }
-  for (; b < nblk; ++b) s0 += wpart[(long long)b * n + e];
-  cgrad[e] = (s0 + s1) + (s2 + s3);
-}
-
-int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s) {
-  const long long n = (long long)g.NA * g.NT;
-  hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g.NA, g.NT, g.nblk,
-                     wpart, cgrad);
-  return (int)hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------
 // finish: canonical gradients -> reference layouts (oracle: uncanonicalize_grads)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o) {

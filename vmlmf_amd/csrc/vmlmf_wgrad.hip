@@ -1,20 +1,20 @@
 // Weight-gradient kernels (gfx950): the batched, non-recurrent half of the backward pass.
 // Every (t,b) row is independent here, so the whole chip works on it after rec_bwd_kernel has produced
-// dpre[t,b,n,k].  Thread <-> hidden unit as in the recurrent kernels; each thread keeps the gradient
-// accumulators of ITS unit's weight rows in registers across the workgroup's RC rows, then writes them as
-// one partial (summed in fixed order by reduce_kernel -> deterministic, no float atomics).
+// dpre[t,b,n,k].  Thread <-> hidden unit as in the recurrent kernels.
 //
-//   wgrad_x:  dqx = dpre V_x (DPP reduce), dx = dqx U_x^T + dpre .* ex,
-//             dV_x += dpre^T qx, dU_x += x^T dqx, d(ex) += dpre .* x
-//   wgrad_h:  dV_h += dpre^T Q, dU_h += h_{t-1}^T dQ, d(eh) += dpre .* h_{t-1}, db += dpre
-// (Q, dQ and qx are the rank-space vectors the forward / backward recurrent kernels already computed.)
+//   dqx_dx_kernel   per row: dqx = dpre V_x (v_fmac_f32_dpp reduce, rows in groups of 8 per barrier),
+//                   dx = dqx U_x^T + dpre .* ex.
+//   wgrad_mfma_kernel  every weight gradient as A^T B over the rows on fp32 MFMA (see below).
+//   reduce_cg_kernel   fixed-order sum of the per-chunk partial products (deterministic, no float atomics).
 #include "vmlmf_launch.h"
 
+constexpr int RG = 8;  // rows per barrier group in dqx_dx_kernel
+
 template <int KX, int MAXT>
-__global__ void __launch_bounds__(MAXT) wgrad_x_kernel(VGeo g, WgxArgs a) {
+__global__ void __launch_bounds__(MAXT) dqx_dx_kernel(VGeo g, WgxArgs a) {
   constexpr int NPX = (KX + 15) / 16, KQX = NPX * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NT = g.NT, NW = g.NW, W = g.W, H = g.H, B = g.B;
+  const int NT = g.NT, NW = g.NW, W = g.W, B = g.B;
   const int TB = g.T * B;
   const int grp = tid / (64 * W);
   const int m = tid - grp * 64 * W;
@@ -22,198 +22,296 @@ __global__ void __launch_bounds__(MAXT) wgrad_x_kernel(VGeo g, WgxArgs a) {
   const int n = grp * g.Hg + (valid ? m : 0);
   const bool has_x = valid && n < g.I;
   const bool wave_x = __ballot(has_x) != 0ull;
-  const int row0 = blockIdx.x * g.RC;
-  const int nrows = (TB - row0 < g.RC) ? (TB - row0) : g.RC;
 
   extern __shared__ float4 smem4[];
-  float* partx = reinterpret_cast<float*>(smem4);  // [RC][NW][KQX]
+  float* partx = reinterpret_cast<float*>(smem4);  // [RG][NW][KQX]
+  float* dqs = partx + RG * NW * KQX;              // [RG][KQX]
 
-  {  // phase 1: dqx partials for every row of the chunk
-    float vrx[4][KQX];
+  float vrx[4][KQX], uxo[KX], exi[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 4; ++k) {
 #pragma unroll
-      for (int j = 0; j < KQX; ++j) vrx[k][j] = a.VRX[(size_t)(k * KQX + j) * NT + tid];
-    for (int rl = 0; rl < nrows; ++rl) {
-      const int row = row0 + rl, t = row / B, b = row - t * B;
-      const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);   // slot-padded, zeros in pad slots
-      const float dp[4] = {d.x, d.y, d.z, d.w};
+    for (int j = 0; j < KQX; ++j) vrx[k][j] = a.VRX[(size_t)(k * KQX + j) * NT + tid];
+    exi[k] = a.EXI[k * NT + tid];
+  }
+#pragma unroll
+  for (int r = 0; r < KX; ++r) uxo[r] = a.UXO[(size_t)r * NT + tid];
+
+  const int row_end = (blockIdx.x + 1) * g.RC < TB ? (blockIdx.x + 1) * g.RC : TB;
+  for (int row0 = blockIdx.x * g.RC; row0 < row_end; row0 += RG) {
+    float4 d[RG];
+#pragma unroll
+    for (int rl = 0; rl < RG; ++rl) {
+      const int row = row0 + rl < row_end ? row0 + rl : row_end - 1;
+      const int t = row / B, b = row - t * B;
+      d[rl] = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);  // slot-padded: zeros in pad slots
+    }
+#pragma unroll
+    for (int rl = 0; rl < RG; ++rl) {
+      float dp[4] = {d[rl].x, d[rl].y, d[rl].z, d[rl].w};
+      dpp_fence(dp[0]);
+      dpp_fence(dp[1]);
+      dpp_fence(dp[2]);
+      dpp_fence(dp[3]);
 #pragma unroll
       for (int p = 0; p < NPX; ++p) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         sfor<16>([&](auto K) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) acc[k] = fmaf(ror16<K>(dp[k]), vrx[k][p * 16 + K], acc[k]);
+          fmac_ror<K>(acc[0], dp[0], vrx[0][p * 16 + K]);
+          fmac_ror<K>(acc[1], dp[1], vrx[1][p * 16 + K]);
+          fmac_ror<K>(acc[2], dp[2], vrx[2][p * 16 + K]);
+          fmac_ror<K>(acc[3], dp[3], vrx[3][p * 16 + K]);
         });
         const float s = rowsum4((acc[0] + acc[1]) + (acc[2] + acc[3]));
         if (lane < 16) partx[(size_t)(rl * NW + wave) * KQX + p * 16 + lane] = s;
       }
     }
-  }
-  __syncthreads();
-
-  float avx[4][KX], aux[KX], aex[4], uxo[KX], exi[4];
+    __syncthreads();
+    for (int e = tid; e < RG * KQX; e += NT) {   // finish the cross-wave sum: one thread per (row, rank)
+      const int rl = e / KQX, r = e - rl * KQX;
+      float s = 0.f;
+      for (int w = 0; w < NW; ++w) s += partx[(size_t)(rl * NW + w) * KQX + r];
+      dqs[e] = s;
+      if (row0 + rl < row_end && r < KX) a.dqx[(size_t)(row0 + rl) * KX + r] = s;
+    }
+    __syncthreads();
+    if (wave_x && a.dx != nullptr) {  // wave-uniform: only waves holding x-units produce dx
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+      for (int rl = 0; rl < RG; ++rl) {
+        const int row = row0 + rl;
+        float dxv = (d[rl].x * exi[0] + d[rl].y * exi[1]) + (d[rl].z * exi[2] + d[rl].w * exi[3]);
 #pragma unroll
-    for (int r = 0; r < KX; ++r) avx[k][r] = 0.f;
-    aex[k] = 0.f;
-    exi[k] = a.EXI[k * NT + tid];
-  }
-#pragma unroll
-  for (int r = 0; r < KX; ++r) {
-    aux[r] = 0.f;
-    uxo[r] = a.UXO[(size_t)r * NT + tid];
-  }
-
-  for (int rl = 0; rl < nrows; ++rl) {
-    const int row = row0 + rl;
-    const int t = row / B, b = row - t * B;
-    const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);
-    const float dp[4] = {d.x, d.y, d.z, d.w};
-    const float* qxr = a.qx + (size_t)row * KX;
-#pragma unroll
-    for (int r4 = 0; r4 < KX / 4; ++r4) {
-      const float4 q = ld4(qxr + 4 * r4);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        avx[k][4 * r4 + 0] = fmaf(dp[k], q.x, avx[k][4 * r4 + 0]);
-        avx[k][4 * r4 + 1] = fmaf(dp[k], q.y, avx[k][4 * r4 + 1]);
-        avx[k][4 * r4 + 2] = fmaf(dp[k], q.z, avx[k][4 * r4 + 2]);
-        avx[k][4 * r4 + 3] = fmaf(dp[k], q.w, avx[k][4 * r4 + 3]);
+        for (int r4 = 0; r4 < KX / 4; ++r4) {
+          const float4 q = ld4(dqs + rl * KQX + 4 * r4);
+          dxv = fmaf(q.x, uxo[4 * r4 + 0], dxv);
+          dxv = fmaf(q.y, uxo[4 * r4 + 1], dxv);
+          dxv = fmaf(q.z, uxo[4 * r4 + 2], dxv);
+          dxv = fmaf(q.w, uxo[4 * r4 + 3], dxv);
+        }
+        if (has_x && row < row_end) {
+          const int t = row / B, b = row - t * B;
+          a.dx[t * g.sxT + b * g.sxB + n] = dxv;
+        }
       }
     }
-    if (wave_x) {  // wave-uniform: only waves that hold x-units need dqx
-      const float xv = has_x ? a.x[t * g.sxT + b * g.sxB + n] : 0.f;
-      float dxv = (dp[0] * exi[0] + dp[1] * exi[1]) + (dp[2] * exi[2] + dp[3] * exi[3]);
-#pragma unroll
-      for (int k = 0; k < 4; ++k) aex[k] = fmaf(dp[k], xv, aex[k]);
-#pragma unroll
-      for (int r4 = 0; r4 < KX / 4; ++r4) {
-        float4 q = f4zero();
-        for (int w = 0; w < NW; ++w) q = f4add(q, ld4(partx + (size_t)(rl * NW + w) * KQX + 4 * r4));
-        aux[4 * r4 + 0] = fmaf(xv, q.x, aux[4 * r4 + 0]);
-        aux[4 * r4 + 1] = fmaf(xv, q.y, aux[4 * r4 + 1]);
-        aux[4 * r4 + 2] = fmaf(xv, q.z, aux[4 * r4 + 2]);
-        aux[4 * r4 + 3] = fmaf(xv, q.w, aux[4 * r4 + 3]);
-        dxv = fmaf(q.x, uxo[4 * r4 + 0], dxv);
-        dxv = fmaf(q.y, uxo[4 * r4 + 1], dxv);
-        dxv = fmaf(q.z, uxo[4 * r4 + 2], dxv);
-        dxv = fmaf(q.w, uxo[4 * r4 + 3], dxv);
-      }
-      if (has_x && a.dx != nullptr) a.dx[t * g.sxT + b * g.sxB + n] = dxv;
-    }
   }
-  float* wp = a.wpart + (size_t)blockIdx.x * g.NA * NT + tid;
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int r = 0; r < KX; ++r) wp[(size_t)va_vx(g, k, r) * NT] = avx[k][r];
-    wp[(size_t)va_ex(g, k) * NT] = aex[k];
-  }
-#pragma unroll
-  for (int r = 0; r < KX; ++r) wp[(size_t)va_ux(g, r) * NT] = aux[r];
 }
 
-template <int KH, bool FLAT, int MAXT>
-__global__ void __launch_bounds__(MAXT) wgrad_h_kernel(VGeo g, WghArgs a) {
-  const int tid = threadIdx.x;
-  const int NT = g.NT, W = g.W, H = g.H, B = g.B;
+// ---------------------------------------------------------------------------------------------------
+// wgrad_mfma_kernel: every weight gradient is a product  C = A^T B  contracted over the (t,b) rows, with a
+// skinny B (the rank-space vectors).  One wave owns a 32-wide tile of A's columns and up to three 32-wide
+// tiles of B's columns for one chunk of rows, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; each
+// instruction contracts 2 rows).  Three products share the kernel (wave task -> mode):
+//   mode 1  A = dpre  [rows x (slot,k)]   B = [qx | Q_0 | Q_1]  -> dV_x, dV_h   (+ column sums d(eh), d(ex), db)
+//   mode 2  A = h_{t-1} [rows x unit]     B = [dQ_0 | dQ_1]      -> dU_h
+//   mode 3  A = x     [rows x input]      B = dqx                -> dU_x
+// Operand layout of the instruction (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5]
+// and B[k = l>>5][j = l&31]; result register r of lane l is C[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
+// Partials per chunk go to P (summed in fixed order by reduce_kernel: deterministic, no float atomics).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct AtbArgs {
+  const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
+  float* P;
+};
+
+template <int MODE>
+__device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const int mt, const int chunk,
+                                         const int lane) {
+  const int B = g.B, H = g.H, NT = g.NT, KX = g.KX, GK = g.G * g.KH;
   const int TB = g.T * B;
-  const int grp = tid / (64 * W);
-  const int m = tid - grp * 64 * W;
-  const bool valid = m < g.Hg;
-  const int n = grp * g.Hg + (valid ? m : 0);
-  const int ugrp = __builtin_amdgcn_readfirstlane(grp);  // groups are wave-aligned
-  const int row0 = blockIdx.x * g.RC;
-  const int nrows = (TB - row0 < g.RC) ? (TB - row0) : g.RC;
-  const int GK = g.G * KH;
-  // offsets (floats) inside a row's G*KH rank-space record
-  const int qoff01 = FLAT ? 0 : ugrp * KH;                 // Q used by gates i,f
-  const int qoff23 = FLAT ? KH : ugrp * KH;                // Q used by gates o,n
-  const int d0 = ugrp * KH;                                // dQ[dest] for block 0: dest = grp
-  const int d1 = ((ugrp - 1 + g.G) % g.G) * KH;            // block 1: dest = grp - 1
-
-  float avc[4][KH], auc[KH], aeh[4], ab[4];
+  const int MT2 = (H + 31) / 32, MT3 = (g.I + 31) / 32;
+  const int row0 = chunk * g.RC2;
+  const int row1 = row0 + g.RC2 < TB ? row0 + g.RC2 : TB;
+  const int li = lane & 31, lk = lane >> 5;
+  const int NB = MODE == 1 ? KX + GK : (MODE == 2 ? GK : KX);     // B columns
+  const int nbt = (NB + 31) / 32;
+  const int col = mt * 32 + li;                                     // A column of this lane
+  int n1 = 0;
+  bool v1 = false;
+  if (MODE == 1) v1 = vg_slot_unit(g, col >> 2, n1);                // unit of this (slot,k) column
+  const int an = MODE == 1 ? (v1 ? n1 : 0) : (MODE == 2 ? (col < H ? col : 0) : (col < g.I ? col : 0));
+  const float amask = MODE == 1 ? 1.f : ((MODE == 2 ? col < H : col < g.I) ? 1.f : 0.f);
+  const float hmask = (MODE == 1 && v1) ? 1.f : 0.f;
+  const bool xm = MODE == 1 && v1 && n1 < g.I;
+  const int xn = xm ? n1 : 0;
+  // B column sources (per lane, fixed): pointer + row stride, masked when out of range
+  const float* bsrc[3];
+  int bstr[3];
+  float bmask[3];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-#pragma unroll
-    for (int rr = 0; rr < KH; ++rr) avc[k][rr] = 0.f;
-    aeh[k] = 0.f;
-    ab[k] = 0.f;
-  }
-#pragma unroll
-  for (int rr = 0; rr < KH; ++rr) auc[rr] = 0.f;
-
-  for (int rl = 0; rl < nrows; ++rl) {
-    const int row = row0 + rl;
-    const int t = row / B, b = row - t * B;
-    const float4 d = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);
-    const float dp[4] = {d.x, d.y, d.z, d.w};
-    float hp = 0.f;
-    if (valid) {
-      if (t > 0)
-        hp = a.y[(t - 1) * g.syT + b * g.syB + n];
-      else if (a.h0 != nullptr)
-        hp = a.h0[(size_t)b * H + n];
+  for (int j = 0; j < 3; ++j) {
+    const int c = j * 32 + li;
+    const bool okc = j < nbt && c < NB;
+    bmask[j] = okc ? 1.f : 0.f;
+    const int cc = okc ? c : 0;
+    if (MODE == 1) {
+      bsrc[j] = cc < KX ? a.qx + cc : a.Qs + (cc - KX);
+      bstr[j] = cc < KX ? KX : GK;
+    } else if (MODE == 2) {
+      bsrc[j] = a.dQs + cc;
+      bstr[j] = GK;
+    } else {
+      bsrc[j] = a.dqx + cc;
+      bstr[j] = KX;
     }
-    const float* Qr = a.Qs + (size_t)row * GK;
-    const float* dQr = a.dQs + (size_t)row * GK;
+  }
+  const bool has_h0 = a.h0 != nullptr;
+
+  f32x16 acc[3];
 #pragma unroll
-    for (int c = 0; c < KH / 4; ++c) {
-      const float4 qa = ld4(Qr + qoff01 + 4 * c);
-      const float4 qb = FLAT ? ld4(Qr + qoff23 + 4 * c) : qa;
-      const float4 dq = ld4(dQr + ((g.G == 2 && 4 * c >= g.off1) ? d1 : d0) + 4 * c);
+  for (int j = 0; j < 3; ++j)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float4 q = (k >= 2) ? qb : qa;
-        avc[k][4 * c + 0] = fmaf(dp[k], q.x, avc[k][4 * c + 0]);
-        avc[k][4 * c + 1] = fmaf(dp[k], q.y, avc[k][4 * c + 1]);
-        avc[k][4 * c + 2] = fmaf(dp[k], q.z, avc[k][4 * c + 2]);
-        avc[k][4 * c + 3] = fmaf(dp[k], q.w, avc[k][4 * c + 3]);
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  float e_h = 0.f, e_x = 0.f, e_b = 0.f;
+
+  constexpr int U = 8;   // row pairs per batch: every load of a batch is issued (branch-free) before its MFMAs
+  for (int rb = row0; rb < row1; rb += 2 * U) {
+    float av[U], bv[U][3], hv[U], xv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int r = rb + 2 * u + lk;
+      const bool ok = r < row1;
+      const int rc = ok ? r : row1 - 1;
+      const int t = rc / B, b = rc - t * B;
+      // h_{t-1}: y[t-1] for t > 0, else h0 (or 0): address select + mask, no branch
+      const float* hp = t > 0 ? a.y + ((size_t)(t - 1) * g.syT + (size_t)b * g.syB)
+                              : (has_h0 ? a.h0 + (size_t)b * H : a.y + (size_t)b * g.syB);
+      const float hm = (t > 0 || has_h0) ? 1.f : 0.f;
+      const float okf = ok ? 1.f : 0.f;
+      if (MODE == 1) {
+        av[u] = okf * a.dpre[((size_t)(t * g.Bp + b) * NT) * 4 + col];
+        hv[u] = hmask * hm * hp[an];
+        xv[u] = xm ? a.x[(size_t)t * g.sxT + (size_t)b * g.sxB + xn] : 0.f;
+      } else if (MODE == 2) {
+        av[u] = okf * amask * hm * hp[an];
+        hv[u] = 0.f, xv[u] = 0.f;
+      } else {
+        av[u] = okf * amask * a.x[(size_t)t * g.sxT + (size_t)b * g.sxB + an];
+        hv[u] = 0.f, xv[u] = 0.f;
       }
-      auc[4 * c + 0] = fmaf(hp, dq.x, auc[4 * c + 0]);
-      auc[4 * c + 1] = fmaf(hp, dq.y, auc[4 * c + 1]);
-      auc[4 * c + 2] = fmaf(hp, dq.z, auc[4 * c + 2]);
-      auc[4 * c + 3] = fmaf(hp, dq.w, auc[4 * c + 3]);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) bv[u][j] = bmask[j] * bsrc[j][(size_t)rc * bstr[j]];
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      aeh[k] = fmaf(dp[k], hp, aeh[k]);
-      ab[k] += dp[k];
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+      if (MODE == 1) {
+        e_h = fmaf(av[u], hv[u], e_h);
+        e_x = fmaf(av[u], xv[u], e_x);
+        e_b += av[u];
+      }
     }
   }
-  float* wp = a.wpart + (size_t)blockIdx.x * g.NA * NT + tid;
+
+  // partial layout per chunk: C1 [NT*4][NB1p] | C2 [M2p][NB2p] | C3 [M3p][NB3p] | E [3][NT*4]
+  const int NB1p = (KX + GK + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
+  const size_t o2 = (size_t)NT * 4 * NB1p, o3 = o2 + (size_t)MT2 * 32 * NB2p, oe = o3 + (size_t)MT3 * 32 * NB3p;
+  float* P = a.P + (size_t)chunk * g.PCH;
+  float* C = MODE == 1 ? P : (MODE == 2 ? P + o2 : P + o3);
+  const int ldc = MODE == 1 ? NB1p : (MODE == 2 ? NB2p : NB3p);
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int j = 0; j < 3; ++j) {
+    if (j < nbt) {
 #pragma unroll
-    for (int rr = 0; rr < KH; ++rr) wp[(size_t)va_vc(g, k, rr) * NT] = avc[k][rr];
-    wp[(size_t)va_eh(g, k) * NT] = aeh[k];
-    wp[(size_t)va_b(g, k) * NT] = ab[k];
+      for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+        C[(size_t)(mt * 32 + i) * ldc + j * 32 + li] = acc[j][r];
+      }
+    }
   }
-#pragma unroll
-  for (int rr = 0; rr < KH; ++rr) wp[(size_t)va_uc(g, rr) * NT] = auc[rr];
+  if (MODE == 1) {   // column sums: the two half-waves hold the even / odd rows
+    e_h += __shfl_xor(e_h, 32);
+    e_x += __shfl_xor(e_x, 32);
+    e_b += __shfl_xor(e_b, 32);
+    if (lk == 0) {
+      P[oe + 0 * (size_t)NT * 4 + col] = e_h;
+      P[oe + 1 * (size_t)NT * 4 + col] = e_x;
+      P[oe + 2 * (size_t)NT * 4 + col] = e_b;
+    }
+  }
 }
 
+__global__ void __launch_bounds__(256) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int task = blockIdx.x * 4 + wave;
+  const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
+  if (task < MT1)
+    atb_task<1>(g, a, task, blockIdx.y, lane);
+  else if (task < MT1 + MT2)
+    atb_task<2>(g, a, task - MT1, blockIdx.y, lane);
+  else if (task < MT1 + MT2 + MT3)
+    atb_task<3>(g, a, task - MT1 - MT2, blockIdx.y, lane);
+}
+
+// One thread per element of a chunk's partial block P (coalesced over chunks), fixed-order sum over the
+// chunks (deterministic), then scatter into cgrad[accumulator][slot] (layout finish_kernel reads).
+__global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __restrict__ Pall,
+                                                        float* __restrict__ cgrad) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.PCH) return;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  int c = 0;
+  for (; c + 7 < g.nchunk; c += 8) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = Pall[(size_t)(c + i) * g.PCH + e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i & 3] += v[i];
+  }
+  for (; c < g.nchunk; ++c) s[0] += Pall[(size_t)c * g.PCH + e];
+  const float total = (s[0] + s[1]) + (s[2] + s[3]);
+
+  const int KX = g.KX, KH = g.KH, GK = g.G * KH, NT = g.NT;
+  const int MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
+  const int NB1p = (KX + GK + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
+  const long long o2 = (long long)NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p,
+                  oe = o3 + (long long)MT3 * 32 * NB3p;
+  if (e < o2) {                       // C1[(slot,k)][j]
+    const int i = (int)(e / NB1p), j = (int)(e - (long long)i * NB1p), slot = i >> 2, k = i & 3;
+    if (j < KX) {
+      cgrad[(size_t)va_vx(g, k, j) * NT + slot] = total;
+    } else if (j < KX + GK) {
+      int n;
+      const bool valid = vg_slot_unit(g, slot, n);
+      const int q = (j - KX) / KH, rr = (j - KX) - q * KH;
+      const int qsel = g.flat ? (k >= 2 ? 1 : 0) : (valid ? n / g.Hg : 0);
+      if (q == qsel) cgrad[(size_t)va_vc(g, k, rr) * NT + slot] = total;
+    }
+  } else if (e < o3) {                // C2[n][dest*KH + rr]
+    const long long e2 = e - o2;
+    const int n = (int)(e2 / NB2p), j = (int)(e2 - (long long)n * NB2p);
+    if (n < g.H && j < GK) {
+      const int dest = j / KH, rr = j - dest * KH;
+      const int s_ = (g.G == 2 && rr >= g.off1) ? 1 : 0;
+      const int grp = n / g.Hg;
+      if (dest == (grp - s_ + g.G) % g.G) cgrad[(size_t)va_uc(g, rr) * NT + vg_slot(g, n)] = total;
+    }
+  } else if (e < oe) {                // C3[m][r]
+    const long long e3 = e - o3;
+    const int m = (int)(e3 / NB3p), r = (int)(e3 - (long long)m * NB3p);
+    if (m < g.I && r < KX) cgrad[(size_t)va_ux(g, r) * NT + vg_slot(g, m)] = total;
+  } else {                            // E[which][(slot,k)]
+    const long long e4 = e - oe;
+    const int which = (int)(e4 / (NT * 4)), i = (int)(e4 - (long long)which * NT * 4), slot = i >> 2, k = i & 3;
+    const int acc = which == 0 ? va_eh(g, k) : (which == 1 ? va_ex(g, k) : va_b(g, k));
+    cgrad[(size_t)acc * NT + slot] = total;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 template <int MAXT>
 static int launch_x_t(const VGeo& g, const WgxArgs& a, hipStream_t s) {
-  const size_t lds = sizeof(float) * (size_t)g.RC * g.NW * g.KQX;
+  const size_t lds = sizeof(float) * (size_t)(RG * g.NW * g.KQX + RG * g.KQX);
   const dim3 grid(g.nblk), block(g.NT);
   switch (g.KX) {
-    case 8:
-      hipLaunchKernelGGL((wgrad_x_kernel<8, MAXT>), grid, block, lds, s, g, a);
-      break;
-    case 16:
-      hipLaunchKernelGGL((wgrad_x_kernel<16, MAXT>), grid, block, lds, s, g, a);
-      break;
-    case 24:
-      hipLaunchKernelGGL((wgrad_x_kernel<24, MAXT>), grid, block, lds, s, g, a);
-      break;
-    case 32:
-      hipLaunchKernelGGL((wgrad_x_kernel<32, MAXT>), grid, block, lds, s, g, a);
-      break;
-    default:
-      return -3;
+    case 8: hipLaunchKernelGGL((dqx_dx_kernel<8, MAXT>), grid, block, lds, s, g, a); break;
+    case 16: hipLaunchKernelGGL((dqx_dx_kernel<16, MAXT>), grid, block, lds, s, g, a); break;
+    case 24: hipLaunchKernelGGL((dqx_dx_kernel<24, MAXT>), grid, block, lds, s, g, a); break;
+    case 32: hipLaunchKernelGGL((dqx_dx_kernel<32, MAXT>), grid, block, lds, s, g, a); break;
+    default: return -3;
   }
   return (int)hipGetLastError();
 }
@@ -224,34 +322,16 @@ int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s) {
   return -3;
 }
 
-template <int KH, int MAXT>
-static int launch_h_kh(const VGeo& g, const WghArgs& a, hipStream_t s) {
-  const dim3 grid(g.nblk), block(g.NT);
-  if (g.flat)
-    hipLaunchKernelGGL((wgrad_h_kernel<KH, true, MAXT>), grid, block, 0, s, g, a);
-  else
-    hipLaunchKernelGGL((wgrad_h_kernel<KH, false, MAXT>), grid, block, 0, s, g, a);
+int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
+  AtbArgs a;
+  a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
+  a.P = w.wpart;
+  const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.I + 31) / 32;
+  hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((tasks + 3) / 4, g.nchunk), dim3(256), 0, s, g, a);
   return (int)hipGetLastError();
 }
 
-template <int MAXT>
-static int launch_h_t(const VGeo& g, const WghArgs& a, hipStream_t s) {
-  switch (g.KH) {
-    case 8:
-      return launch_h_kh<8, MAXT>(g, a, s);
-    case 16:
-      return launch_h_kh<16, MAXT>(g, a, s);
-    case 24:
-      return launch_h_kh<24, MAXT>(g, a, s);
-    case 32:
-      return launch_h_kh<32, MAXT>(g, a, s);
-    default:
-      return -3;
-  }
-}
-
-int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s) {
-  if (g.NT <= 256) return launch_h_t<256>(g, a, s);
-  if (g.NT <= 512) return launch_h_t<512>(g, a, s);
-  return -3;
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad);
+  return (int)hipGetLastError();
 }
