@@ -1,0 +1,123 @@
+"""GPU: the nn.Module surface (what the reference's harness calls) against golden vectors from the reference:
+Net + Adam loop (train.py:58-65), two-layer MyLSTM at BASELINE config C's shape, LM state carry
+(lm_test.py:196-203), bare cell calls."""
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_oracle as O
+from conftest import load_golden
+from hip_util import assert_out, assert_grad
+from vmlmf_amd import MyLSTM, MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGroup, Net
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def load_cell(cell, P, group_sep=None):
+    with torch.no_grad():
+        for k, v in P.items():
+            if hasattr(cell, "layers") and k in cell.layers:
+                cell.layers[k].copy_(torch.tensor(v))
+            elif "." in k:                                   # u_h.0 -> ParameterList
+                name, idx = k.split(".")
+                getattr(cell, name)[int(idx)].copy_(torch.tensor(v))
+            else:
+                getattr(cell, k).copy_(torch.tensor(v))
+
+
+def test_net_adam_three_steps_vs_reference():
+    d = load_golden("cfgA_net_adam3")
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    torch.manual_seed(0)                                      # same creation order => same lin init
+    net = Net(I, layer_sizes=[H], w_rank=rw, u_rank=[ru], model=MyLSTM, cell=MyVMLMFCell)
+    assert np.array_equal(net.lin.weight.detach().numpy(), d["lin_w"])
+    load_cell(net.rnn.rnncells[0], O.make_params(O.V1, I, H, rw, ru, seed=int(d["seeds"][0])))
+    net = net.to(DEV)
+    x, tgt = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    x, tgt = torch.tensor(x, device=DEV), torch.tensor(tgt, device=DEV)
+    opt = torch.optim.Adam(net.parameters(), lr=0.002)
+    for step in range(3):
+        net.zero_grad()
+        out = net(x)
+        loss = torch.nn.functional.cross_entropy(out, tgt.long())
+        loss.backward()
+        opt.step()
+        assert abs(loss.item() - float(d["losses"][step])) < 2e-5, (step, loss.item(), d["losses"][step])
+        assert_out(out.detach().cpu().numpy(), d["logits"][step], f"logits[{step}]", atol=2e-5)
+    assert all(p.grad is None for p in net.cell.parameters())          # the unused duplicate stays untouched
+    sd = net.state_dict()
+    for k, v in d["final"].items():
+        assert_out(sd[k].cpu().numpy(), v, "final." + k, atol=2e-5, rtol=1e-3)
+
+
+def test_config_c_two_layer_mylstm_vs_reference():
+    """BASELINE config C shape (fp32): Opportunity, 2 layers H=256 rank 24, B=128 T=24 I=77."""
+    d = load_golden("cfgC_v1_opp2")
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    rnn = MyLSTM(I, hidden_layer_sizes=[H, H], batch_first=True, w_rank=rw, u_ranks=[ru], cell=MyVMLMFCell)
+    load_cell(rnn.rnncells[0], O.make_params(O.V1, I, H, rw, ru, seed=int(d["seeds"][0])))
+    load_cell(rnn.rnncells[1], O.make_params(O.V1, H, H, rw, ru, seed=int(d["seeds"][1])))
+    rnn = rnn.to(DEV)
+    x_np, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][2]), classes=18)
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][3]))).standard_normal((B, T, H)).astype(np.float32)
+    x = torch.tensor(x_np, device=DEV, requires_grad=True)
+    y, hcat = rnn(x)
+    (y * torch.tensor(dy, device=DEV)).sum().backward()
+    assert_out(y.detach().cpu().numpy()[:, ::6], d["y_s"], "y")
+    assert_out(hcat.detach().cpu().numpy(), d["hT"], "hT")
+    assert_grad(x.grad.cpu().numpy()[::4], d["dx_s"], "dx")
+    for li, G in ((0, d["G0"]), (1, d["G1"])):
+        for k, v in G.items():
+            assert_grad(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, f"layer{li}.{k}")
+
+
+def test_lm_state_carry_two_minibatches_vs_reference():
+    d = load_golden("lm_v3_carry")
+    _, B, T, H, _, rw, ru = (int(v) for v in d["meta"])
+    layer = MyVMLSTM(H, H, w_rank=rw, u_ranks=ru)
+    load_cell(layer, d["P"])
+    layer = layer.to(DEV)
+    states = (torch.zeros(B, H, device=DEV), torch.zeros(B, H, device=DEV))
+    for i in range(2):
+        layer.zero_grad()
+        states = (states[0].detach(), states[1].detach())
+        y, states = layer(torch.tensor(d[f"x{i}"], device=DEV), states)
+        loss = torch.mean(y * torch.tensor(d[f"w{i}"], device=DEV)) * B
+        loss.backward()
+        assert abs(loss.item() - float(d[f"loss{i}"][0])) < 1e-5
+        assert_out(states[0].detach().cpu().numpy(), d[f"hT{i}"], "hT")
+        assert_out(states[1].detach().cpu().numpy(), d[f"cT{i}"], "cT")
+        for k, v in d[f"G{i}"].items():
+            assert_grad(getattr(layer, k).grad.cpu().numpy(), v, f"carry{i}.{k}")
+
+
+@pytest.mark.parametrize("name,cls", [("cell_v1", MyVMLMFCell), ("cell_v2", MyVMLMFCellg2),
+                                      ("cell_v3", MyVMLSTM), ("cell_v4", MyVMLSTMGroup)])
+def test_bare_cell_calls_vs_reference(name, cls):
+    d = load_golden(name)
+    meta = [int(v) for v in d["meta"]]
+    variant, B, _, I, H, rw = meta[:6]
+    ru = meta[6:]
+    if variant in (O.V1, O.V3):
+        cell = cls(I, H, w_rank=rw, u_ranks=ru[0])
+    else:
+        cell = cls(I, H, w_rank=rw, u_ranks=ru)
+    load_cell(cell, d["P"])
+    cell = cell.to(DEV)
+    x = torch.tensor(d["x"], device=DEV)
+    h = torch.tensor(d["h0"], device=DEV)
+    c = torch.tensor(d["c0"], device=DEV)
+    with torch.no_grad():
+        hn, cn = cell(x, (h, c)) if variant in (O.V1, O.V2) else cell.lstm_step(x, h, c)
+    assert_out(hn.cpu().numpy(), d["h1"], "h1")
+    assert_out(cn.cpu().numpy(), d["c1"], "c1")
+
+
+def test_unsupported_shape_raises_and_never_falls_back():
+    """BASELINE config E (H=650, ranks 32/[32,32]) is outside this round's kernels: explicit error."""
+    from vmlmf_amd import _lib
+    layer = MyVMLSTMGroup(650, 650, w_rank=32, u_ranks=[32, 32]).to(DEV)
+    with pytest.raises(_lib.VmlmfError) as ei:
+        layer(torch.zeros(3, 4, 650, device=DEV), (torch.zeros(4, 650, device=DEV), torch.zeros(4, 650, device=DEV)))
+    assert ei.value.code == _lib.E_UNSUPPORTED

@@ -115,7 +115,7 @@ struct AtbArgs {
   float* P;
 };
 
-template <int MODE>
+template <int MODE, int NBT>
 __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const int mt, const int chunk,
                                          const int lane) {
   const int B = g.B, H = g.H, NT = g.NT, KX = g.KX, GK = g.G * g.KH;
@@ -125,7 +125,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const int row1 = row0 + g.RC2 < TB ? row0 + g.RC2 : TB;
   const int li = lane & 31, lk = lane >> 5;
   const int NB = MODE == 1 ? KX + GK : (MODE == 2 ? GK : KX);     // B columns
-  const int nbt = (NB + 31) / 32;
+  constexpr int nbt = NBT;
   const int col = mt * 32 + li;                                     // A column of this lane
   int n1 = 0;
   bool v1 = false;
@@ -136,11 +136,11 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const bool xm = MODE == 1 && v1 && n1 < g.I;
   const int xn = xm ? n1 : 0;
   // B column sources (per lane, fixed): pointer + row stride, masked when out of range
-  const float* bsrc[3];
-  int bstr[3];
-  float bmask[3];
+  const float* bsrc[NBT];
+  unsigned bstr[NBT];
+  float bmask[NBT];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NBT; ++j) {
     const int c = j * 32 + li;
     const bool okc = j < nbt && c < NB;
     bmask[j] = okc ? 1.f : 0.f;
@@ -158,46 +158,46 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   }
   const bool has_h0 = a.h0 != nullptr;
 
-  f32x16 acc[3];
+  f32x16 acc[NBT];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < NBT; ++j)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   float e_h = 0.f, e_x = 0.f, e_b = 0.f;
+  // element offsets fit 32 bits (checked by the host: T*B*H and T*Bp*NT*4 < 2^31)
+  const unsigned usyT = (unsigned)g.syT, usyB = (unsigned)g.syB, usxT = (unsigned)g.sxT, usxB = (unsigned)g.sxB;
 
   constexpr int U = 8;   // row pairs per batch: every load of a batch is issued (branch-free) before its MFMAs
   for (int rb = row0; rb < row1; rb += 2 * U) {
-    float av[U], bv[U][3], hv[U], xv[U];
+    float av[U], bv[U][NBT], hv[U], xv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = rb + 2 * u + lk;
       const bool ok = r < row1;
-      const int rc = ok ? r : row1 - 1;
-      const int t = rc / B, b = rc - t * B;
+      const unsigned rc = ok ? r : row1 - 1;
+      const unsigned t = rc / (unsigned)B, b = rc - t * (unsigned)B;
       // h_{t-1}: y[t-1] for t > 0, else h0 (or 0): address select + mask, no branch
-      const float* hp = t > 0 ? a.y + ((size_t)(t - 1) * g.syT + (size_t)b * g.syB)
-                              : (has_h0 ? a.h0 + (size_t)b * H : a.y + (size_t)b * g.syB);
+      const float* hp = t > 0 ? a.y + ((t - 1) * usyT + b * usyB) : (has_h0 ? a.h0 + b * (unsigned)H : a.y + b * usyB);
       const float hm = (t > 0 || has_h0) ? 1.f : 0.f;
       const float okf = ok ? 1.f : 0.f;
       if (MODE == 1) {
-        av[u] = okf * a.dpre[((size_t)(t * g.Bp + b) * NT) * 4 + col];
+        av[u] = okf * a.dpre[(t * (unsigned)g.Bp + b) * (unsigned)(NT * 4) + col];
         hv[u] = hmask * hm * hp[an];
-        xv[u] = xm ? a.x[(size_t)t * g.sxT + (size_t)b * g.sxB + xn] : 0.f;
+        xv[u] = xm ? a.x[t * usxT + b * usxB + xn] : 0.f;
       } else if (MODE == 2) {
         av[u] = okf * amask * hm * hp[an];
         hv[u] = 0.f, xv[u] = 0.f;
       } else {
-        av[u] = okf * amask * a.x[(size_t)t * g.sxT + (size_t)b * g.sxB + an];
+        av[u] = okf * amask * a.x[t * usxT + b * usxB + an];
         hv[u] = 0.f, xv[u] = 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < 3; ++j) bv[u][j] = bmask[j] * bsrc[j][(size_t)rc * bstr[j]];
+      for (int j = 0; j < NBT; ++j) bv[u][j] = bmask[j] * bsrc[j][rc * bstr[j]];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j)
-        if (j < nbt) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NBT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
       if (MODE == 1) {
         e_h = fmaf(av[u], hv[u], e_h);
         e_x = fmaf(av[u], xv[u], e_x);
@@ -213,13 +213,11 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   float* C = MODE == 1 ? P : (MODE == 2 ? P + o2 : P + o3);
   const int ldc = MODE == 1 ? NB1p : (MODE == 2 ? NB2p : NB3p);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (j < nbt) {
+  for (int j = 0; j < NBT; ++j) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-        C[(size_t)(mt * 32 + i) * ldc + j * 32 + li] = acc[j][r];
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
+      C[(size_t)(mt * 32 + i) * ldc + j * 32 + li] = acc[j][r];
     }
   }
   if (MODE == 1) {   // column sums: the two half-waves hold the even / odd rows
@@ -234,16 +232,18 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   }
 }
 
+// NBT1 / NBT2: 32-wide tiles of B for mode 1 (KX + G*KH columns) and mode 2 (G*KH columns); mode 3 has one.
+template <int NBT1, int NBT2>
 __global__ void __launch_bounds__(256) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int task = blockIdx.x * 4 + wave;
   const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
   if (task < MT1)
-    atb_task<1>(g, a, task, blockIdx.y, lane);
+    atb_task<1, NBT1>(g, a, task, blockIdx.y, lane);
   else if (task < MT1 + MT2)
-    atb_task<2>(g, a, task - MT1, blockIdx.y, lane);
+    atb_task<2, NBT2>(g, a, task - MT1, blockIdx.y, lane);
   else if (task < MT1 + MT2 + MT3)
-    atb_task<3>(g, a, task - MT1 - MT2, blockIdx.y, lane);
+    atb_task<3, 1>(g, a, task - MT1 - MT2, blockIdx.y, lane);
 }
 
 // One thread per element of a chunk's partial block P (coalesced over chunks), fixed-order sum over the
@@ -327,7 +327,17 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
   a.P = w.wpart;
   const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.I + 31) / 32;
-  hipLaunchKernelGGL(wgrad_mfma_kernel, dim3((tasks + 3) / 4, g.nchunk), dim3(256), 0, s, g, a);
+  const dim3 grid((tasks + 3) / 4, g.nchunk), block(256);
+  const int GK = g.G * g.KH, n1 = (g.KX + GK + 31) / 32, n2 = (GK + 31) / 32;
+#define WG_CASE(A, Bv) \
+  if (n1 == A && n2 == Bv) hipLaunchKernelGGL((wgrad_mfma_kernel<A, Bv>), grid, block, 0, s, g, a)
+  WG_CASE(1, 1);
+  else WG_CASE(2, 1);
+  else WG_CASE(2, 2);
+  else WG_CASE(3, 1);
+  else WG_CASE(3, 2);
+  else return -3;
+#undef WG_CASE
   return (int)hipGetLastError();
 }
 
