@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="time eager launches only")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,11 +144,15 @@ def main():
     reducer = FlatGradAllReduce(net.parameters(), op="avg")
     lib = _lib.lib()
 
-    def step():
+    def fwd_bwd():
         net.zero_grad(set_to_none=True)
         out = net(x)
         loss = torch.nn.functional.cross_entropy(out, tgt)
         loss.backward()
+        return loss
+
+    def step():
+        loss = fwd_bwd()
         if world > 1:
             reducer.reduce()
         return loss
@@ -166,21 +171,71 @@ def main():
         step()
     barrier()
     log("warm-up done")
-    # HIP event pairs around the two serial recurrent kernels only (rocprof names them
-    # rec_fwd_kernel / rec_bwd_kernel), recorded on the stream they are launched on
+
+    # ---- timed region 1 (eager launches): HIP event pairs around the two serial recurrent kernels (rocprof
+    # names them rec_fwd_kernel / rec_bwd_kernel), recorded on the stream they are launched on.  Eager PyTorch
+    # is HOST-bound at this size (~0.4 ms of Python/dispatcher per step vs ~0.3 ms of GPU work), so this region
+    # supplies the per-kernel durations for the roofline, and region 2 supplies `value`.
     lib.vmlmf_profile_enable((1 << 2) | (1 << 3))
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        step()
     barrier()
-    dt = time.perf_counter() - t0
-    log(f"timed region done: {dt / args.steps * 1e3:.4f} ms/step")
+    dt_eager = time.perf_counter() - t0
     usec = (ctypes.c_float * _lib.NKERNELS)()
     cnt = (ctypes.c_int32 * _lib.NKERNELS)()
     lib.vmlmf_profile_read(usec, cnt, 1)
     lib.vmlmf_profile_enable(0)
     rec = {lib.vmlmf_kernel_name(k).decode(): usec[k] / max(cnt[k], 1) for k in (2, 3)}
+    log(f"eager timed region done: {dt_eager / args.steps * 1e3:.4f} ms/step")
+
+    # ---- timed region 2 (hipGraph): forward + loss + backward captured ONCE into a HIP graph and replayed;
+    # the gradient all-reduce (N > 1) stays an eager RCCL call after each replay.
+    launch_mode, dt = "eager", dt_eager
+    loss = step().detach().clone()      # keep no reference into the autograd graph across the capture
+    if not args.no_graph:
+        import gc
+        gc.collect()
+        try:
+            side = torch.cuda.Stream(dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fwd_bwd()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            net.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                g_loss = fwd_bwd()
+            captured = True
+        except Exception as e:   # capture unsupported -> keep the eager number, say so
+            log(f"hipGraph capture failed ({type(e).__name__}: {e}); reporting the eager timed region")
+            torch.cuda.synchronize()
+            captured = False
+        if world > 1:            # every rank must take the same path (the replay loop contains a collective)
+            flag = torch.tensor([1 if captured else 0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            captured = bool(flag.item())
+        if captured:
+            def gstep():
+                graph.replay()
+                if world > 1:
+                    reducer.reduce()
+                return g_loss
+
+            for _ in range(args.warmup):
+                gstep()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                gstep()
+            barrier()
+            dt_graph = time.perf_counter() - t0
+            loss = g_loss.detach().clone()
+            log(f"hipGraph timed region done: {dt_graph / args.steps * 1e3:.4f} ms/step")
+            launch_mode, dt = "hipgraph", dt_graph
 
     # untimed extra pass: every internal kernel bracketed, for the breakdown
     lib.vmlmf_profile_enable(0xff)
@@ -221,14 +276,19 @@ def main():
             "config": {"workload": "BASELINE configs[1]: UCI-HAR shape, Net(MyLSTM[MyVMLMFCell]) 1 layer, "
                                    "B=64/GPU T=128 I=9 H=180 w_rank=16 u_rank=16, CE loss, fwd+bwd"
                                    + (", flat RCCL all-reduce (AVG) of grads" if world > 1 else ""),
-                       "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}"},
+                       "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "launch": launch_mode},
+            "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
             "step_flops": rows * F_STEP,
             "step_tflops": round(rows * F_STEP / (ms_per_step * 1e-3) / 1e12, 3),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3),
                          "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
-                         "launch_us": round(rec[dom], 2), "flops_per_launch": flops,
+                         "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
+                         "flops_per_launch": flops,
+                         "measured": "HIP event pairs on the launch stream over the eager timed region of the same K "
+                                     "steps (events cannot be read inside a replayed hipGraph)",
                          "note": "fp32: MFMA peak == vector peak on gfx950; the kernel is a 2T-long dependent "
                                  "chain on 64 of 256 CUs (one batch row per CU), see DESIGN.md"},
             "kernels_us": kern,

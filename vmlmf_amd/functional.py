@@ -31,6 +31,35 @@ def _params_struct(tensors, g):
     return p
 
 
+# (variant, g, w_rank, u_ranks, time_major, B, T, I, H, training) -> (Desc, Sizes): host-side descriptor cache
+_DESC_CACHE = {}
+# one grow-only scratch buffer per device: workspace contents never outlive the call that fills them and all
+# calls on a device are serialised on the current stream
+_WORKSPACE = {}
+
+
+def _desc_for(cfg, B, T, I, H, training):
+    key = cfg + (B, T, I, H, training)
+    hit = _DESC_CACHE.get(key)
+    if hit is None:
+        variant, g, w_rank, u_ranks, time_major = cfg
+        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major, training=training)
+        hit = (desc, _lib.query(desc))
+        _DESC_CACHE[key] = hit
+    return hit
+
+
+def _workspace(dev, nbytes):
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, device=dev, dtype=torch.uint8)      # graph-private pool
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    buf = _WORKSPACE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+        _WORKSPACE[key] = buf
+    return buf
+
+
 def _require_hip(t, what):
     if not t.is_cuda:
         raise RuntimeError(
@@ -58,14 +87,12 @@ class VmlmfSeqFn(torch.autograd.Function):
             B, T, I = x.shape
         H = params[1].shape[-1]
         training = bool(any(ctx.needs_input_grad))   # False under torch.no_grad(): inference kernels
-        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major,
-                              training=training)
-        sizes = _lib.query(desc)
+        desc, sizes = _desc_for(cfg, B, T, I, H, training)
         dev = x.device
         y = torch.empty((T, B, H) if time_major else (B, T, H), device=dev, dtype=torch.float32)
         hT = torch.empty((B, H), device=dev, dtype=torch.float32)
         cT = torch.empty((B, H), device=dev, dtype=torch.float32)
-        ws = torch.empty(sizes.workspace_bytes, device=dev, dtype=torch.uint8)
+        ws = _workspace(dev, sizes.workspace_bytes)
         reserve = torch.empty(sizes.reserve_bytes, device=dev, dtype=torch.uint8) if training else None
         h0c = None if h0 is None else h0.contiguous()
         c0c = None if c0 is None else c0.contiguous()
@@ -102,8 +129,15 @@ class VmlmfSeqFn(torch.autograd.Function):
         B, H = y.shape[1 if time_major else 0], y.shape[2]
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
         dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_c0 else None
-        grads = tuple(torch.empty_like(p) for p in params)
-        ws = torch.empty(sizes.workspace_bytes, device=dev, dtype=torch.uint8)
+        # one flat buffer for all parameter gradients (views are returned): a single allocation, and the
+        # gradients of a layer are contiguous for the data-parallel all-reduce
+        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        grads = tuple(grads)
+        ws = _workspace(dev, sizes.workspace_bytes)
         ps = _params_struct(params, g)
         gs = _params_struct(grads, g)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
