@@ -45,6 +45,9 @@ def test_query_headline_geometry():
     assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kh) == (2, 256, 256, 32)   # 2 groups x 2 waves
     s = _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 81, 24, 77, 180, 8, [2, 4], g=2))  # demo.sh:10
     assert (s.kx, s.kh) == (8, 16)
+    # BASELINE config E (PTB group layer): too large for the register-resident kernels -> step-wise path
+    s = _lib.query(_lib.make_desc(_lib.V4_LM_GROUP, 256, 35, 650, 650, 32, [32, 32], g=2, time_major=True))
+    assert (s.kx, s.kh, s.threads_per_wg) == (32, 64, 768)
 
 
 @pytest.mark.parametrize("desc,code", [
@@ -55,7 +58,8 @@ def test_query_headline_geometry():
     (dict(variant=_lib.V1_CELL, B=0, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
     (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[0]), _lib.E_BADARG),
     (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=12, w_rank=3, u_ranks=[2, 2, 2], g=3), _lib.E_UNSUPPORTED),
-    (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=64, w_rank=3, u_ranks=[40]), _lib.E_UNSUPPORTED),
+    (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=64, w_rank=40, u_ranks=[8]), _lib.E_UNSUPPORTED),
+    (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=64, w_rank=4, u_ranks=[72, 72], g=2), _lib.E_UNSUPPORTED),
 ])
 def test_query_rejects_what_it_must(desc, code):
     with pytest.raises(_lib.VmlmfError) as ei:

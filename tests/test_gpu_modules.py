@@ -115,9 +115,9 @@ def test_bare_cell_calls_vs_reference(name, cls):
 
 
 def test_unsupported_shape_raises_and_never_falls_back():
-    """BASELINE config E (H=650, ranks 32/[32,32]) is outside this round's kernels: explicit error."""
+    """w_rank > 32 is outside this round's kernels: explicit error, no fallback."""
     from vmlmf_amd import _lib
-    layer = MyVMLSTMGroup(650, 650, w_rank=32, u_ranks=[32, 32]).to(DEV)
+    layer = MyVMLSTM(64, 64, w_rank=40, u_ranks=8).to(DEV)
     with pytest.raises(_lib.VmlmfError) as ei:
-        layer(torch.zeros(3, 4, 650, device=DEV), (torch.zeros(4, 650, device=DEV), torch.zeros(4, 650, device=DEV)))
+        layer(torch.zeros(3, 4, 64, device=DEV), (torch.zeros(4, 64, device=DEV), torch.zeros(4, 64, device=DEV)))
     assert ei.value.code == _lib.E_UNSUPPORTED

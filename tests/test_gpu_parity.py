@@ -85,6 +85,12 @@ CASES = [
     (O.V3, 6, 5, 24, 24, 4, [6], True, True),
     (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),     # batch != 40 (the reference cannot run this)
     (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
+    # shapes that do not fit the register-resident kernels -> step-wise path (vmlmf_generic.hip)
+    (O.V1, 5, 4, 12, 40, 6, [40], False, True),      # rank 40 > 32
+    (O.V1, 3, 3, 20, 600, 8, [8], False, False),     # 640 thread slots > 512
+    (O.V2, 4, 3, 10, 48, 4, [24, 20], False, True),  # group ranks pad to 24 + 24 = 48
+    (O.V3, 6, 4, 70, 70, 9, [33], True, True),       # rank 33 -> padded 40
+    (O.V4, 7, 3, 44, 44, 5, [20, 36], True, True),   # flat layout, padded 24 + 40 = 64
 ]
 
 
@@ -103,6 +109,40 @@ def test_seeded_shapes_vs_oracle(case):
     got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
     ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
     compare_all(got, ref, "case")
+
+
+def _regen_lm_inputs(seed, B, T, H, xscale):
+    """Same draw order as oracle/make_golden.py:case_lm_seq (the large fixtures store only the seed)."""
+    r = np.random.Generator(np.random.PCG64(seed))
+    x = (xscale * r.standard_normal((T, B, H))).astype(np.float32)
+    h0 = (0.3 * r.standard_normal((B, H))).astype(np.float32)
+    c0 = (0.3 * r.standard_normal((B, H))).astype(np.float32)
+    dy = r.standard_normal((T, B, H)).astype(np.float32)
+    dhT = r.standard_normal((B, H)).astype(np.float32)
+    dcT = r.standard_normal((B, H)).astype(np.float32)
+    return x, h0, c0, dy, dhT, dcT
+
+
+@pytest.mark.parametrize("name", ["cfgE_v4_b40", "cfgE_v3_b64"])
+def test_config_e_shape_vs_reference_golden(name):
+    """BASELINE config E shape: PTB layer H=650, ranks 32 / [32,32], T=35 (B=40 is the only batch the
+    reference's group layer can run).  Runs the step-wise path."""
+    d = load_golden(name)
+    meta = [int(v) for v in d["meta"]]
+    variant, B, T, _, H, rw = meta[:6]
+    ru = meta[6:]
+    seed, (scale, xscale) = int(d["seed"][0]), (float(d["scale"][0]), float(d["scale"][1]))
+    P = O.make_params(variant, H, H, rw, ru if variant == O.V4 else ru[0], seed=seed + 1, scale=scale)
+    x, h0, c0, dy, dhT, dcT = _regen_lm_inputs(seed, B, T, H, xscale)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=True)
+    assert_out(got["y"][::4, ::4], d["y_s"], "y")
+    assert_out(got["hT"], d["hT"], "hT")
+    assert_out(got["cT"], d["cT"], "cT")
+    assert_grad(got["dx"][::4, ::4], d["dx_s"], "dx")
+    assert_grad(got["dh0"], d["dh0"], "dh0")
+    assert_grad(got["dc0"], d["dc0"], "dc0")
+    for k, v in d["G"].items():
+        assert_grad(got["G"][k], v, "G." + k)
 
 
 def test_inference_mode_matches_training_forward():

@@ -103,12 +103,13 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
     g.syT = g.H;
     g.syB = (long long)g.T * g.H;
   }
-  if (g.KH > 32 || g.KX > 32)
-    return fail(VMLMF_E_UNSUPPORTED, "padded rank > 32: the register-resident kernels hold at most 32 ranks per path");
-  if (g.NT > 512)
-    return fail(VMLMF_E_UNSUPPORTED, "hidden_size needs > 512 threads per workgroup: not instantiated yet");
+  if (g.KX > 32) return fail(VMLMF_E_UNSUPPORTED, "padded w_rank > 32 is not covered by the HIP kernels");
+  if (g.G * g.KH > 128) return fail(VMLMF_E_UNSUPPORTED, "padded hidden rank (summed over groups) > 128 is not covered");
+  // register-resident persistent kernels need <= 32 ranks per unit and <= 512 thread slots; larger layers
+  // (e.g. H = 650, ranks [32,32]) run the step-wise path of vmlmf_generic.hip
+  g.generic = (g.KH > 32 || g.NT > 512) ? 1 : 0;
   // rows per workgroup: one row per CU while the batch fits the chip once, then two
-  g.R = (g.B <= 256 || g.flat) ? 1 : 2;
+  g.R = (g.B <= 256 || g.flat || g.generic) ? 1 : 2;
   g.nwg = (g.B + g.R - 1) / g.R;
   g.Bp = g.nwg * g.R;
   if ((long long)g.T * g.Bp * g.NT * 4 >= (1LL << 31) || (long long)g.T * g.B * g.H >= (1LL << 31))
@@ -140,9 +141,9 @@ struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
   long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
   // forward workspace  : PACK (inference only) | gx
-  long long f_pack, f_gx, f_trash, f_total;
+  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P) {
@@ -160,6 +161,13 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   L.f_pack = o, o += align64(P.total);
   L.f_gx = o, o += align64(TS * 4);
   L.f_trash = o, o += 64;
+  {
+    const long long gen = g.generic ? 1 : 0, BN = (long long)g.B * g.NT;
+    L.f_Qtmp = o, o += align64(gen * g.B * g.G * g.KH);
+    L.f_P = o, o += align64(gen * BN * 4);
+    L.f_ccar = o, o += align64(gen * BN);
+    L.f_zeros = o, o += align64(gen * (long long)g.B * g.H);
+  }
   L.f_total = o;
   o = 0;
   L.b_dpre = o, o += align64(TS * 4);
@@ -168,6 +176,12 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   L.b_wpart = o, o += align64((long long)g.nchunk * g.PCH);
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT);
   L.b_trash = o, o += 64;
+  {
+    const long long gen = g.generic ? 1 : 0, BN = (long long)g.B * g.NT;
+    L.b_dHrec = o, o += align64(gen * (long long)g.B * g.H);
+    L.b_ehterm = o, o += align64(gen * BN);
+    L.b_dcar = o, o += align64(gen * BN);
+  }
   L.b_total = o;
   return L;
 }
@@ -249,6 +263,20 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : nullptr, s), "xproj")) != 0)
       return rc;
   }
+  if (g.generic) {
+    GenericBuf w;
+    memset(&w, 0, sizeof(w));
+    w.gx = gx, w.EH = pack + P.EH, w.h0 = h0, w.c0 = c0, w.Ud = pack + P.UD, w.Vd = pack + P.VD;
+    w.zeros = ws + L.f_zeros, w.y = y, w.hT = hT, w.cT = cT;
+    w.gates = g.training ? rs + L.r_gates : nullptr, w.cs = g.training ? rs + L.r_cs : nullptr;
+    w.Qs = g.training ? rs + L.r_Qs : nullptr, w.Qtmp = ws + L.f_Qtmp, w.P = ws + L.f_P, w.ccar = ws + L.f_ccar;
+    if (h0 == nullptr) {
+      rc = (int)hipMemsetAsync(ws + L.f_zeros, 0, sizeof(float) * (size_t)g.B * g.H, s);
+      if (rc != 0) return hip_fail(rc, "memset");
+    }
+    Scope sc(2, s);
+    return hip_fail(generic_forward(g, w, s), "generic_forward");
+  }
   FwdArgs a;
   a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
   a.y = y, a.hT = hT, a.cT = cT, a.trash = ws + L.f_trash;
@@ -283,6 +311,19 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   float* ws = (float*)workspace;
   const float* rs = (const float*)reserve;
   const float* pack = rs + L.r_pack;
+  if (g.generic) {
+    GenericBuf w;
+    memset(&w, 0, sizeof(w));
+    w.EH = pack + P.EH, w.gates = const_cast<float*>(rs + L.r_gates), w.cs = const_cast<float*>(rs + L.r_cs);
+    w.dy = dy, w.dhT = dhT, w.dcT = dcT, w.UdT = pack + P.UDT, w.VdT = pack + P.VDT, w.VxT = pack + P.VXTT;
+    w.UXP = pack + P.UXP, w.EXT = pack + P.EXT;
+    w.dpre = ws + L.b_dpre, w.dQs = ws + L.b_dQs, w.dHrec = ws + L.b_dHrec, w.ehterm = ws + L.b_ehterm;
+    w.dcar = ws + L.b_dcar, w.dh0 = dh0, w.dc0 = dc0, w.dqx = ws + L.b_dqx, w.dx = dx;
+    {
+      Scope sc(3, s);
+      if ((rc = hip_fail(generic_backward(g, w, s), "generic_backward")) != 0) return rc;
+    }
+  } else {
   BwdArgs a;
   a.gates = rs + L.r_gates, a.cs = rs + L.r_cs, a.c0 = c0, a.dy = dy, a.dhT = dhT, a.dcT = dcT;
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
@@ -298,6 +339,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
     Scope sc(4, s);
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
+  }  // persistent path
   WghArgs wh;
   wh.dpre = ws + L.b_dpre, wh.x = x, wh.y = y, wh.h0 = h0, wh.qx = rs + L.r_qx, wh.dqx = ws + L.b_dqx;
   wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs, wh.wpart = ws + L.b_wpart;

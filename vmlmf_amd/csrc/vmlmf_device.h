@@ -156,15 +156,17 @@ __device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
 // All loads are issued before the first FMA (fixed trip count 32 = the rank limit, predicated): a
 // run-time-bounded loop would serialise 2 dependent global loads per rank (~1 us each) in pack_kernel.
 __device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
-  float u[32], v[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    u[r] = r < g.ru0 ? ref_uc(g, p, n, r) : 0.f;
-    v[r] = r < g.ru0 ? ref_vc(g, p, n, k, r) : 0.f;
-  }
   float acc = 0.f;
+  for (int r0 = 0; r0 < g.ru0; r0 += 32) {   // ranks in blocks of 32: loads of a block are issued together
+    float u[32], v[32];
 #pragma unroll
-  for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
+    for (int r = 0; r < 32; ++r) {
+      u[r] = r0 + r < g.ru0 ? ref_uc(g, p, n, r0 + r) : 0.f;
+      v[r] = r0 + r < g.ru0 ? ref_vc(g, p, n, k, r0 + r) : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
+  }
   return p.dia_h[n] - acc;
 }
 __device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {

@@ -28,11 +28,13 @@ struct VGeo {
   int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12
   long long sxT, sxB, syT, syB;  // element strides of x/dx and y/dy
   int time_major, training;
+  int generic;  // 1: step-wise path (vmlmf_generic.hip): factors do not fit the register-resident kernels
 };
 
 // float offsets inside the PACK region (parameter images, produced by pack_kernel)
 struct VPack {
-  long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT, total;
+  long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
+  long long UD, VD, UDT, VDT, VXTT, total;   // dense group factors + V_x^T, step-wise path only
 };
 
 #ifdef __HIPCC__
@@ -47,18 +49,25 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   VPack p;
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
-  p.VE = take(4LL * g.KH * g.NT);
-  p.UR = take(1LL * g.KQ * g.NT);
-  p.VR = take(4LL * g.KQ * g.NT);
-  p.UE = take(1LL * g.KH * g.NT);
+  const int pk = g.generic ? 0 : 1;   // register images exist only for the persistent kernels
+  p.VE = take(pk * 4LL * g.KH * g.NT);
+  p.UR = take(pk * 1LL * g.KQ * g.NT);
+  p.VR = take(pk * 4LL * g.KQ * g.NT);
+  p.UE = take(pk * 1LL * g.KH * g.NT);
   p.EH = take(4LL * g.NT);
-  p.VRX = take(4LL * g.KQX * g.NT);
-  p.UXO = take(1LL * g.KX * g.NT);
-  p.EXI = take(4LL * g.NT);
+  p.VRX = take(pk * 4LL * g.KQX * g.NT);
+  p.UXO = take(pk * 1LL * g.KX * g.NT);
+  p.EXI = take(pk * 4LL * g.NT);
   p.UXP = take(1LL * g.I * g.KX);
   p.VXT = take(4LL * g.KX * g.H);
   p.EXT = take(4LL * g.H);
   p.BBT = take(4LL * g.H);
+  const long long GK = (long long)g.G * g.KH, N4 = 4LL * g.NT;
+  p.UD = take(g.generic ? g.H * GK : 0);
+  p.VD = take(g.generic ? GK * N4 : 0);
+  p.UDT = take(g.generic ? GK * g.H : 0);
+  p.VDT = take(g.generic ? N4 * GK : 0);
+  p.VXTT = take(g.generic ? N4 * g.KX : 0);
   p.total = o;
   return p;
 }

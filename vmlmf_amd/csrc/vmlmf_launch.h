@@ -22,6 +22,18 @@ struct WghArgs {
   float* wpart;
 };
 
+// buffers of the step-wise path (vmlmf_generic.hip)
+struct GenericBuf {
+  // forward
+  const float *gx, *EH, *h0, *c0, *Ud, *Vd, *zeros;
+  float *y, *hT, *cT, *gates, *cs, *Qs, *Qtmp, *P, *ccar;
+  // backward
+  const float *dy, *dhT, *dcT, *UdT, *VdT, *VxT, *UXP, *EXT;
+  float *dpre, *dQs, *dHrec, *ehterm, *dcar, *dh0, *dc0, *dqx, *dx;
+};
+int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s);
+int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s);
+
 // every launcher returns hipGetLastError() of its launch, or VMLMF_E_UNSUPPORTED (-3) when no
 // instantiation covers the geometry
 int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s);

@@ -92,9 +92,50 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
     } else if (e < L.BBT) {  // EXT[k][n]
       const long long le = e - L.EXT;
       if (le < 4LL * g.H) v = ref_ex(g, p, (int)(le % g.H), (int)(le / g.H));
-    } else {  // BBT[k][n]
+    } else if (e < L.UD) {  // BBT[k][n]
       const long long le = e - L.BBT;
       if (le < 4LL * g.H) v = ref_bb(g, p, (int)(le % g.H), (int)(le / g.H));
+    } else {  // step-wise path: group structure written out densely
+      const int GK = g.G * g.KH, N4 = 4 * NT;
+      int n = -1, k = 0, rr = 0, j = 0, mode = 0;   // mode 1: U element (n, j, rr)   2: V element (n, k, j, rr)   3: Vx
+      if (e < L.VD) {           // UD[n][j*KH+rr]
+        const long long le = e - L.UD;
+        if (le < (long long)g.H * GK) { n = (int)(le / GK); const int c = (int)(le % GK); j = c / g.KH; rr = c % g.KH; mode = 1; }
+      } else if (e < L.UDT) {   // VD[j*KH+rr][slot*4+k]
+        const long long le = e - L.VD;
+        if (le < (long long)GK * N4) {
+          const int c = (int)(le / N4), i = (int)(le % N4);
+          j = c / g.KH; rr = c % g.KH; k = i & 3;
+          if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
+        }
+      } else if (e < L.VDT) {   // UDT[j*KH+rr][n]
+        const long long le = e - L.UDT;
+        if (le < (long long)GK * g.H) { const int c = (int)(le / g.H); n = (int)(le % g.H); j = c / g.KH; rr = c % g.KH; mode = 1; }
+      } else if (e < L.VXTT) {  // VDT[slot*4+k][j*KH+rr]
+        const long long le = e - L.VDT;
+        if (le < (long long)N4 * GK) {
+          const int i = (int)(le / GK), c = (int)(le % GK);
+          j = c / g.KH; rr = c % g.KH; k = i & 3;
+          if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
+        }
+      } else {                  // VXTT[slot*4+k][r]
+        const long long le = e - L.VXTT;
+        if (le < (long long)N4 * g.KX) {
+          const int i = (int)(le / g.KX);
+          rr = (int)(le % g.KX); k = i & 3;
+          if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
+        }
+      }
+      if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s
+        const int sblk = (g.G == 2 && rr >= g.off1) ? 1 : 0;
+        const int dest = (n / g.Hg - sblk + g.G) % g.G;
+        if (dest == j) v = ref_uc(g, p, n, rr);
+      } else if (mode == 2) {   // gate k of unit n reads Q[qsel]
+        const int qsel = g.G == 1 ? 0 : (g.flat ? (k * g.H + n) / (4 * g.Hg) : n / g.Hg);
+        if (qsel == j) v = ref_vc(g, p, n, k, rr);
+      } else if (mode == 3) {
+        v = ref_vx(g, p, n, k, rr);
+      }
     }
     out[e] = v;
   }

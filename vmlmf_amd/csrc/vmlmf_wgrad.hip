@@ -331,11 +331,18 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   const int GK = g.G * g.KH, n1 = (g.KX + GK + 31) / 32, n2 = (GK + 31) / 32;
 #define WG_CASE(A, Bv) \
   if (n1 == A && n2 == Bv) hipLaunchKernelGGL((wgrad_mfma_kernel<A, Bv>), grid, block, 0, s, g, a)
+  // n1 = tiles of KX + G*KH (<= 160 columns), n2 = tiles of G*KH (<= 128 columns), n2 <= n1
   WG_CASE(1, 1);
   else WG_CASE(2, 1);
   else WG_CASE(2, 2);
   else WG_CASE(3, 1);
   else WG_CASE(3, 2);
+  else WG_CASE(3, 3);
+  else WG_CASE(4, 2);
+  else WG_CASE(4, 3);
+  else WG_CASE(4, 4);
+  else WG_CASE(5, 3);
+  else WG_CASE(5, 4);
   else return -3;
 #undef WG_CASE
   return (int)hipGetLastError();
