@@ -28,36 +28,51 @@ struct GemmArgs {
   int M, N, K;
 };
 
-// C[M x N] = A[M x K] B[K x N], row-major, any sizes (masked).  One wave per 32x32 tile of C.
+// C[M x N] = A[M x K] B[K x N], row-major, any sizes (masked).  One 32x32 tile of C per workgroup of SPLIT
+// waves: the waves split K between them (skinny products such as dQ = dpre VdT have few tiles but a long K)
+// and their partial tiles are summed through LDS in wave order (deterministic).
 // Lane l = (lk = l>>5, li = l&31) supplies A[row li][k] and B[k][col li]; within an 8-wide k block MFMA step s
 // contracts k = kb + 4*lk + s, so a lane reads 4 consecutive floats of its A row per block.
-__global__ void __launch_bounds__(256) gemm_nn_kernel(GemmArgs a) {
+template <int SPLIT, bool VEC>
+__global__ void __launch_bounds__(64 * SPLIT) gemm_nn_kernel(GemmArgs a) {
+  __shared__ float red[SPLIT > 1 ? SPLIT * 1024 : 1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles_n = (a.N + 31) / 32, tiles_m = (a.M + 31) / 32;
-  const int tile = blockIdx.x * 4 + wave;
-  if (tile >= tiles_m * tiles_n) return;
+  const int tiles_n = (a.N + 31) / 32;
+  const int tile = blockIdx.x;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int li = lane & 31, lk = lane >> 5;
   const int row = tm * 32 + li, col = tn * 32 + li;
   const bool rok = row < a.M, cok = col < a.N;
   const float* Ar = a.A + (long long)(rok ? row : 0) * a.lda;
   const float* Bc = a.B + (cok ? col : 0);
+  // this wave's K range, in multiples of 16
+  const int kper = ((a.K + SPLIT - 1) / SPLIT + 15) / 16 * 16;
+  const int k0 = wave * kper, k1 = k0 + kper < a.K ? k0 + kper : a.K;
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int UB = 2;  // 8-wide k blocks per batch of loads
-  for (int kb = 0; kb < a.K; kb += 8 * UB) {
+  constexpr int UB = 4;  // 8-wide k blocks per batch of loads (all loads of a batch are issued together)
+  for (int kb = k0; kb < k1; kb += 8 * UB) {
     float av[UB][4], bv[UB][4];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
+      if (VEC) {   // rows of A are 16-byte aligned and K % 4 == 0: one 16-byte load per lane and block
+        const int k = kb + 8 * u + 4 * lk;
+        const bool kok = k < k1;
+        const float4 x = ld4(Ar + (kok ? k : 0));
+        const float m = (kok && rok) ? 1.f : 0.f;
+        av[u][0] = m * x.x, av[u][1] = m * x.y, av[u][2] = m * x.z, av[u][3] = m * x.w;
+      }
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int k = kb + 8 * u + 4 * lk + s;
-        const bool kok = k < a.K;
+        const bool kok = k < k1;
         const int kc = kok ? k : 0;
-        const float x = Ar[kc];
+        if (!VEC) {
+          const float x = Ar[kc];
+          av[u][s] = (kok && rok) ? x : 0.f;
+        }
         const float y = Bc[(long long)kc * a.ldb];
-        av[u][s] = (kok && rok) ? x : 0.f;
         bv[u][s] = (kok && cok) ? y : 0.f;
       }
     }
@@ -65,6 +80,18 @@ __global__ void __launch_bounds__(256) gemm_nn_kernel(GemmArgs a) {
     for (int u = 0; u < UB; ++u)
 #pragma unroll
       for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][s], bv[u][s], acc, 0, 0, 0);
+  }
+  if (SPLIT > 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float sum = red[r * 64 + lane];
+      for (int w = 1; w < SPLIT; ++w) sum += red[w * 1024 + r * 64 + lane];
+      acc[r] = sum;
+    }
   }
   if (cok) {
 #pragma unroll
@@ -79,7 +106,22 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
                 int K, hipStream_t s) {
   GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K};
   const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-  hipLaunchKernelGGL(gemm_nn_kernel, dim3((tiles + 3) / 4), dim3(256), 0, s, a);
+  // few tiles and a long K: split K over up to 16 waves of the tile's workgroup
+  const bool vec = (lda % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+#define GEMM_GO(SP)                                                                              \
+  do {                                                                                           \
+    if (vec)                                                                                     \
+      hipLaunchKernelGGL((gemm_nn_kernel<SP, true>), dim3(tiles), dim3(64 * SP), 0, s, a);       \
+    else                                                                                         \
+      hipLaunchKernelGGL((gemm_nn_kernel<SP, false>), dim3(tiles), dim3(64 * SP), 0, s, a);      \
+  } while (0)
+  if (tiles <= 128 && K >= 256)
+    GEMM_GO(16);
+  else if (tiles <= 512 && K >= 128)
+    GEMM_GO(4);
+  else
+    GEMM_GO(1);
+#undef GEMM_GO
   return (int)hipGetLastError();
 }
 
