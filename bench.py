@@ -265,6 +265,15 @@ def main():
 
     if rank == 0:
         dom = max(rec, key=rec.get)                      # dominant kernel by measured time
+        # HBM traffic of that kernel: PMC counters cannot be read from inside the process; they were collected
+        # with rocprofv3 in separate passes on this same command and committed under profiles/
+        traffic, traffic_note = None, None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+            traffic_note = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x FETCH correction)"
+        except (OSError, KeyError, ValueError):
+            pass
         rows = B_PER_GPU * T                             # sample-timesteps one launch processes
         flops = rows * F_H * (1 if dom == "rec_fwd_kernel" else 1)   # 10 H ru per sample-step either way
         achieved = flops / (rec[dom] * 1e-6) / 1e12
@@ -284,7 +293,8 @@ def main():
             "step_tflops": round(rows * F_STEP / (ms_per_step * 1e-3) / 1e12, 3),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3),
                          "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": None,
+                         "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
+                         "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                          "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
                          "flops_per_launch": flops,
                          "measured": "HIP event pairs on the launch stream over the eager timed region of the same K "
