@@ -78,12 +78,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.ru1 = g.G == 2 ? d->u_ranks[1] : 0;
   if (g.ru0 < 1 || (g.G == 2 && g.ru1 < 1)) return fail(VMLMF_E_BADARG, "u_ranks must be positive");
   g.Hg = g.H / g.G;
-  g.SG = (g.Hg + 31) / 32 * 32;
-  g.NT = (g.G * g.SG + 63) / 64 * 64;
-  g.NW = g.NT / 64;
-  g.NT2 = 2 * g.G * g.SG;
-  g.W2 = g.SG / 32;
-  g.NW2 = g.G * g.W2;
+  g.W = (g.Hg + 63) / 64;
+  g.NW = g.G * g.W;
+  g.NT = g.NW * 64;
   g.off1 = vg_pad8(g.ru0);
   g.KH = g.off1 + (g.G == 2 ? vg_pad8(g.ru1) : 0);
   g.KX = vg_pad8(g.rw);
@@ -110,7 +107,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (g.G * g.KH > 128) return fail(VMLMF_E_UNSUPPORTED, "padded hidden rank (summed over groups) > 128 is not covered");
   // register-resident persistent kernels need <= 32 ranks per unit and <= 512 thread slots; larger layers
   // (e.g. H = 650, ranks [32,32]) run the step-wise path of vmlmf_generic.hip
-  g.generic = (g.KH > 32 || g.NT2 > 512) ? 1 : 0;
+  g.generic = (g.KH > 32 || g.NT > 512) ? 1 : 0;
   // rows per workgroup: one row per CU while the batch fits the chip once, then two
   g.R = (g.B <= 256 || g.flat || g.generic) ? 1 : 2;
   g.nwg = (g.B + g.R - 1) / g.R;
@@ -231,7 +228,7 @@ int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
   out->workspace_bytes = (size_t)ws * sizeof(float);
   out->reserve_bytes = (size_t)L.r_total * sizeof(float);
   out->rows_per_wg = g.R;
-  out->threads_per_wg = g.generic ? 256 : g.NT2;
+  out->threads_per_wg = g.NT;
   out->workgroups = g.nwg;
   out->kx = g.KX;
   out->kh = g.KH;
@@ -281,7 +278,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     return hip_fail(generic_forward(g, w, s), "generic_forward");
   }
   FwdArgs a;
-  a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EHM = pack + P.EHM, a.h0 = h0, a.c0 = c0;
+  a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
   a.y = y, a.hT = hT, a.cT = cT, a.trash = ws + L.f_trash;
   a.gates = g.training ? rs + L.r_gates : nullptr;
   a.cs = g.training ? rs + L.r_cs : nullptr;

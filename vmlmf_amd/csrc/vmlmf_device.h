@@ -185,16 +185,8 @@ __device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {
 
 // thread slot -> unit
 __device__ __forceinline__ bool vg_slot_unit(const VGeo& g, int slot, int& n) {
-  const int grp = slot / g.SG;
-  const int m = slot - grp * g.SG;
-  const bool ok = grp < g.G && m < g.Hg;
-  n = ok ? grp * g.Hg + m : 0;
-  return ok;
-}
-// The gates are evaluated as rcp(1 + exp2(pre')) with pre' = PRESCALE[k] * pre: the persistent path folds the
-// factor into V_h, eh and the x-side pre-activation (pack_kernel), saving the multiplies on the serial chain.
-//   sigmoid(x) = rcp(1 + exp2(-log2(e) x))          tanh(x) = 1 - 2 rcp(1 + exp2(2 log2(e) x))
-__device__ __forceinline__ float vg_prescale(const VGeo& g, int k) {
-  if (g.generic) return 1.f;
-  return k < 3 ? -1.4426950408889634f : 2.8853900817779268f;
+  const int grp = slot / (64 * g.W);
+  const int m = slot - grp * 64 * g.W;
+  n = grp * g.Hg + m;
+  return m < g.Hg;
 }

@@ -1,12 +1,9 @@
 // Geometry shared by host launch code and device kernels (gfx950 only; wave = 64 lanes).
 //
-// Slots.  Every per-unit buffer ([t][Bp][NT] tapes, parameter images) is indexed by a SLOT, not by the unit:
-// group grp owns SG = 32*ceil(Hg/32) consecutive slots, NT = roundup(G*SG, 64):
-//     grp = slot / SG,  m = slot % SG,  unit n = grp * Hg + m  (valid iff grp < G and m < Hg).
-// The persistent recurrent kernels run TWO lanes per slot (tid = 2*slot + half): the two lanes split the rank
-// space of the expansion / the rank halves of the reduction between them, so a workgroup has NT2 = 2*G*SG
-// threads and each group is wave-aligned (W2 = SG/32 waves), i.e. a wave's rank-space partial sums belong to
-// exactly one source group.  The slot-threaded kernels (dqx_dx) use one lane per slot, NT threads.
+// Thread <-> hidden-unit map of the persistent kernels.  A workgroup has NT = G * W * 64 threads; the G
+// groups of the hidden->hidden path are wave-aligned (W waves each), so that a wave's rank-space partial
+// sums belong to exactly one source group:
+//     grp = tid / (64 W),  m = tid % (64 W),  unit n = grp * Hg + m  (valid iff m < Hg).
 //
 // Rank space.  Shift s of the group path has rank ru[s]; blocks are padded to multiples of 8 and
 // concatenated: block 0 = [0, off1), block 1 = [off1, KH).  KX = pad8(w_rank).  The reductions run in
@@ -15,8 +12,7 @@
 #include <stdint.h>
 
 struct VGeo {
-  int variant, B, T, I, H, rw, G, Hg, SG, NT, NW;   // NW = NT/64 (waves of the slot-threaded kernels)
-  int NT2, W2, NW2;   // persistent kernels: threads, waves per group, waves
+  int variant, B, T, I, H, rw, G, Hg, W, NT, NW;
   int ru0, ru1, off1;
   int KX, KH, NP, KQ, NPX, KQX;
   int flat;   // V4: [B, g*4Hg] flattened then chunked (vmlmf_lm.py:135,155): gate k picks Q[k / 2]
@@ -38,7 +34,7 @@ struct VGeo {
 // float offsets inside the PACK region (parameter images, produced by pack_kernel)
 struct VPack {
   long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
-  long long UD, VD, UDT, VDT, VXTT, EHM, total;   // EHM: [2][NT2] prescaled eh of the lane's own gate pair   // dense group factors + V_x^T, step-wise path only
+  long long UD, VD, UDT, VDT, VXTT, total;   // dense group factors + V_x^T, step-wise path only
 };
 
 #ifdef __HIPCC__
@@ -54,12 +50,10 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
   const int pk = g.generic ? 0 : 1;   // register images exist only for the persistent kernels
-  // pair-kernel images are indexed by THREAD (2 per slot): VE = [4][KH/2] (mine.x mine.y theirs.x theirs.y),
-  // UR = [NP*8] rotated U, VR = [4][NP*8] rotated V, UE = [KH/2] own U half;  EH = [4] per SLOT (unscaled)
-  p.VE = take(pk * 2LL * g.KH * g.NT2);
-  p.UR = take(pk * 8LL * g.NP * g.NT2);
-  p.VR = take(pk * 32LL * g.NP * g.NT2);
-  p.UE = take(pk * (g.KH / 2LL) * g.NT2);
+  p.VE = take(pk * 4LL * g.KH * g.NT);
+  p.UR = take(pk * 1LL * g.KQ * g.NT);
+  p.VR = take(pk * 4LL * g.KQ * g.NT);
+  p.UE = take(pk * 1LL * g.KH * g.NT);
   p.EH = take(4LL * g.NT);
   p.VRX = take(pk * 4LL * g.KQX * g.NT);
   p.UXO = take(pk * 1LL * g.KX * g.NT);
@@ -74,7 +68,6 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   p.UDT = take(g.generic ? GK * g.H : 0);
   p.VDT = take(g.generic ? N4 * GK : 0);
   p.VXTT = take(g.generic ? N4 * g.KX : 0);
-  p.EHM = take(pk * 2LL * g.NT2);
   p.total = o;
   return p;
 }
@@ -91,5 +84,5 @@ VG_HD int va_b(const VGeo& g, int k) { return 5 * g.KX + 5 * g.KH + 8 + k; }
 // thread slot of hidden unit n
 VG_HD int vg_slot(const VGeo& g, int n) {
   int grp = n / g.Hg;
-  return grp * g.SG + (n - grp * g.Hg);
+  return grp * 64 * g.W + (n - grp * g.Hg);
 }

@@ -4,7 +4,7 @@
 #include "vmlmf_device.h"
 
 struct FwdArgs {
-  const float *gx, *VE, *UR, *EHM, *h0, *c0;
+  const float *gx, *VE, *UR, *EH, *h0, *c0;
   float *y, *hT, *cT, *gates, *cs, *Qs;
   float* trash;  // >= 64 floats: target of the redirected stores of inactive lanes (keeps stores unconditional)
 };

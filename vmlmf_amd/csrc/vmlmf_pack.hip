@@ -19,39 +19,36 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < L.total; e += stride) {
     float v = 0.f;
-    const int NT2 = g.NT2, KHH = g.KH / 2;
-    if (e < L.UR) {  // VE[(q*KHH + j)][tid]: lane (slot, half) owns ranks [half*KHH, ...) of all four gates;
-                     // q = 0,1: its own gate pair (2*half, 2*half+1), q = 2,3: the partner's pair
+    if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
       const long long le = e - L.VE;
-      if (le < 2LL * g.KH * NT2) {
-        const int jq = (int)(le / NT2), tid = (int)(le % NT2), q = jq / KHH, j = jq % KHH, half = tid & 1;
-        const int k = q < 2 ? 2 * half + q : 2 * (1 - half) + (q - 2);
+      if (le < 4LL * g.KH * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KH, rr = j % g.KH;
         int n;
-        if (vg_slot_unit(g, tid >> 1, n)) v = vg_prescale(g, k) * ref_vc(g, p, n, k, half * KHH + j);
+        if (vg_slot_unit(g, slot, n)) v = ref_vc(g, p, n, k, rr);
       }
-    } else if (e < L.VR) {  // UR[(p*8 + j)][tid] = uc(n(src), p*16 + i), src = lane i + sgn*2j of the 16-lane row
+    } else if (e < L.VR) {  // UR[(p*16+kk)][slot] = uc(n(src), p*16+i)
       const long long le = e - L.UR;
-      if (le < 8LL * g.NP * NT2) {
-        const int jj = (int)(le / NT2), tid = (int)(le % NT2), pp = jj / 8, j = jj % 8, i = tid & 15;
-        const int src = (tid & ~15) | ((i + sgn * 2 * j) & 15);
+      if (le < 1LL * g.KQ * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), pp = j / 16, kk = j % 16, i = slot & 15;
+        const int src = (slot & ~15) | ((i + sgn * kk) & 15);
         int n;
-        if (vg_slot_unit(g, src >> 1, n) && pp * 16 + i < g.KH) v = ref_uc(g, p, n, pp * 16 + i);
+        if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_uc(g, p, n, pp * 16 + i);
       }
-    } else if (e < L.UE) {  // VR[(k*NP*8 + p*8 + j)][tid] = vc(n(src), k, p*16 + i)
+    } else if (e < L.UE) {  // VR[(k*KQ + p*16+kk)][slot] = vc(n(src), k, p*16+i)
       const long long le = e - L.VR;
-      if (le < 32LL * g.NP * NT2) {
-        const int jj = (int)(le / NT2), tid = (int)(le % NT2), k = jj / (8 * g.NP), r8 = jj % (8 * g.NP);
-        const int pp = r8 / 8, j = r8 % 8, i = tid & 15;
-        const int src = (tid & ~15) | ((i + sgn * 2 * j) & 15);
+      if (le < 4LL * g.KQ * NT) {
+        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KQ, jj = j % g.KQ;
+        const int pp = jj / 16, kk = jj % 16, i = slot & 15;
+        const int src = (slot & ~15) | ((i + sgn * kk) & 15);
         int n;
-        if (vg_slot_unit(g, src >> 1, n) && pp * 16 + i < g.KH) v = ref_vc(g, p, n, k, pp * 16 + i);
+        if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_vc(g, p, n, k, pp * 16 + i);
       }
-    } else if (e < L.EH) {  // UE[j][tid] = uc(n, half*KHH + j)
+    } else if (e < L.EH) {  // UE[rr][slot] = uc(n, rr)
       const long long le = e - L.UE;
-      if (le < (long long)KHH * NT2) {
-        const int j = (int)(le / NT2), tid = (int)(le % NT2);
+      if (le < 1LL * g.KH * NT) {
+        const int rr = (int)(le / NT), slot = (int)(le % NT);
         int n;
-        if (vg_slot_unit(g, tid >> 1, n)) v = ref_uc(g, p, n, (tid & 1) * KHH + j);
+        if (vg_slot_unit(g, slot, n)) v = ref_uc(g, p, n, rr);
       }
     } else if (e < L.VRX) {  // EH[k][slot]
       const long long le = e - L.EH;
@@ -90,14 +87,14 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
       const long long le = e - L.VXT;
       if (le < 4LL * g.KX * g.H) {
         const int j = (int)(le / g.H), n = (int)(le % g.H);
-        v = vg_prescale(g, j / g.KX) * ref_vx(g, p, n, j / g.KX, j % g.KX);
+        v = ref_vx(g, p, n, j / g.KX, j % g.KX);
       }
-    } else if (e < L.BBT) {  // EXT[k][n]   (prescaled: feeds xproj only; dx uses the unscaled EXI / ref_ex)
+    } else if (e < L.BBT) {  // EXT[k][n]
       const long long le = e - L.EXT;
-      if (le < 4LL * g.H) v = vg_prescale(g, (int)(le / g.H)) * ref_ex(g, p, (int)(le % g.H), (int)(le / g.H));
+      if (le < 4LL * g.H) v = ref_ex(g, p, (int)(le % g.H), (int)(le / g.H));
     } else if (e < L.UD) {  // BBT[k][n]
       const long long le = e - L.BBT;
-      if (le < 4LL * g.H) v = vg_prescale(g, (int)(le / g.H)) * ref_bb(g, p, (int)(le % g.H), (int)(le / g.H));
+      if (le < 4LL * g.H) v = ref_bb(g, p, (int)(le % g.H), (int)(le / g.H));
     } else {  // step-wise path: group structure written out densely
       const int GK = g.G * g.KH, N4 = 4 * NT;
       int n = -1, k = 0, rr = 0, j = 0, mode = 0;   // mode 1: U element (n, j, rr)   2: V element (n, k, j, rr)   3: Vx
@@ -121,19 +118,12 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
           j = c / g.KH; rr = c % g.KH; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
         }
-      } else if (e < L.EHM) {   // VXTT[slot*4+k][r]
+      } else {                  // VXTT[slot*4+k][r]
         const long long le = e - L.VXTT;
         if (le < (long long)N4 * g.KX) {
           const int i = (int)(le / g.KX);
           rr = (int)(le % g.KX); k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
-        }
-      } else {                  // EHM[q][tid]: prescaled eh of the lane's own gate pair
-        const long long le = e - L.EHM;
-        if (le < 2LL * g.NT2) {
-          const int q = (int)(le / g.NT2), tid = (int)(le % g.NT2);
-          k = 2 * (tid & 1) + q;
-          if (vg_slot_unit(g, tid >> 1, n)) v = vg_prescale(g, k) * ref_eh(g, p, n, k);
         }
       }
       if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s

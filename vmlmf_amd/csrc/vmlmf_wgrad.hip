@@ -14,10 +14,12 @@ template <int KX, int MAXT>
 __global__ void __launch_bounds__(MAXT) dqx_dx_kernel(VGeo g, WgxArgs a) {
   constexpr int NPX = (KX + 15) / 16, KQX = NPX * 16;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int NT = g.NT, NW = g.NW, B = g.B;
+  const int NT = g.NT, NW = g.NW, W = g.W, B = g.B;
   const int TB = g.T * B;
-  int n;
-  const bool valid = vg_slot_unit(g, tid, n);
+  const int grp = tid / (64 * W);
+  const int m = tid - grp * 64 * W;
+  const bool valid = m < g.Hg;
+  const int n = grp * g.Hg + (valid ? m : 0);
   const bool has_x = valid && n < g.I;
   const bool wave_x = __ballot(has_x) != 0ull;
 
