@@ -54,7 +54,7 @@ int main() {
   a.gates = dalloc(TS * 4, 0.f);
   a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
   a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
-  a.trash = dalloc(64, 0.f);
+  a.trash = dalloc(256, 0.f);
   const int it = 50;
   printf("full                         %8.2f us\n", run<0>(g, a, it));
   printf("no tape stores        (1)    %8.2f us\n", run<1>(g, a, it));
@@ -71,5 +71,16 @@ int main() {
   printf("only: no barrier      (64)   %8.2f us\n", run<64>(g, a, it));
   printf("only: no DPP          (128)  %8.2f us\n", run<128>(g, a, it));
   printf("only: no prefetch     (4)    %8.2f us\n", run<4>(g, a, it));
+  printf("instrumented          (256)  %8.2f us\n", run<256>(g, a, 5));
+  {
+    float hbuf[256];
+    CK(hipMemcpy(hbuf, a.trash, sizeof(hbuf), hipMemcpyDeviceToHost));
+    const char* names[7] = {"reduce+write", "wait+barrier", "lds sum", "fma", "gates c h", "stores", "step total"};
+    for (int w = 0; w < 3; ++w) {
+      printf("wave %d memtime ticks/step:", w);
+      for (int i = 0; i < 7; ++i) printf("  %s %.0f", names[i], hbuf[64 + w * 8 + i]);
+      printf("\n");
+    }
+  }
   return 0;
 }
