@@ -88,6 +88,21 @@ __device__ __forceinline__ const gf32* sel_g(bool c, const float* a, const float
 __device__ __forceinline__ void st4g(gf32* p, float4 v) {
   *reinterpret_cast<gf32x4*>(p) = f32x4{v.x, v.y, v.z, v.w};
 }
+// LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base + lane*SIZE).
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gl_cvoid_t;
+__device__ __forceinline__ void dma16(const float* gsrc, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gl_cvoid_t*)gsrc, (lds_void_t*)lds_dst, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const float* gsrc, float* lds_dst) {
+  __builtin_amdgcn_global_load_lds((gl_cvoid_t*)gsrc, (lds_void_t*)lds_dst, 4, 0, 0);
+}
+// wait until at most N vector-memory operations of this wave are outstanding, then the workgroup barrier
+template <int N>
+__device__ __forceinline__ void wait_vm_barrier() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // explicit s_waitcnt vmcnt(0) that hipcc's waitcnt pass understands (expcnt/lgkmcnt left at max)
 __device__ __forceinline__ void wait_vm0() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
