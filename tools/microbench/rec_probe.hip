@@ -1,6 +1,6 @@
-// Ablation probe for rec_fwd_kernel at the bench shape (B=64 T=128 H=180 rank 16): which part of the
-// per-timestep chain costs what.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vmlmf_amd/csrc
-//   tools/microbench/rec_probe.hip -o gpurun_out/rec_probe ; run on the GPU box.  Not part of the library.
+// Phase-timing probe for rec_fwd_kernel at the bench shape (B=64 T=128 H=180 rank 16): s_memtime stamps at
+// the phase boundaries of the compute waves.  Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I vmlmf_amd/csrc
+//   tools/microbench/rec_probe.hip -o tools/microbench/bin/rec_probe ; run on the GPU box.  Not part of the library.
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -11,16 +11,16 @@
 template <int ABL>
 float run(const VGeo& g, const FwdArgs& a, int iters) {
   constexpr int KQ = 16;
-  const size_t lds = sizeof(float) * 2 * 1 * g.NW * KQ;
+  const size_t lds = sizeof(float) * ((size_t)2 * g.NW * KQ + (size_t)FWD_NB * g.NT * 4 + (size_t)2 * g.NT * 8 + 256);
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT), lds, 0, g, a);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT), lds, 0, g, a);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -55,32 +55,15 @@ int main() {
   a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
   a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
   a.trash = dalloc(256, 0.f);
-  const int it = 50;
-  printf("full                         %8.2f us\n", run<0>(g, a, it));
-  printf("no tape stores        (1)    %8.2f us\n", run<1>(g, a, it));
-  printf("no stores at all      (3)    %8.2f us\n", run<3>(g, a, it));
-  printf("no stores, no prefetch (7)   %8.2f us\n", run<7>(g, a, it));
-  printf("+ cheap gates         (15)   %8.2f us\n", run<15>(g, a, it));
-  printf("+ no expansion FMAs   (31)   %8.2f us\n", run<31>(g, a, it));
-  printf("+ no x-wave LDS reads (63)   %8.2f us\n", run<63>(g, a, it));
-  printf("+ no barrier          (127)  %8.2f us\n", run<127>(g, a, it));
-  printf("+ no DPP reduce       (255)  %8.2f us\n", run<255>(g, a, it));
-  printf("only: cheap gates     (8)    %8.2f us\n", run<8>(g, a, it));
-  printf("only: no expansion    (16)   %8.2f us\n", run<16>(g, a, it));
-  printf("only: no LDS reads    (32)   %8.2f us\n", run<32>(g, a, it));
-  printf("only: no barrier      (64)   %8.2f us\n", run<64>(g, a, it));
-  printf("only: no DPP          (128)  %8.2f us\n", run<128>(g, a, it));
-  printf("only: no prefetch     (4)    %8.2f us\n", run<4>(g, a, it));
+  printf("full                         %8.2f us\n", run<0>(g, a, 50));
   printf("instrumented          (256)  %8.2f us\n", run<256>(g, a, 5));
-  {
-    float hbuf[256];
-    CK(hipMemcpy(hbuf, a.trash, sizeof(hbuf), hipMemcpyDeviceToHost));
-    const char* names[7] = {"reduce+write", "wait+barrier", "lds sum", "fma", "gates c h", "stores", "step total"};
-    for (int w = 0; w < 3; ++w) {
-      printf("wave %d memtime ticks/step:", w);
-      for (int i = 0; i < 7; ++i) printf("  %s %.0f", names[i], hbuf[64 + w * 8 + i]);
-      printf("\n");
-    }
+  float hbuf[256];
+  CK(hipMemcpy(hbuf, a.trash, sizeof(hbuf), hipMemcpyDeviceToHost));
+  const char* names[6] = {"reduce+write", "wait+barrier", "lds sum", "fma", "gates+outs", "step total"};
+  for (int w = 0; w < 3; ++w) {
+    printf("wave %d memtime ticks/step:", w);
+    for (int i = 0; i < 6; ++i) printf("  %s %.0f", names[i], hbuf[64 + w * 8 + i]);
+    printf("\n");
   }
   return 0;
 }

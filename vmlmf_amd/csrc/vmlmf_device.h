@@ -51,6 +51,23 @@ __device__ __forceinline__ void fmac_ror(float& acc, float src, float w) {
 }
 __device__ __forceinline__ void dpp_fence(float& src) { asm volatile("s_nop 1" : "+v"(src)); }
 
+// x + (x rotated by K lanes inside the 16-lane row), one instruction (v_add_f32 with a DPP operand)
+template <int K>
+__device__ __forceinline__ float add_ror16(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + K, 0xf, 0xf, true));
+}
+// Sum of the lanes {cc, cc+NC, cc+2NC, ...} of a 16-lane row, delivered to every lane of the class (NC = 2,4,8)
+template <int NC>
+__device__ __forceinline__ float class_sum16(float x) {
+  x = add_ror16<8>(x);
+  if constexpr (NC <= 4) x = add_ror16<4>(x);
+  if constexpr (NC <= 2) x = add_ror16<2>(x);
+  return x;
+}
+__device__ __forceinline__ float bcast_lane(float x, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l));
+}
+
 // Sum over the four 16-lane rows of a wave: every lane i ends with v[i] + v[i+16] + v[i+32] + v[i+48].
 __device__ __forceinline__ float rowsum4(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
