@@ -168,14 +168,27 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const unsigned usyT = (unsigned)g.syT, usyB = (unsigned)g.syB, usxT = (unsigned)g.sxT, usxB = (unsigned)g.sxB;
 
   constexpr int U = 8;   // row pairs per batch: every load of a batch is issued (branch-free) before its MFMAs
+  // (t, b) of this lane's first row; advanced incrementally (one integer division per task, not per row)
+  unsigned tt = (unsigned)(row0 + lk) / (unsigned)B, bb = (unsigned)(row0 + lk) - tt * (unsigned)B;
   for (int rb = row0; rb < row1; rb += 2 * U) {
     float av[U], bv[U][NBT], hv[U], xv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int r = rb + 2 * u + lk;
       const bool ok = r < row1;
-      const unsigned rc = ok ? r : row1 - 1;
-      const unsigned t = rc / (unsigned)B, b = rc - t * (unsigned)B;
+      // clamp to the last valid row of the chunk (values are masked by okf)
+      const unsigned t = ok ? tt : (unsigned)(row1 - 1) / (unsigned)B;
+      const unsigned b = ok ? bb : (unsigned)(row1 - 1) - t * (unsigned)B;
+      const unsigned rc = t * (unsigned)B + b;
+      bb += 2;
+      if (bb >= (unsigned)B) {   // B >= 1; two rows ahead wraps at most... (B == 1: twice)
+        bb -= (unsigned)B;
+        ++tt;
+        if (bb >= (unsigned)B) {
+          bb -= (unsigned)B;
+          ++tt;
+        }
+      }
       // h_{t-1}: y[t-1] for t > 0, else h0 (or 0): address select + mask, no branch
       const float* hp = t > 0 ? a.y + ((t - 1) * usyT + b * usyB) : (has_h0 ? a.h0 + b * (unsigned)H : a.y + b * usyB);
       const float hm = (t > 0 || has_h0) ? 1.f : 0.f;
