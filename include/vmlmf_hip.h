@@ -102,14 +102,28 @@ int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *
                        const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream);
 
 /*
+ * Classifier head of the HAR model: logits = h W^T + bias, the nn.Linear(H, 18) applied to the last timestep
+ * in Net.forward (V/src/models/vmlmf.py:345,353-355) — SURVEY §8f "next" row.  h: B rows of H floats, row
+ * stride ldh (so the last-timestep slice of a (B,T,H) output can be passed without a copy); weight (C,H) and
+ * bias (C) in nn.Linear's layout; logits (B,C) dense.  bias may be NULL.
+ * Backward: dlogits (B,C) -> dh (B,H dense), dweight (C,H), dbias (C); any of the three may be NULL.  C <= 32.
+ * Fixed summation order (no atomics).
+ */
+int vmlmf_head_forward(int B, int H, int C, const float *h, long long ldh, const float *weight,
+                       const float *bias, float *logits, void *stream);
+int vmlmf_head_backward(int B, int H, int C, const float *h, long long ldh, const float *weight,
+                        const float *dlogits, float *dh, float *dweight, float *dbias, void *stream);
+
+/*
  * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel
  * k with bit k set in `mask` is bracketed by a HIP event pair recorded on the SAME stream the kernel is
  * launched on (mask 0 = off, 0xff = all).  vmlmf_profile_read()
  * synchronises the recorded events and returns, per internal kernel, the summed duration in microseconds
  * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 dqx_dx,
- * 5 wgrad, 6 reduce, 7 finish (vmlmf_kernel_name(i) gives the symbol name rocprofv3 reports).
+ * 5 wgrad, 6 reduce, 7 finish, 8 head_fwd, 9 head_bwd (vmlmf_kernel_name(i) gives the symbol name rocprofv3
+ * reports).
  */
-#define VMLMF_NKERNELS 8
+#define VMLMF_NKERNELS 10
 int vmlmf_profile_enable(int mask);
 int vmlmf_profile_read(float *usec_sum, int32_t *count, int reset);
 const char *vmlmf_kernel_name(int k);

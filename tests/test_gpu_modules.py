@@ -121,3 +121,37 @@ def test_unsupported_shape_raises_and_never_falls_back():
     with pytest.raises(_lib.VmlmfError) as ei:
         layer(torch.zeros(3, 4, 64, device=DEV), (torch.zeros(4, 64, device=DEV), torch.zeros(4, 64, device=DEV)))
     assert ei.value.code == _lib.E_UNSUPPORTED
+
+
+@pytest.mark.parametrize("B,H,C,strided", [(64, 180, 18, False), (64, 180, 18, True), (1, 7, 1, False),
+                                           (513, 650, 32, True), (40, 33, 6, False)])
+def test_head_linear_matches_library_linear(B, H, C, strided):
+    """Classifier head kernels (Net.lin, V/src/models/vmlmf.py:345,353-355) against F.linear in fp64."""
+    from vmlmf_amd.functional import HeadLinearFn
+    g = torch.Generator().manual_seed(B * 1000 + H + C)
+    seq = torch.randn(B, 3, H, generator=g).cuda()
+    h = (seq[:, -1] if strided else seq[:, -1].contiguous()).requires_grad_(True)
+    W = (0.1 * torch.randn(C, H, generator=g)).cuda().requires_grad_(True)
+    b = torch.randn(C, generator=g).cuda().requires_grad_(True)
+    dl = torch.randn(B, C, generator=g).cuda()
+    out = HeadLinearFn.apply(h, W, b)
+    gh, gW, gb = torch.autograd.grad(out, (h, W, b), dl)
+    h64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (h, W, b))
+    ref = torch.nn.functional.linear(h64, W64, b64)
+    rh, rW, rb = torch.autograd.grad(ref, (h64, W64, b64), dl.double())
+    for got, want in ((out, ref), (gh, rh), (gW, rW), (gb, rb)):
+        scale = max(1.0, float(want.abs().max()))
+        assert float((got.double() - want).abs().max()) <= 2e-5 * scale
+    out2 = HeadLinearFn.apply(h, W, b)
+    gW2, = torch.autograd.grad(out2, (W,), dl)
+    assert torch.equal(out, out2) and torch.equal(gW, gW2)     # fixed summation order
+
+
+def test_head_rejects_too_many_classes_in_backward_only_through_dispatch():
+    from vmlmf_amd.functional import head_linear
+    h = torch.randn(4, 16).cuda().requires_grad_(True)
+    W = torch.randn(40, 16).cuda().requires_grad_(True)
+    out = head_linear(h, W, None)           # > 32 classes: stock library linear
+    assert out.shape == (4, 40)
+    out.sum().backward()
+    assert h.grad is not None

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .functional import vmlmf_sequence
+from .functional import head_linear, vmlmf_sequence
 
 TIME_STEPS = 128
 RECURRENT_MAX = pow(2, 1 / TIME_STEPS)
@@ -204,7 +204,8 @@ class MyLSTM(nn.Module):
             in_size = hidden_size
         self.rnncells = nn.ModuleList(cells)
 
-    def forward(self, x):
+    def run_layers(self, x):
+        """(output sequence of the last layer, [final h of every layer])."""
         hiddens = []
         for i, cell in enumerate(self.rnncells):
             if hasattr(cell, "sequence"):
@@ -219,6 +220,10 @@ class MyLSTM(nn.Module):
                     outs.append(h)
                 x = torch.stack(outs, self.time_index)
             hiddens.append(h)
+        return x, hiddens
+
+    def forward(self, x):
+        x, hiddens = self.run_layers(x)
         return x, torch.cat(hiddens, -1)
 
 
@@ -240,5 +245,12 @@ class Net(nn.Module):
         self.cell = cell(input_size, layer_sizes[-1], w_rank=w_rank, u_ranks=u)
 
     def forward(self, x):
-        y, _ = self.rnn(x)
-        return self.lin(y[:, -1]).squeeze(1)
+        if isinstance(self.rnn, MyLSTM) and self.rnn.batch_first:
+            # y[:, -1] IS the last layer's final h (same kernel value): taking it from there keeps autograd
+            # from materialising a zero (B,T,H) gradient for y just to carry its last slice
+            _, hiddens = self.rnn.run_layers(x)
+            last = hiddens[-1]
+        else:
+            y, _ = self.rnn(x)
+            last = y[:, -1]
+        return head_linear(last, self.lin.weight, self.lin.bias).squeeze(1)

@@ -21,7 +21,7 @@ int fail(int code, const std::string& msg) {
 }
 
 // ---- profiling (bench.py): HIP event pairs around every internal launch, on the launch stream ----
-constexpr int NKERN = 8;
+constexpr int NKERN = 10;
 struct Prof {
   std::mutex mu;
   unsigned mask = 0;  // bit k: bracket kernel k with an event pair
@@ -367,6 +367,28 @@ int vmlmf_profile_enable(int mask) {
   return 0;
 }
 
+int vmlmf_head_forward(int B, int H, int C, const float* h, long long ldh, const float* weight,
+                       const float* bias, float* logits, void* stream) {
+  if (B < 1 || H < 1 || C < 1 || ldh < H) return fail(VMLMF_E_BADARG, "head: B, H, C must be >= 1 and ldh >= H");
+  if (C > head_max_classes()) return fail(VMLMF_E_UNSUPPORTED, "head: more than 32 classes");
+  if (h == nullptr || weight == nullptr || logits == nullptr) return fail(VMLMF_E_BADARG, "head: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Scope sc(8, s);
+  hipError_t e = launch_head_fwd(B, H, C, h, ldh, weight, bias, logits, s);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+int vmlmf_head_backward(int B, int H, int C, const float* h, long long ldh, const float* weight,
+                        const float* dlogits, float* dh, float* dweight, float* dbias, void* stream) {
+  if (B < 1 || H < 1 || C < 1 || ldh < H) return fail(VMLMF_E_BADARG, "head: B, H, C must be >= 1 and ldh >= H");
+  if (C > head_max_classes()) return fail(VMLMF_E_UNSUPPORTED, "head: more than 32 classes");
+  if (h == nullptr || weight == nullptr || dlogits == nullptr) return fail(VMLMF_E_BADARG, "head: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Scope sc(9, s);
+  hipError_t e = launch_head_bwd(B, H, C, h, ldh, weight, dlogits, dh, dweight, dbias, s);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
 int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int k = 0; k < NKERN; ++k) {
@@ -392,7 +414,8 @@ int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
 
 const char* vmlmf_kernel_name(int k) {
   static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
-                                     "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel"};
+                                     "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel",
+                                     "head_fwd_kernel", "head_bwd_kernel"};
   return (k >= 0 && k < NKERN) ? names[k] : "";
 }
 

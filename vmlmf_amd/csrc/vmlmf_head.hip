@@ -1,0 +1,152 @@
+// Classifier head of Net: logits = h_last W^T + bias (nn.Linear(H, 18), V/src/models/vmlmf.py:345,353-355)
+// and its backward.  B x H x C is tiny (64 x 180 x 18 at the headline shape): a library GEMM costs three
+// launches of 8-10 us plus a bias-gradient reduction; these two kernels are latency-sized instead.
+// Summation orders are fixed (no atomics): results are run-to-run identical.
+#include <hip/hip_runtime.h>
+
+#include "vmlmf_launch.h"
+
+namespace {
+
+constexpr int HEAD_CMAX = 32;   // classes held in registers by the weight-gradient blocks
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// grid B, block 256: wave w owns classes w, w+4, ... (<= 8 of them, accumulated together so that every load
+// of the feature loop is independent of the others); lanes stride the H features.
+__global__ __launch_bounds__(256) void head_fwd_kernel(int H, int C, const float* __restrict__ h, long long ldh,
+                                                       const float* __restrict__ W,
+                                                       const float* __restrict__ bias, float* __restrict__ out) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const float* hb = h + (size_t)b * ldh;
+  float acc[HEAD_CMAX / 4];
+#pragma unroll
+  for (int j = 0; j < HEAD_CMAX / 4; ++j) acc[j] = 0.f;
+  for (int n = lane; n < H; n += 64) {
+    const float hv = hb[n];
+#pragma unroll
+    for (int j = 0; j < HEAD_CMAX / 4; ++j) {
+      const int c = w + 4 * j;
+      const float wv = c < C ? W[(size_t)c * H + n] : 0.f;
+      acc[j] = fmaf(hv, wv, acc[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < HEAD_CMAX / 4; ++j) {
+    const int c = w + 4 * j;
+    const float v = wave_sum(acc[j]);
+    if (lane == 0 && c < C) out[(size_t)b * C + c] = v + (bias != nullptr ? bias[c] : 0.f);
+  }
+}
+
+// One launch, three kinds of workgroup (256 threads each):
+//   [0, B)               dh[b][:]  = dl[b][:] W                      (threads stride n)
+//   [B, B + nH)          dW[:][n]  = sum_b dl[b][:] h[b][n]          (64 features per workgroup; batch rows staged
+//                                                                     through LDS 64 at a time; lane <-> n,
+//                                                                     wave <-> 8 classes)
+//   B + nH               db[:]     = sum_b dl[b][:]
+__global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int C, const float* __restrict__ h,
+                                                       long long ldh, const float* __restrict__ W,
+                                                       const float* __restrict__ dl, float* __restrict__ dh,
+                                                       float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float sh[64][64];                       // h tile  [b][n]
+  __shared__ __attribute__((aligned(16))) float sdl[64][HEAD_CMAX];   // dl tile [b][wave * 8 + j]  (class = wave + 4 j)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int nH = (H + 63) / 64;
+  int blk = blockIdx.x;
+  if (blk < B) {
+    if (dh == nullptr) return;
+    if (threadIdx.x < HEAD_CMAX) sdl[0][threadIdx.x] = (int)threadIdx.x < C ? dl[(size_t)blk * C + threadIdx.x] : 0.f;
+    __syncthreads();
+    for (int n = threadIdx.x; n < H; n += 256) {
+      float acc = 0.f;
+#pragma unroll 8
+      for (int c = 0; c < C; ++c) acc = fmaf(sdl[0][c], W[(size_t)c * H + n], acc);
+      dh[(size_t)blk * H + n] = acc;
+    }
+    return;
+  }
+  blk -= B;
+  if (blk < nH) {
+    if (dW == nullptr) return;
+    const int n = blk * 64 + lane;
+    const bool ok = n < H;
+    float acc[HEAD_CMAX / 4];
+#pragma unroll
+    for (int j = 0; j < HEAD_CMAX / 4; ++j) acc[j] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += 64) {
+      if (b0 > 0) __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {                 // 16 independent coalesced loads per thread
+        const int b = b0 + i * 4 + w;
+        sh[i * 4 + w][lane] = (ok && b < B) ? h[(size_t)b * ldh + n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {                  // 64 x 32 dl tile: thread -> (row, class slot)
+        const int e = i * 256 + threadIdx.x, r = e >> 5, slot = e & 31, c = (slot >> 3) + 4 * (slot & 7);
+        const int b = b0 + r;
+        sdl[r][slot] = (b < B && c < C) ? dl[(size_t)b * C + c] : 0.f;
+      }
+      __syncthreads();
+#pragma unroll 4
+      for (int r = 0; r < 64; ++r) {
+        const float hv = sh[r][lane];
+        const float4 d0 = *reinterpret_cast<const float4*>(&sdl[r][w * 8]);
+        const float4 d1 = *reinterpret_cast<const float4*>(&sdl[r][w * 8 + 4]);
+        acc[0] = fmaf(d0.x, hv, acc[0]);
+        acc[1] = fmaf(d0.y, hv, acc[1]);
+        acc[2] = fmaf(d0.z, hv, acc[2]);
+        acc[3] = fmaf(d0.w, hv, acc[3]);
+        acc[4] = fmaf(d1.x, hv, acc[4]);
+        acc[5] = fmaf(d1.y, hv, acc[5]);
+        acc[6] = fmaf(d1.z, hv, acc[6]);
+        acc[7] = fmaf(d1.w, hv, acc[7]);
+      }
+    }
+    if (ok) {
+#pragma unroll
+      for (int j = 0; j < HEAD_CMAX / 4; ++j) {
+        const int c = w + 4 * j;
+        if (c < C) dW[(size_t)c * H + n] = acc[j];
+      }
+    }
+    return;
+  }
+  if (db == nullptr) return;
+  // bias gradient: thread -> (class, one of 8 batch stripes); stripes are summed in a fixed order
+  const int c = threadIdx.x & 31, st = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < C) {
+#pragma unroll 8
+    for (int b = st; b < B; b += 8) s += dl[(size_t)b * C + c];
+  }
+  sdl[st][c] = s;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    float t = sdl[0][c];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) t += sdl[q][c];
+    db[c] = t;
+  }
+}
+
+}  // namespace
+
+int head_max_classes() { return HEAD_CMAX; }
+
+hipError_t launch_head_fwd(int B, int H, int C, const float* h, long long ldh, const float* W, const float* bias,
+                           float* out, hipStream_t s) {
+  hipLaunchKernelGGL(head_fwd_kernel, dim3(B), dim3(256), 0, s, H, C, h, ldh, W, bias, out);
+  return hipGetLastError();
+}
+
+hipError_t launch_head_bwd(int B, int H, int C, const float* h, long long ldh, const float* W, const float* dl,
+                           float* dh, float* dW, float* db, hipStream_t s) {
+  const int nH = (H + 63) / 64;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3(B + nH + 1), dim3(256), 0, s, B, H, C, h, ldh, W, dl, dh, dW, db);
+  return hipGetLastError();
+}

@@ -46,5 +46,12 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s);
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s);
 
+// classifier head (vmlmf_head.hip)
+int head_max_classes();
+hipError_t launch_head_fwd(int B, int H, int C, const float* h, long long ldh, const float* W, const float* bias,
+                           float* out, hipStream_t s);
+hipError_t launch_head_bwd(int B, int H, int C, const float* h, long long ldh, const float* W, const float* dl,
+                           float* dh, float* dW, float* db, hipStream_t s);
+
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

@@ -158,3 +158,57 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major))
     return VmlmfSeqFn.apply(cfg, x, h0, c0, *params)
+
+
+class HeadLinearFn(torch.autograd.Function):
+    """logits = h @ W^T + bias for the classifier on the last timestep (Net.lin, V/src/models/vmlmf.py:345,
+    353-355): two latency-sized kernels instead of three library GEMM launches and a bias-gradient reduction."""
+
+    @staticmethod
+    def forward(ctx, h, weight, bias):
+        ctx.set_materialize_grads(False)
+        _require_hip(h, "head input")
+        _require_hip(weight, "head weight")
+        if h.stride(-1) != 1:
+            h = h.contiguous()
+        weight = weight.contiguous()
+        bias_c = None if bias is None else bias.contiguous()
+        B, H = h.shape
+        C = weight.shape[0]
+        out = torch.empty((B, C), device=h.device, dtype=torch.float32)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().vmlmf_head_forward(B, H, C, _ptr(h), h.stride(0), _ptr(weight), _ptr(bias_c),
+                                                     _ptr(out), stream))
+        ctx.save_for_backward(h, weight)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        if dl is None:
+            return None, None, None
+        h, weight = ctx.saved_tensors
+        dl = dl.contiguous()
+        B, H = h.shape
+        C = weight.shape[0]
+        need_h, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        dh = torch.empty((B, H), device=h.device, dtype=torch.float32) if need_h else None
+        # weight and bias gradients share one allocation (contiguous for the data-parallel all-reduce)
+        flat = torch.empty(C * H + C, device=h.device, dtype=torch.float32) if (need_w or need_b) else None
+        dW = flat[:C * H].view(C, H) if need_w else None
+        db = flat[C * H:] if need_b else None
+        stream = ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
+        with torch.cuda.device(h.device):
+            _lib.check(_lib.lib().vmlmf_head_backward(B, H, C, _ptr(h), h.stride(0), _ptr(weight), _ptr(dl),
+                                                      _ptr(dh), _ptr(dW), _ptr(db), stream))
+        return dh, dW, db
+
+
+def head_linear(h, weight, bias):
+    """nn.Linear on (B, H) rows through the head kernels when they apply (HIP fp32, <= 32 classes); the stock
+    library op otherwise (it is not part of the VMLMF path and has no CPU restriction of its own)."""
+    if (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and weight.dtype == torch.float32
+            and weight.shape[0] <= _lib.HEAD_MAX_CLASSES):
+        return HeadLinearFn.apply(h, weight, bias)
+    return torch.nn.functional.linear(h, weight, bias)
