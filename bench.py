@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only")
+    ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -144,10 +145,15 @@ def main():
     reducer = FlatGradAllReduce(net.parameters(), op="avg")
     lib = _lib.lib()
 
+    # the criterion of the reference's loop (nn.CrossEntropyLoss, train.py:58-65): the package's fused kernels,
+    # or the stock library op with --torch-loss (same values, six launches instead of two)
+    import vmlmf_amd
+    criterion = torch.nn.functional.cross_entropy if args.torch_loss else vmlmf_amd.cross_entropy
+
     def fwd_bwd():
         net.zero_grad(set_to_none=True)
         out = net(x)
-        loss = torch.nn.functional.cross_entropy(out, tgt)
+        loss = criterion(out, tgt)
         loss.backward()
         return loss
 
@@ -286,7 +292,8 @@ def main():
                                    "B=64/GPU T=128 I=9 H=180 w_rank=16 u_rank=16, CE loss, fwd+bwd"
                                    + (", flat RCCL all-reduce (AVG) of grads" if world > 1 else ""),
                        "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}",
-                       "launch": launch_mode},
+                       "launch": launch_mode,
+                       "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
             "step_flops": rows * F_STEP,

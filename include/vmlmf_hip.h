@@ -115,15 +115,28 @@ int vmlmf_head_backward(int B, int H, int C, const float *h, long long ldh, cons
                         const float *dlogits, float *dh, float *dweight, float *dbias, void *stream);
 
 /*
+ * Cross-entropy of the classifier logits, mean over the rows whose target != ignore_index: the criterion of
+ * the reference's training loop (nn.CrossEntropyLoss on Net's output, V/src/train_test/train.py:58-65) — SURVEY
+ * §8f "next" row.  logits (B,C) dense fp32, target (B) int64.  Forward writes the scalar loss, the row
+ * log-sum-exps lse (B) and the number of counted rows nvalid (1); backward turns them and the incoming
+ * gradient of the loss (device scalar) into dlogits (B,C).  One workgroup in forward: meant for classifier
+ * sized problems (the Python wrapper dispatches B*C <= 65536 here and leaves larger ones to the library op).
+ */
+int vmlmf_ce_forward(int B, int C, const float *logits, const int64_t *target, int64_t ignore_index, float *loss,
+                     float *lse, float *nvalid, void *stream);
+int vmlmf_ce_backward(int B, int C, const float *logits, const int64_t *target, int64_t ignore_index,
+                      const float *lse, const float *nvalid, const float *dloss, float *dlogits, void *stream);
+
+/*
  * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel
  * k with bit k set in `mask` is bracketed by a HIP event pair recorded on the SAME stream the kernel is
  * launched on (mask 0 = off, 0xff = all).  vmlmf_profile_read()
  * synchronises the recorded events and returns, per internal kernel, the summed duration in microseconds
  * and the number of launches.  Kernel indices: 0 pack, 1 xproj, 2 rec_fwd, 3 rec_bwd, 4 dqx_dx,
- * 5 wgrad, 6 reduce, 7 finish, 8 head_fwd, 9 head_bwd (vmlmf_kernel_name(i) gives the symbol name rocprofv3
- * reports).
+ * 5 wgrad, 6 reduce, 7 finish, 8 head_fwd, 9 head_bwd, 10 ce_fwd, 11 ce_bwd (vmlmf_kernel_name(i) gives the
+ * symbol name rocprofv3 reports).
  */
-#define VMLMF_NKERNELS 10
+#define VMLMF_NKERNELS 12
 int vmlmf_profile_enable(int mask);
 int vmlmf_profile_read(float *usec_sum, int32_t *count, int reset);
 const char *vmlmf_kernel_name(int k);

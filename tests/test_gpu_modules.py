@@ -155,3 +155,31 @@ def test_head_rejects_too_many_classes_in_backward_only_through_dispatch():
     assert out.shape == (4, 40)
     out.sum().backward()
     assert h.grad is not None
+
+
+@pytest.mark.parametrize("B,C,ignored", [(64, 18, 0), (64, 18, 5), (1, 2, 0), (300, 7, 17), (513, 100, 0)])
+def test_fused_cross_entropy_matches_library(B, C, ignored):
+    """vmlmf_amd.cross_entropy against torch.nn.functional.cross_entropy (the reference's criterion) in fp64."""
+    import vmlmf_amd
+    g = torch.Generator().manual_seed(B + C)
+    z = (3 * torch.randn(B, C, generator=g)).cuda().requires_grad_(True)
+    t = torch.randint(0, C, (B,), generator=g)
+    if ignored:
+        t[torch.randperm(B, generator=g)[:min(ignored, B - 1)]] = -100
+    t = t.cuda()
+    loss = vmlmf_amd.cross_entropy(z, t)
+    (3.0 * loss).backward()
+    z64 = z.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(z64, t)
+    (3.0 * ref).backward()
+    assert abs(float(loss) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    assert float((z.grad.double() - z64.grad).abs().max()) <= 1e-7 + 2e-6 * float(z64.grad.abs().max())
+    loss2 = vmlmf_amd.CrossEntropyLoss()(z.detach(), t)
+    assert torch.equal(loss.detach(), loss2)
+
+
+def test_cross_entropy_dispatch_leaves_other_cases_to_the_library():
+    import vmlmf_amd
+    z = torch.randn(4, 3, 5).cuda()            # (N, C, d) form: not the classifier case
+    t = torch.randint(0, 3, (4, 5)).cuda()
+    assert torch.allclose(vmlmf_amd.cross_entropy(z, t), torch.nn.functional.cross_entropy(z, t))

@@ -6,7 +6,7 @@ MI355X (gfx950), behind the reference's own nn.Module API.
 """
 from .cells import MyVMLMFCell, MyVMLMFCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
 from .lm import MyVMLSTM, MyVMLSTMGroup
-from .functional import vmlmf_sequence
+from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss
 
-__all__ = ["MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
+__all__ = ["head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
            "vmlmf_sequence"]

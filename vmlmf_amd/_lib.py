@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libvmlmf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_G = 2
-NKERNELS = 10
+NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP = 1, 2, 3, 4
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
@@ -53,6 +53,8 @@ SYMBOLS = {
                                 _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp]),
     "vmlmf_head_forward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "vmlmf_head_backward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "vmlmf_ce_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "vmlmf_ce_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_profile_enable": (_i, [_i]),
     "vmlmf_profile_read": (_i, [_fp, ctypes.POINTER(ctypes.c_int32), _i]),
     "vmlmf_kernel_name": (ctypes.c_char_p, [_i]),

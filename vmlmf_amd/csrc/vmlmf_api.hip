@@ -21,7 +21,7 @@ int fail(int code, const std::string& msg) {
 }
 
 // ---- profiling (bench.py): HIP event pairs around every internal launch, on the launch stream ----
-constexpr int NKERN = 10;
+constexpr int NKERN = 12;
 struct Prof {
   std::mutex mu;
   unsigned mask = 0;  // bit k: bracket kernel k with an event pair
@@ -389,6 +389,27 @@ int vmlmf_head_backward(int B, int H, int C, const float* h, long long ldh, cons
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 
+int vmlmf_ce_forward(int B, int C, const float* logits, const int64_t* target, int64_t ignore_index, float* loss,
+                     float* lse, float* nvalid, void* stream) {
+  if (B < 1 || C < 1) return fail(VMLMF_E_BADARG, "ce: B and C must be >= 1");
+  if (!logits || !target || !loss || !lse || !nvalid) return fail(VMLMF_E_BADARG, "ce: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Scope sc(10, s);
+  hipError_t e = launch_ce_fwd(B, C, logits, (const long long*)target, (long long)ignore_index, loss, lse, nvalid, s);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+int vmlmf_ce_backward(int B, int C, const float* logits, const int64_t* target, int64_t ignore_index,
+                      const float* lse, const float* nvalid, const float* dloss, float* dlogits, void* stream) {
+  if (B < 1 || C < 1) return fail(VMLMF_E_BADARG, "ce: B and C must be >= 1");
+  if (!logits || !target || !lse || !nvalid || !dloss || !dlogits) return fail(VMLMF_E_BADARG, "ce: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  Scope sc(11, s);
+  hipError_t e = launch_ce_bwd(B, C, logits, (const long long*)target, (long long)ignore_index, lse, nvalid, dloss,
+                               dlogits, s);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
 int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int k = 0; k < NKERN; ++k) {
@@ -415,7 +436,7 @@ int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
 const char* vmlmf_kernel_name(int k) {
   static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
                                      "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel",
-                                     "head_fwd_kernel", "head_bwd_kernel"};
+                                     "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel"};
   return (k >= 0 && k < NKERN) ? names[k] : "";
 }
 

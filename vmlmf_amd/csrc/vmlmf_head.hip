@@ -150,3 +150,80 @@ hipError_t launch_head_bwd(int B, int H, int C, const float* h, long long ldh, c
   hipLaunchKernelGGL(head_bwd_kernel, dim3(B + nH + 1), dim3(256), 0, s, B, H, C, h, ldh, W, dl, dh, dW, db);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Cross-entropy of the classifier logits (mean over the rows whose target is not ignore_index), the loss the
+// reference's training loop applies to Net's output (nn.CrossEntropyLoss, V/src/train_test/train.py:58-65).
+// Stock PyTorch spends six launches on it (log_softmax, nll_loss, two fills and their two backward kernels);
+// at B x C = 64 x 18 each of them is pure launch latency.  One workgroup, fixed summation order.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+
+// row statistics: lse[b] = log sum_c exp(z[b][c]);  loss = -(1/N) sum_valid (z[b][t_b] - lse[b])
+__global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* __restrict__ z,
+                                                     const long long* __restrict__ tgt, long long ignore_index,
+                                                     float* __restrict__ loss, float* __restrict__ lse,
+                                                     float* __restrict__ nvalid) {
+  __shared__ float ssum[256];
+  __shared__ float scnt[256];
+  float part = 0.f, cnt = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float* zb = z + (size_t)b * C;
+    float m = -INFINITY;
+    for (int c = 0; c < C; ++c) m = fmaxf(m, zb[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(zb[c] - m);
+    const float l = m + logf(s);
+    lse[b] = l;
+    const long long t = tgt[b];
+    if (t != ignore_index) {
+      part += l - zb[t];
+      cnt += 1.f;
+    }
+  }
+  ssum[threadIdx.x] = part;
+  scnt[threadIdx.x] = cnt;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {   // fixed-shape tree: run-to-run identical
+    if ((int)threadIdx.x < o) {
+      ssum[threadIdx.x] += ssum[threadIdx.x + o];
+      scnt[threadIdx.x] += scnt[threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *nvalid = scnt[0];
+    *loss = ssum[0] / scnt[0];   // 0/0 = NaN when every target is ignored, as PyTorch returns
+  }
+}
+
+// dz[b][c] = (softmax(z[b])[c] - [c == t_b]) * dloss / N   (0 for ignored rows)
+__global__ __launch_bounds__(256) void ce_bwd_kernel(int B, int C, const float* __restrict__ z,
+                                                     const long long* __restrict__ tgt, long long ignore_index,
+                                                     const float* __restrict__ lse,
+                                                     const float* __restrict__ nvalid,
+                                                     const float* __restrict__ dloss, float* __restrict__ dz) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (long long)B * C) return;
+  const int b = (int)(e / C), c = (int)(e - (long long)b * C);
+  const long long t = tgt[b];
+  const float scale = dloss[0] / nvalid[0];
+  const float p = expf(z[e] - lse[b]);
+  dz[e] = t == ignore_index ? 0.f : scale * (p - (c == (int)t ? 1.f : 0.f));
+}
+
+}  // namespace
+
+hipError_t launch_ce_fwd(int B, int C, const float* z, const long long* tgt, long long ignore_index, float* loss,
+                         float* lse, float* nvalid, hipStream_t s) {
+  hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid);
+  return hipGetLastError();
+}
+
+hipError_t launch_ce_bwd(int B, int C, const float* z, const long long* tgt, long long ignore_index,
+                         const float* lse, const float* nvalid, const float* dloss, float* dz, hipStream_t s) {
+  const long long n = (long long)B * C;
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, B, C, z, tgt, ignore_index,
+                     lse, nvalid, dloss, dz);
+  return hipGetLastError();
+}

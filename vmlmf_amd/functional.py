@@ -212,3 +212,59 @@ def head_linear(h, weight, bias):
             and weight.shape[0] <= _lib.HEAD_MAX_CLASSES):
         return HeadLinearFn.apply(h, weight, bias)
     return torch.nn.functional.linear(h, weight, bias)
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    """Mean cross-entropy of (B, C) logits against int64 targets, forward and backward in one launch each."""
+
+    @staticmethod
+    def forward(ctx, logits, target, ignore_index):
+        _require_hip(logits, "logits")
+        logits = logits.contiguous()
+        target = target.contiguous()
+        B, C = logits.shape
+        dev = logits.device
+        stats = torch.empty(B + 2, device=dev, dtype=torch.float32)     # loss | nvalid | lse[B]
+        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        with torch.cuda.device(dev):
+            _lib.check(_lib.lib().vmlmf_ce_forward(B, C, _ptr(logits), _ptr(target), int(ignore_index),
+                                                   stats.data_ptr(), stats.data_ptr() + 8, stats.data_ptr() + 4,
+                                                   stream))
+        ctx.save_for_backward(logits, target, stats)
+        ctx.ignore_index = int(ignore_index)
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logits, target, stats = ctx.saved_tensors
+        B, C = logits.shape
+        dloss = dloss.contiguous()
+        dz = torch.empty_like(logits)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        with torch.cuda.device(logits.device):
+            _lib.check(_lib.lib().vmlmf_ce_backward(B, C, _ptr(logits), _ptr(target), ctx.ignore_index,
+                                                    stats.data_ptr() + 8, stats.data_ptr() + 4, _ptr(dloss),
+                                                    _ptr(dz), stream))
+        return dz, None, None
+
+
+def cross_entropy(input, target, ignore_index=-100):
+    """Drop-in for torch.nn.functional.cross_entropy(input, target) with the default arguments (mean reduction,
+    class-index targets, no weights, no label smoothing) — the criterion of the reference's training loop
+    (V/src/train_test/train.py:58-65).  Classifier-sized (B, C) fp32 logits on a HIP device take the fused
+    kernels; anything else goes to the library op."""
+    if (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and target.dtype == torch.int64
+            and target.dim() == 1 and input.numel() <= 65536):
+        return CrossEntropyFn.apply(input, target, ignore_index)
+    return torch.nn.functional.cross_entropy(input, target, ignore_index=ignore_index)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """nn.CrossEntropyLoss() with default arguments, on the fused kernels (see cross_entropy)."""
+
+    def __init__(self, ignore_index=-100):
+        super().__init__()
+        self.ignore_index = ignore_index
+
+    def forward(self, input, target):
+        return cross_entropy(input, target, self.ignore_index)
