@@ -113,6 +113,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only")
+    ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
     ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
     args = ap.parse_args()
 
@@ -124,8 +125,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # --force-collective: run the gradient all-reduce (RCCL) even on one GPU, to exercise the N > 1 code path
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from vmlmf_amd import MyLSTM, MyVMLMFCell, Net, _lib
@@ -143,6 +147,7 @@ def main():
     x = torch.tensor(x_np, device=dev)
     tgt = torch.tensor(tgt_np, device=dev)
     reducer = FlatGradAllReduce(net.parameters(), op="avg")
+    reducer.always = args.force_collective
     lib = _lib.lib()
 
     # the criterion of the reference's loop (nn.CrossEntropyLoss, train.py:58-65): the package's fused kernels,
@@ -159,12 +164,12 @@ def main():
 
     def step():
         loss = fwd_bwd()
-        if world > 1:
+        if collective:
             reducer.reduce()
         return loss
 
     def barrier():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -203,31 +208,48 @@ def main():
     if not args.no_graph:
         import gc
         gc.collect()
-        try:
+        def capture(body):
             side = torch.cuda.Stream(dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    fwd_bwd()
+                    body()
             torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             net.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
-                g_loss = fwd_bwd()
-            captured = True
-        except Exception as e:   # capture unsupported -> keep the eager number, say so
-            log(f"hipGraph capture failed ({type(e).__name__}: {e}); reporting the eager timed region")
-            torch.cuda.synchronize()
-            captured = False
-        if world > 1:            # every rank must take the same path (the replay loop contains a collective)
-            flag = torch.tensor([1 if captured else 0], device=dev)
+                out = body()
+            return graph, out
+
+        def agree(ok):      # every rank must take the same path (the replay loop may contain a collective)
+            if not collective:
+                return ok
+            flag = torch.tensor([1 if ok else 0], device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            captured = bool(flag.item())
+            return bool(flag.item())
+
+        # first choice: the gradient all-reduce captured too (one graph launch per step); second: the
+        # collective stays an eager RCCL call after each replay; last: the eager timed region above
+        graph, g_loss, reduce_in_graph = None, None, False
+        for body, with_reduce in ((step, True), (fwd_bwd, False)) if collective else ((fwd_bwd, False),):
+            try:
+                graph, g_loss = capture(body)
+                ok = True
+            except Exception as e:
+                log(f"hipGraph capture ({'with' if with_reduce else 'without'} the all-reduce) failed "
+                    f"({type(e).__name__}: {e})")
+                torch.cuda.synchronize()
+                graph, ok = None, False
+            if agree(ok):
+                reduce_in_graph = with_reduce
+                break
+            graph = None
+        captured = graph is not None
         if captured:
             def gstep():
                 graph.replay()
-                if world > 1:
+                if collective and not reduce_in_graph:
                     reducer.reduce()
                 return g_loss
 
@@ -241,7 +263,8 @@ def main():
             dt_graph = time.perf_counter() - t0
             loss = g_loss.detach().clone()
             log(f"hipGraph timed region done: {dt_graph / args.steps * 1e3:.4f} ms/step")
-            launch_mode, dt = "hipgraph", dt_graph
+            launch_mode = "hipgraph" + ("+allreduce" if reduce_in_graph else "")
+            dt = dt_graph
 
     # untimed extra pass: every internal kernel bracketed, for the breakdown
     lib.vmlmf_profile_enable(0xff)
@@ -263,7 +286,7 @@ def main():
     adam_ms = (time.perf_counter() - t1) / 20 * 1e3
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
+    if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -290,7 +313,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: UCI-HAR shape, Net(MyLSTM[MyVMLMFCell]) 1 layer, "
                                    "B=64/GPU T=128 I=9 H=180 w_rank=16 u_rank=16, CE loss, fwd+bwd"
-                                   + (", flat RCCL all-reduce (AVG) of grads" if world > 1 else ""),
+                                   + (", in-place RCCL all-reduce (AVG) of the flat gradient buffers" if collective else ""),
                        "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}",
                        "launch": launch_mode,
                        "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
@@ -316,7 +339,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out))
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

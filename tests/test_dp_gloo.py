@@ -26,13 +26,36 @@ class Toy(torch.nn.Module):
         return torch.tanh(x @ self.a + self.b)
 
 
-def _worker(rank, world, port, op, out):
+class _FlatGradAffine(torch.autograd.Function):
+    """x @ a + b whose backward hands autograd VIEWS of one flat buffer, like functional.VmlmfSeqFn does."""
+
+    @staticmethod
+    def forward(ctx, x, a, b):
+        ctx.save_for_backward(x, a)
+        return x @ a + b
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, a = ctx.saved_tensors
+        flat = torch.empty(a.numel() + dy.shape[1])
+        da, db = flat[:a.numel()].view_as(a), flat[a.numel():]
+        da.copy_(x.t() @ dy)
+        db.copy_(dy.sum(0))
+        return None, da, db
+
+
+class TiledToy(Toy):
+    def forward(self, x):
+        return torch.tanh(_FlatGradAffine.apply(x, self.a, self.b))
+
+
+def _worker(rank, world, port, op, out, tiled=False):
     sys.path.insert(0, ROOT)
     from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters, shard_batch
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.manual_seed(100 + rank)                 # replicas start different ...
-    m = Toy()
+    m = TiledToy() if tiled else Toy()
     with torch.no_grad():
         m.a.add_(rank)
     broadcast_parameters(m)                       # ... and are made identical
@@ -42,17 +65,23 @@ def _worker(rank, world, port, op, out):
     loss = y.mean(dim=1).mean() if op == "avg" else y.mean(dim=1).sum()
     loss.backward()
     red = FlatGradAllReduce(m.parameters(), op=op)
+    in_place = [flat is not None for flat, _ in red._spans([p.grad for p in m.parameters() if p.grad is not None])]
     red.reduce()
     if rank == 0:
-        torch.save({"a": m.a.grad, "b": m.b.grad, "n": red.numel(), "a0": m.a.detach()}, out)
+        torch.save({"a": m.a.grad.clone(), "b": m.b.grad.clone(), "n": red.numel(), "a0": m.a.detach(),
+                    "in_place": in_place, "staged": red.flat is not None}, out)
     dist.destroy_process_group()
 
 
-def _run(op, tmp_path):
-    out = str(tmp_path / f"dp_{op}.pt")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, op, out), nprocs=2, join=True)
+def _run(op, tmp_path, tiled=False):
+    out = str(tmp_path / f"dp_{op}_{int(tiled)}.pt")
+    port = 29500 + (os.getpid() % 2000) + (7 if tiled else 0)
+    mp.spawn(_worker, args=(2, port, op, out, tiled), nprocs=2, join=True)
     got = torch.load(out)
+    if tiled:      # both gradients live in one allocation: reduced where they are, no staging buffer
+        assert got["in_place"] == [True] and not got["staged"]
+    else:          # gradients alone in their allocations share the staging buffer (one collective)
+        assert not any(got["in_place"]) and got["staged"]
     m = Toy()
     x = torch.randn(10, 6, generator=torch.Generator().manual_seed(1))
     y = m(x)
@@ -70,6 +99,11 @@ def test_avg_matches_global_batch_mean_loss(tmp_path):
 
 def test_sum_matches_global_batch_sum_loss(tmp_path):
     _run("sum", tmp_path)
+
+
+def test_gradients_sharing_a_flat_allocation_are_reduced_in_place(tmp_path):
+    _run("avg", tmp_path, tiled=True)
+    _run("sum", tmp_path, tiled=True)
 
 
 def test_shard_batch_is_a_contiguous_partition():

@@ -3,8 +3,9 @@
 The reference has no distributed code.  Batch rows are independent through the
 whole forward/backward, so the only exchange is the sum over ranks of the parameter gradients.  The
 payload is tiny (HAR Net: 30 951 floats = 121 KiB), i.e. latency-bound on xGMI: bucketing would only add
-launches, so every gradient goes through a single all-reduce on the compute stream
-(torch.distributed backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
+launches.  The kernels already write a layer's gradients into one flat allocation, so the exchange is one
+in-place all-reduce per such allocation on the compute stream (HAR Net: the layer's and the classifier's),
+with no staging copies (torch.distributed backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
 
 Reduction op must reproduce single-process semantics:
   HAR  loss = mean CE over the local batch  (train.py:63)      -> AVG over ranks
@@ -24,38 +25,68 @@ class FlatGradAllReduce:
         self.op = op
         self.group = group
         self.params = [p for p in params if p.requires_grad]
-        self.flat = None
-        self.active = None
+        self.always = False   # run the collectives even in a group of one (bench self-test of the RCCL path)
+        self.flat = None   # staging buffer for gradients that do not already share a flat allocation
 
-    def _layout(self):
-        # parameters that never receive a gradient (e.g. Net.cell, the reference's unused duplicate,
-        # vmlmf.py:349-350) are left out; every rank sees the same set because the model is replicated
-        self.active = [p for p in self.params if p.grad is not None]
-        n = sum(p.numel() for p in self.active)
-        dev = self.active[0].device if self.active else torch.device("cpu")
-        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.views, o = [], 0
-        for p in self.active:
-            self.views.append(self.flat[o:o + p.numel()].view_as(p))
-            o += p.numel()
-
+    # parameters that never receive a gradient (e.g. Net.cell, the reference's unused duplicate,
+    # vmlmf.py:349-350) are left out; every rank sees the same set because the model is replicated
     def numel(self):
-        return 0 if self.flat is None else self.flat.numel()
+        return sum(p.grad.numel() for p in self.params if p.grad is not None)
+
+    @staticmethod
+    def _spans(grads):
+        """Group gradient tensors by the allocation they live in.  The VMLMF layer (functional.VmlmfSeqFn) and
+        the classifier head hand autograd views of ONE flat buffer each, so a group usually tiles a contiguous
+        range that can be reduced in place; a gradient alone in its allocation goes through the staging buffer with
+        the other loners (one collective for all of them).  Returns [(flat_view_or_None, [grads])]."""
+        groups = {}
+        for g in grads:
+            groups.setdefault(g.untyped_storage().data_ptr(), []).append(g)
+        out = []
+        for gs in groups.values():
+            gs = sorted(gs, key=lambda t: t.storage_offset())
+            tiled = len(gs) > 1 and all(t.is_contiguous() and t.dtype == torch.float32 for t in gs) and all(
+                a.storage_offset() + a.numel() == b.storage_offset() for a, b in zip(gs, gs[1:]))
+            if tiled:
+                n = gs[-1].storage_offset() + gs[-1].numel() - gs[0].storage_offset()
+                out.append((torch.as_strided(gs[0], (n,), (1,), gs[0].storage_offset()), gs))
+            else:
+                out.append((None, gs))
+        return out
 
     def reduce(self):
-        """Call after backward().  In-place on the parameters' .grad tensors."""
-        if self.flat is None:
-            self._layout()
-        if not self.active:
+        """Call after backward().  In-place on the parameters' .grad tensors: gradients that already tile a flat
+        allocation are reduced where they are (no staging copies); the rest go through the staging buffer."""
+        params = [p for p in self.params if p.grad is not None]
+        if not params:
             return
-        grads = [p.grad for p in self.active]
-        torch._foreach_copy_(self.views, grads)
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.op == "avg":
-                self.flat.mul_(1.0 / world)
-        torch._foreach_copy_(grads, self.views)
+        backend = dist.get_backend(self.group) if dist.is_initialized() else ""
+        native_avg = self.op == "avg" and backend == "nccl"      # RCCL averages in the collective itself
+        op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
+        scale = None if (native_avg or self.op == "sum") else 1.0 / world
+        loose = []
+        for flat, gs in self._spans([p.grad for p in params]):
+            if flat is None:
+                loose += gs
+                continue
+            if world > 1 or self.always:
+                dist.all_reduce(flat, op=op, group=self.group)
+                if scale is not None:
+                    flat.mul_(scale)
+        if loose:
+            if self.flat is None or self.flat.numel() != sum(g.numel() for g in loose):
+                self.flat = torch.empty(sum(g.numel() for g in loose), dtype=torch.float32, device=loose[0].device)
+            views, o = [], 0
+            for g in loose:
+                views.append(self.flat[o:o + g.numel()].view_as(g))
+                o += g.numel()
+            torch._foreach_copy_(views, loose)
+            if world > 1 or self.always:
+                dist.all_reduce(self.flat, op=op, group=self.group)
+                if scale is not None:
+                    self.flat.mul_(scale)
+            torch._foreach_copy_(loose, views)
 
 
 def broadcast_parameters(module, src=0, group=None):
