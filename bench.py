@@ -5,7 +5,7 @@ Metric: RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16 (UCI-HAR shape, M
 A "step" is one pass of the hot path over one synthetic batch:
     zero_grad -> Net.forward (MyLSTM over T=128 + Linear) -> cross-entropy -> backward
     (+ ONE flat RCCL all-reduce of the gradients when N > 1).  The optimizer is outside the timed region and
-reported separately (`adam_ms`).  Inputs are resident in HBM before the timed region starts.
+reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step_ms` everything in one graph).  Inputs are resident in HBM before the timed region starts.
 value = (N ranks x T timesteps per step) / step time: weak scaling, per-GPU batch fixed at 64
 (N = 8 is BASELINE config D: global batch 512).
 
@@ -275,15 +275,40 @@ def main():
     lib.vmlmf_profile_enable(0)
     kern = {lib.vmlmf_kernel_name(k).decode(): round(usec[k] / max(cnt[k], 1), 2) for k in range(_lib.NKERNELS)}
 
-    # optimizer, outside the metric (train.py:47,65)
-    opt = torch.optim.Adam(net.parameters(), lr=0.002)
-    step()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(20):
+    # optimizer, outside the metric (train.py:47,65): the stock one and the package's single-launch one, and the
+    # whole training step (forward + loss + backward + optimizer) replayed from one hipGraph
+    def time_opt(opt):
+        step()
         opt.step()
-    torch.cuda.synchronize()
-    adam_ms = (time.perf_counter() - t1) / 20 * 1e3
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            opt.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t1) / 20 * 1e3
+
+    adam_ms = time_opt(torch.optim.Adam(net.parameters(), lr=0.002))
+    fused_opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.002)
+    fused_adam_ms = time_opt(fused_opt)
+    train_step_ms = None
+    if launch_mode.startswith("hipgraph") and (not collective or reduce_in_graph):
+        try:
+            def train_step():
+                out = step()
+                fused_opt.step()
+                return out
+            tgraph, _ = capture(train_step)
+            for _ in range(args.warmup):
+                tgraph.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                tgraph.replay()
+            torch.cuda.synchronize()
+            train_step_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        except Exception as e:
+            log(f"training-step capture failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if collective:
@@ -333,6 +358,8 @@ def main():
                                  "chain on 64 of 256 CUs (one batch row per CU), see DESIGN.md"},
             "kernels_us": kern,
             "adam_ms": round(adam_ms, 4),
+            "fused_adam_ms": round(fused_adam_ms, 4),
+            "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
             "loss": round(float(loss.item()), 6),
         }
         if world == 1 and not args.no_cpu_baseline:

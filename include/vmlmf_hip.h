@@ -128,6 +128,34 @@ int vmlmf_ce_backward(int B, int C, const float *logits, const int64_t *target, 
                       const float *lse, const float *nvalid, const float *dloss, float *dlogits, void *stream);
 
 /*
+ * Optimizer steps of the reference's two training loops, one launch over every parameter tensor.
+ * vmlmf_tensor_list carries up to VMLMF_MAX_TENSORS (param, grad, numel, state_offset, step_index) entries; larger
+ * models are stepped in several calls.  All tensors fp32, dense.
+ *   vmlmf_adam_step      torch.optim.Adam(params, lr) semantics (V/src/train_test/train.py:47,65; betas, eps,
+ *                        L2 weight_decay as in torch, no amsgrad).  exp_avg / exp_avg_sq are flat device buffers,
+ *                        entry i owns [state_offset[i], state_offset[i] + numel[i]).  `steps` is a device array
+ *                        of fp32 step counts (torch counts per parameter); the call increments
+ *                        steps[step_index[i]] of every listed tensor first, so it also works inside a hipGraph.
+ *   vmlmf_sgd_clip_step  clip_grad_norm_(params, max_norm) followed by param -= lr * grad
+ *                        (V/src/train_test/lm_test.py:203-209).  The gradients are scaled in place, the total
+ *                        norm before clipping is left in `norm` (device scalar); max_norm <= 0 skips clipping.
+ *                        `scratch`: VMLMF_MAX_TENSORS * 64 floats.
+ */
+#define VMLMF_MAX_TENSORS 48
+typedef struct vmlmf_tensor_list {
+  void *param[VMLMF_MAX_TENSORS];
+  const void *grad[VMLMF_MAX_TENSORS];
+  int64_t numel[VMLMF_MAX_TENSORS];
+  int64_t state_offset[VMLMF_MAX_TENSORS];
+  int32_t step_index[VMLMF_MAX_TENSORS];
+  int32_t count;
+} vmlmf_tensor_list;
+int vmlmf_adam_step(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp_avg_sq, float *steps, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, void *stream);
+int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_norm, float *norm, float *scratch,
+                        void *stream);
+
+/*
  * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel
  * k with bit k set in `mask` is bracketed by a HIP event pair recorded on the SAME stream the kernel is
  * launched on (mask 0 = off, 0xff = all).  vmlmf_profile_read()

@@ -183,3 +183,52 @@ def test_cross_entropy_dispatch_leaves_other_cases_to_the_library():
     z = torch.randn(4, 3, 5).cuda()            # (N, C, d) form: not the classifier case
     t = torch.randint(0, 3, (4, 5)).cuda()
     assert torch.allclose(vmlmf_amd.cross_entropy(z, t), torch.nn.functional.cross_entropy(z, t))
+
+
+@pytest.mark.parametrize("wd", [0.0, 0.01])
+def test_fused_adam_matches_torch_adam(wd):
+    """vmlmf_amd.optim.Adam against torch.optim.Adam (the reference's optimizer, train.py:47) over 6 steps,
+    including a parameter that never gets a gradient (Net.cell) and one that gets it late."""
+    import vmlmf_amd
+    g = torch.Generator().manual_seed(11)
+    shapes = [(9, 16), (720, 16), (1, 180), (720,), (18, 180), (5,)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    o1 = vmlmf_amd.optim.Adam(mine, lr=2e-3, weight_decay=wd)
+    o2 = torch.optim.Adam(ref, lr=2e-3, weight_decay=wd)
+    for it in range(6):
+        for k, (a, b) in enumerate(zip(mine, ref)):
+            if k == 5 or (k == 4 and it < 2):       # never / late
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(*a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        o1.step()
+        o2.step()
+    for a, b in zip(mine, ref):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    assert float(o1.state[mine[0]]["step"]) == 6.0
+    sd = o1.state_dict()                        # same structure as the stock optimizer's
+    assert set(sd["param_groups"][0]) == set(o2.state_dict()["param_groups"][0]) - {
+        "amsgrad", "maximize", "foreach", "capturable", "differentiable", "fused", "decoupled_weight_decay"}
+
+
+def test_clip_sgd_step_matches_the_lm_loop():
+    """clip_grad_norm_ + `param -= lr * grad` (lm_test.py:203-209), clipping active and inactive."""
+    import vmlmf_amd
+    g = torch.Generator().manual_seed(3)
+    for max_norm, scale in ((0.25, 1.0), (1e3, 1.0)):
+        mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in [(650, 32), (2600,), (1, 650)]]
+        ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+        for a, b in zip(mine, ref):
+            gr = scale * torch.randn(*a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+        norm = vmlmf_amd.optim.clip_sgd_step(mine, lr=0.5, max_norm=max_norm)
+        with torch.no_grad():
+            rnorm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+            for p in ref:
+                p -= 0.5 * p.grad
+        assert abs(float(norm) - float(rnorm)) <= 1e-5 * float(rnorm)
+        for a, b in zip(mine, ref):
+            assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+            assert float((a.grad - b.grad).abs().max()) <= 2e-6 * max(1.0, float(b.grad.abs().max()))

@@ -78,3 +78,21 @@ def test_baseline_cell_still_runs_inside_mylstm_on_cpu():
     rnn = MyLSTM(5, hidden_layer_sizes=[8, 8], w_rank=3, u_ranks=[3], cell=MyLSTMCell)
     y, hc = rnn(torch.randn(2, 4, 5))
     assert y.shape == (2, 4, 8) and hc.shape == (2, 16)
+
+
+def test_widened_rows_have_no_cpu_path_either():
+    """SURVEY section 8f rows (classifier head, loss, optimizers): stock ops where they are not the product
+    (head / loss dispatch), a loud error where they are (optimizers never touch the CPU)."""
+    import pytest
+    import vmlmf_amd
+    z = torch.randn(4, 5, requires_grad=True)
+    t = torch.tensor([0, 1, 2, 3])
+    assert torch.allclose(vmlmf_amd.cross_entropy(z, t), torch.nn.functional.cross_entropy(z, t))
+    w, b = torch.randn(3, 5), torch.randn(3)
+    assert torch.allclose(vmlmf_amd.head_linear(z, w, b), torch.nn.functional.linear(z, w, b))
+    p = torch.nn.Parameter(torch.randn(3))
+    p.grad = torch.randn(3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vmlmf_amd.optim.Adam([p]).step()
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        vmlmf_amd.optim.clip_sgd_step([p], lr=0.1, max_norm=1.0)

@@ -7,6 +7,7 @@ MI355X (gfx950), behind the reference's own nn.Module API.
 from .cells import MyVMLMFCell, MyVMLMFCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
 from .lm import MyVMLSTM, MyVMLSTMGroup
 from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss
+from . import optim
 
-__all__ = ["head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
+__all__ = ["optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
            "vmlmf_sequence"]

@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 MAX_G = 2
 NKERNELS = 12
 HEAD_MAX_CLASSES = 32
+MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP = 1, 2, 3, 4
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
 
@@ -40,6 +41,12 @@ class Sizes(ctypes.Structure):
                 ("workgroups", ctypes.c_int32), ("kx", ctypes.c_int32), ("kh", ctypes.c_int32)]
 
 
+class TensorList(ctypes.Structure):
+    _fields_ = [("param", ctypes.c_void_p * MAX_TENSORS), ("grad", ctypes.c_void_p * MAX_TENSORS),
+                ("numel", ctypes.c_int64 * MAX_TENSORS), ("state_offset", ctypes.c_int64 * MAX_TENSORS),
+                ("step_index", ctypes.c_int32 * MAX_TENSORS), ("count", ctypes.c_int32)]
+
+
 # every symbol include/vmlmf_hip.h declares: (restype, argtypes)
 _vp, _sz, _i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
 SYMBOLS = {
@@ -55,6 +62,9 @@ SYMBOLS = {
     "vmlmf_head_backward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_ce_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "vmlmf_ce_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                             ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "vmlmf_profile_enable": (_i, [_i]),
     "vmlmf_profile_read": (_i, [_fp, ctypes.POINTER(ctypes.c_int32), _i]),
     "vmlmf_kernel_name": (ctypes.c_char_p, [_i]),

@@ -1,0 +1,160 @@
+// Optimizer steps of the reference's two training loops as one launch over every parameter tensor (gfx950):
+//   Adam            torch.optim.Adam(model.parameters(), lr)  V/src/train_test/train.py:47,65
+//   clip + SGD      clip_grad_norm_ then  param -= lr * grad   V/src/train_test/lm_test.py:203-209
+// The models have 10-20 small tensors (113 K parameters at the headline shape): the stock optimizer is pure
+// launch / dispatcher latency (2 ms per step against 0.24 ms for forward + backward), the kernels here are
+// bandwidth-trivial.  Pointers travel in the kernel-argument segment (no device-side table to maintain).
+// SURVEY.md section 8f ("next" row).
+#include <hip/hip_runtime.h>
+
+#include "../../include/vmlmf_hip.h"
+
+namespace {
+
+struct TensorList {
+  float* p[VMLMF_MAX_TENSORS];
+  const float* g[VMLMF_MAX_TENSORS];
+  long long n[VMLMF_MAX_TENSORS];
+  long long off[VMLMF_MAX_TENSORS];   // offset of the tensor's optimizer state inside the flat state buffers
+  int sidx[VMLMF_MAX_TENSORS];        // which step counter is the tensor's
+};
+
+// torch.optim.Adam counts steps per parameter (one that receives its first gradient late starts at 1)
+__global__ void tick_kernel(TensorList t, int count, float* steps) {
+  if ((int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
+}
+
+// Same operation order as torch.optim.Adam's reference implementation (lerp for the first moment, mul + addcmul
+// for the second, sqrt / sqrt(bias_correction2) + eps, addcdiv), so that results agree to rounding.
+__global__ __launch_bounds__(256) void adam_kernel(TensorList t, float* __restrict__ m, float* __restrict__ v,
+                                                   const float* __restrict__ step, float lr, float b1, float b2,
+                                                   float eps, float wd) {
+  const int ti = blockIdx.y;
+  const long long n = t.n[ti];
+  float* __restrict__ p = t.p[ti];
+  const float* __restrict__ g = t.g[ti];
+  float* __restrict__ mt = m + t.off[ti];
+  float* __restrict__ vt = v + t.off[ti];
+  const float s = step[t.sidx[ti]];
+  const float bc1 = 1.f - powf(b1, s), bc2 = 1.f - powf(b2, s);
+  const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float gi = g[i];
+    const float pi = p[i];
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = mt[i], vi = vt[i];
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    mt[i] = mi;
+    vt[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+// sum of squares of every gradient: per-workgroup partials (fixed order), then one workgroup finishes
+__global__ __launch_bounds__(256) void sqsum_kernel(TensorList t, float* __restrict__ partial) {
+  __shared__ float red[256];
+  const int ti = blockIdx.y;
+  const long long n = t.n[ti];
+  const float* __restrict__ g = t.g[ti];
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s = fmaf(g[i], g[i], s);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void norm_kernel(const float* __restrict__ partial, int count, float* __restrict__ norm) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < count; i += 256) s += partial[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) norm[0] = sqrtf(red[0]);
+}
+
+// clip_grad_norm_ semantics: clip_coef = max_norm / (norm + 1e-6), clamped to 1; the gradients are scaled in
+// place (the reference's loop reads param.grad afterwards) and the parameters take the plain SGD step.
+__global__ __launch_bounds__(256) void sgd_clip_kernel(TensorList t, const float* __restrict__ norm, float lr,
+                                                       float max_norm) {
+  const int ti = blockIdx.y;
+  const long long n = t.n[ti];
+  float* __restrict__ p = t.p[ti];
+  float* __restrict__ g = const_cast<float*>(t.g[ti]);
+  float coef = 1.f;
+  if (max_norm > 0.f) {
+    coef = max_norm / (norm[0] + 1e-6f);
+    coef = coef < 1.f ? coef : 1.f;
+  }
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    g[i] = gi;
+    p[i] = p[i] - lr * gi;
+  }
+}
+
+int fill(const vmlmf_tensor_list* in, TensorList* t, long long* maxn) {
+  if (in == nullptr || in->count < 1 || in->count > VMLMF_MAX_TENSORS) return VMLMF_E_BADARG;
+  *maxn = 0;
+  for (int i = 0; i < VMLMF_MAX_TENSORS; ++i) {
+    const bool live = i < in->count;
+    if (live && (in->param[i] == nullptr || in->grad[i] == nullptr || in->numel[i] < 0)) return VMLMF_E_BADARG;
+    t->p[i] = live ? (float*)in->param[i] : nullptr;
+    t->g[i] = live ? (const float*)in->grad[i] : nullptr;
+    t->n[i] = live ? in->numel[i] : 0;
+    t->off[i] = live ? in->state_offset[i] : 0;
+    t->sidx[i] = live ? in->step_index[i] : 0;
+    if (live && in->numel[i] > *maxn) *maxn = in->numel[i];
+  }
+  return 0;
+}
+
+unsigned blocks_for(long long maxn) {
+  long long b = (maxn + 1023) / 1024;   // four elements per thread before the grid-stride loop wraps
+  return (unsigned)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
+}
+
+}  // namespace
+
+extern "C" {
+
+int vmlmf_adam_step(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  TensorList t;
+  long long maxn = 0;
+  const int rc = fill(tensors, &t, &maxn);
+  if (rc != 0) return rc;
+  if (exp_avg == nullptr || exp_avg_sq == nullptr || steps == nullptr) return VMLMF_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(maxn), tensors->count), dim3(256), 0, s, t, exp_avg, exp_avg_sq,
+                     steps, lr, beta1, beta2, eps, weight_decay);
+  return (int)hipGetLastError();
+}
+
+int vmlmf_sgd_clip_step(const vmlmf_tensor_list* tensors, float lr, float max_norm, float* norm, float* scratch,
+                        void* stream) {
+  TensorList t;
+  long long maxn = 0;
+  const int rc = fill(tensors, &t, &maxn);
+  if (rc != 0) return rc;
+  if (norm == nullptr || scratch == nullptr) return VMLMF_E_BADARG;
+  hipStream_t s = (hipStream_t)stream;
+  unsigned nb = blocks_for(maxn);
+  if (nb > 64) nb = 64;   // scratch holds VMLMF_MAX_TENSORS * 64 partial sums
+  hipLaunchKernelGGL(sqsum_kernel, dim3(nb, tensors->count), dim3(256), 0, s, t, scratch);
+  hipLaunchKernelGGL(norm_kernel, dim3(1), dim3(256), 0, s, scratch, (int)(nb * tensors->count), norm);
+  hipLaunchKernelGGL(sgd_clip_kernel, dim3(blocks_for(maxn), tensors->count), dim3(256), 0, s, t, norm, lr, max_norm);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"
