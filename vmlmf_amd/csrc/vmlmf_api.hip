@@ -117,7 +117,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // backward, parallel part: dqx_dx works on RC rows per workgroup (groups of 8 per barrier); wgrad keeps
   // register accumulators over RC2 rows per chunk, 5 parts per chunk
   const int TB = g.T * g.B;
-  int rc = ((TB + 255) / 256 + 7) / 8 * 8;
+  // (measured at the headline shape: ~1024 dqx_dx workgroups 12.9 us, 512 14.0, 256 16.7; 64 wgrad chunks:
+  // 128 chunks gain 2 us there and lose them again in reduce_cg_kernel, 32 chunks cost 10 us)
+  int rc = ((TB + 1023) / 1024 + 7) / 8 * 8;
   if (rc < 8) rc = 8;
   g.RC = rc;
   g.nblk = (TB + rc - 1) / rc;

@@ -150,7 +150,7 @@ int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipSt
 // ---------------------------------------------------------------------------------------------------
 // xproj: the non-recurrent half of the gate pre-activations for every (t,b) row
 // ---------------------------------------------------------------------------------------------------
-constexpr int XR = 16;  // rows per workgroup (32 was measured slower: too few workgroups to cover the gx write latency)
+constexpr int XR = 8;  // rows per workgroup (measured at the headline shape: 4 -> 19.1 us, 8 -> 15.5, 16 -> 16.7, 32 slower still)
 
 template <int KX>
 __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restrict__ x,
