@@ -54,6 +54,20 @@ class FlatGradAllReduce:
                 out.append((None, gs))
         return out
 
+    def _all_reduce(self, tensors, op, backend):
+        """One collective launch for all `tensors`: on RCCL several all-reduces issued under the coalescing manager
+        become one group call (the exchange is latency-bound: two launches would cost twice one)."""
+        if len(tensors) > 1 and backend == "nccl" and hasattr(dist, "_coalescing_manager"):
+            try:
+                with dist._coalescing_manager(group=self.group, device=tensors[0].device, async_ops=False):
+                    for t in tensors:
+                        dist.all_reduce(t, op=op, group=self.group)
+                return
+            except (TypeError, RuntimeError):   # private API moved: plain back-to-back collectives
+                pass
+        for t in tensors:
+            dist.all_reduce(t, op=op, group=self.group)
+
     def reduce(self):
         """Call after backward().  In-place on the parameters' .grad tensors: gradients that already tile a flat
         allocation are reduced where they are (no staging copies); the rest go through the staging buffer."""
@@ -65,14 +79,16 @@ class FlatGradAllReduce:
         native_avg = self.op == "avg" and backend == "nccl"      # RCCL averages in the collective itself
         op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
         scale = None if (native_avg or self.op == "sum") else 1.0 / world
-        loose = []
+        loose, flats = [], []
         for flat, gs in self._spans([p.grad for p in params]):
             if flat is None:
                 loose += gs
-                continue
-            if world > 1 or self.always:
-                dist.all_reduce(flat, op=op, group=self.group)
-                if scale is not None:
+            else:
+                flats.append(flat)
+        if flats and (world > 1 or self.always):
+            self._all_reduce(flats, op, backend)
+            if scale is not None:
+                for flat in flats:
                     flat.mul_(scale)
         if loose:
             if self.flat is None or self.flat.numel() != sum(g.numel() for g in loose):
@@ -83,7 +99,7 @@ class FlatGradAllReduce:
                 o += g.numel()
             torch._foreach_copy_(views, loose)
             if world > 1 or self.always:
-                dist.all_reduce(self.flat, op=op, group=self.group)
+                self._all_reduce([self.flat], op, backend)
                 if scale is not None:
                     self.flat.mul_(scale)
             torch._foreach_copy_(loose, views)
