@@ -267,7 +267,7 @@ def main():
             dt = dt_graph
 
     # untimed extra pass: every internal kernel bracketed, for the breakdown
-    lib.vmlmf_profile_enable(0xff)
+    lib.vmlmf_profile_enable((1 << _lib.NKERNELS) - 1)
     for _ in range(10):
         step()
     torch.cuda.synchronize()

@@ -10,7 +10,7 @@ def main(db, out, title):
         f.write(f"# {title}\n# source: rocprofv3 --kernel-trace --stats (view top_kernels); durations in microseconds\n")
         f.write("name,calls,total_us,avg_us,percent\n")
         for name, calls, tot, avg, pct in rows:
-            short = name.split("(")[0].replace("void ", "")
+            short = name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "")
             if short.startswith("Cijk_"):
                 short = short[:40] + "...(rocBLAS/hipBLASLt, Net.lin)"
             if len(short) > 110:
