@@ -85,6 +85,13 @@ CASES = [
     (O.V3, 6, 5, 24, 24, 4, [6], True, True),
     (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),     # batch != 40 (the reference cannot run this)
     (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
+    # 257..512 thread slots: the 8-wave instantiations of the persistent kernels
+    (O.V1, 4, 5, 20, 300, 8, [16], False, True),     # 5 compute waves
+    (O.V1, 3, 3, 9, 500, 16, [32], False, False),    # 8 compute waves, rank 32
+    (O.V1, 260, 2, 9, 300, 8, [8], False, False),    # ... with two rows per workgroup
+    (O.V2, 3, 4, 12, 280, 8, [8, 16], False, True),  # two groups of three waves (384 slots), rank 8 + 16
+    (O.V3, 5, 4, 330, 330, 8, [24], True, True),     # LM layer, 6 waves
+    (O.V4, 6, 3, 264, 264, 6, [8, 8], True, True),   # flat layout on 2 x 3 waves
     # shapes that do not fit the register-resident kernels -> step-wise path (vmlmf_generic.hip)
     (O.V1, 5, 4, 12, 40, 6, [40], False, True),      # rank 40 > 32
     (O.V1, 3, 3, 20, 600, 8, [8], False, False),     # 640 thread slots > 512
