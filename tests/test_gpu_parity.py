@@ -185,3 +185,18 @@ def test_linearity_of_backward_in_upstream_gradient():
     for k in g1["G"]:
         assert_grad(g1["G"][k] + 2 * g2["G"][k], g3["G"][k], "lin." + k, rel=2e-4)
     assert_grad(g1["dx"] + 2 * g2["dx"], g3["dx"], "lin.dx", rel=2e-4)
+
+
+def test_dy_is_never_read_past_its_end():
+    """Pad thread slots (H = 180 on 192 slots) used to index dy with their slot number: for the last batch row of
+    the last timestep that is up to 12 floats past the tensor.  B*T*H*4 = 45 * 2 MiB here, so the allocation
+    has no slack behind it and the old kernel faulted."""
+    from vmlmf_amd import MyLSTM, MyVMLMFCell
+    torch.manual_seed(0)
+    rnn = MyLSTM(9, hidden_layer_sizes=[180], batch_first=True, w_rank=16, u_ranks=[16], cell=MyVMLMFCell).cuda()
+    x = torch.randn(1024, 128, 9, device="cuda")
+    y, _ = rnn(x)
+    assert y.numel() * 4 % (2 << 20) == 0
+    y[:, -1].sum().backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in rnn.parameters())

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -28,11 +29,17 @@ struct Prof {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[NKERN];
 } g_prof;
 
+// VMLMF_DEBUG_SYNC=1: synchronise after every internal launch and name it on stderr (finds the kernel behind an
+// asynchronous GPU fault; never set in production: it serialises everything and breaks hipGraph capture)
+const bool g_debug_sync = getenv("VMLMF_DEBUG_SYNC") != nullptr;
+const char* kernel_label(int k);
+
 struct Scope {
   int k;
   hipStream_t s;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   Scope(int which, hipStream_t st) : k(which), s(st) {
+    if (g_debug_sync) fprintf(stderr, "[vmlmf] launching %s\n", kernel_label(which));
     if ((g_prof.mask >> which) & 1u) {
       hipEventCreate(&e0);
       hipEventCreate(&e1);
@@ -40,6 +47,10 @@ struct Scope {
     }
   }
   ~Scope() {
+    if (g_debug_sync) {
+      const hipError_t e = hipStreamSynchronize(s);
+      fprintf(stderr, "[vmlmf] %s done: %s\n", kernel_label(k), hipGetErrorString(e));
+    }
     if (e0 != nullptr) {
       hipEventRecord(e1, s);
       std::lock_guard<std::mutex> lk(g_prof.mu);
@@ -108,8 +119,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // register-resident persistent kernels need <= 32 ranks per unit and <= 512 thread slots; larger layers
   // (e.g. H = 650, ranks [32,32]) run the step-wise path of vmlmf_generic.hip
   g.generic = (g.KH > 32 || g.NT > 512) ? 1 : 0;
-  // rows per workgroup: one row per CU while the batch fits the chip once, then two
-  g.R = (g.B <= 256 || g.flat || g.generic) ? 1 : 2;
+  // rows per workgroup: one while at most two workgroups share a CU (measured at H = 180, T = 128: B = 512 takes
+  // 0.506 ms with one row per workgroup against 0.562 ms with two; at B = 768 the two are equal), then two
+  g.R = (g.B <= 512 || g.flat || g.generic) ? 1 : 2;
   g.nwg = (g.B + g.R - 1) / g.R;
   g.Bp = g.nwg * g.R;
   if ((long long)g.T * g.Bp * g.NT * 4 >= (1LL << 31) || (long long)g.T * g.B * g.H >= (1LL << 31))
@@ -436,10 +448,16 @@ int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
 }
 
 const char* vmlmf_kernel_name(int k) {
+  return kernel_label(k);
+}
+
+}  // extern "C"
+
+namespace {
+const char* kernel_label(int k) {
   static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
                                      "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel",
                                      "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel"};
   return (k >= 0 && k < NKERN) ? names[k] : "";
 }
-
-}  // extern "C"
+}  // namespace
