@@ -155,9 +155,9 @@ struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
   long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
   // forward workspace  : PACK (inference only) | gx
-  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_total;
+  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P) {
@@ -181,6 +181,7 @@ Layout make_layout(const VGeo& g, const VPack& P) {
     L.f_P = o, o += align64(gen * BN * 4);
     L.f_ccar = o, o += align64(gen * BN);
     L.f_zeros = o, o += align64(gen * (long long)g.B * g.H);
+    L.f_part = o, o += align64(gen * (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64));
   }
   L.f_total = o;
   o = 0;
@@ -195,6 +196,7 @@ Layout make_layout(const VGeo& g, const VPack& P) {
     L.b_dHrec = o, o += align64(gen * (long long)g.B * g.H);
     L.b_ehterm = o, o += align64(gen * BN);
     L.b_dcar = o, o += align64(gen * BN);
+    L.b_part = o, o += align64(gen * (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64));
   }
   L.b_total = o;
   return L;
@@ -284,6 +286,8 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     w.zeros = ws + L.f_zeros, w.y = y, w.hT = hT, w.cT = cT;
     w.gates = g.training ? rs + L.r_gates : nullptr, w.cs = g.training ? rs + L.r_cs : nullptr;
     w.Qs = g.training ? rs + L.r_Qs : nullptr, w.Qtmp = ws + L.f_Qtmp, w.P = ws + L.f_P, w.ccar = ws + L.f_ccar;
+    w.part = ws + L.f_part, w.part_cap = (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64);
+    w.ticket = reinterpret_cast<int*>(pack + P.TKT), w.ticket_cap = VG_GEMM_TICKETS;
     if (h0 == nullptr) {
       rc = (int)hipMemsetAsync(ws + L.f_zeros, 0, sizeof(float) * (size_t)g.B * g.H, s);
       if (rc != 0) return hip_fail(rc, "memset");
@@ -333,6 +337,8 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
     w.UXP = pack + P.UXP, w.EXT = pack + P.EXT;
     w.dpre = ws + L.b_dpre, w.dQs = ws + L.b_dQs, w.dHrec = ws + L.b_dHrec, w.ehterm = ws + L.b_ehterm;
     w.dcar = ws + L.b_dcar, w.dh0 = dh0, w.dc0 = dc0, w.dqx = ws + L.b_dqx, w.dx = dx;
+    w.part = ws + L.b_part, w.part_cap = (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64);
+    w.ticket = reinterpret_cast<int*>(const_cast<float*>(pack + P.TKT)), w.ticket_cap = VG_GEMM_TICKETS;
     {
       Scope sc(3, s);
       if ((rc = hip_fail(generic_backward(g, w, s), "generic_backward")) != 0) return rc;

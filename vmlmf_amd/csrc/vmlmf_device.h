@@ -105,6 +105,16 @@ __device__ __forceinline__ const gf32* sel_g(bool c, const float* a, const float
 __device__ __forceinline__ void st4g(gf32* p, float4 v) {
   *reinterpret_cast<gf32x4*>(p) = f32x4{v.x, v.y, v.z, v.w};
 }
+// Store written through to agent scope (sc1): visible to workgroups on every XCD once vmcnt has counted it,
+// without the whole-L2 write-back of a release fence (split-K partials of the step-wise GEMMs).  Inline asm: the
+// compiler's waitcnt pass does not see it, the caller waits on vmcnt itself.
+__device__ __forceinline__ void st4g_agent(gf32* p, float4 v) {
+  const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+}
+__device__ __forceinline__ void st1g_agent(gf32* p, float v) {
+  asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
 // LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base + lane*SIZE).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gl_cvoid_t;

@@ -3,8 +3,8 @@
 //
 // The persistent kernels keep U_h/V_h in registers for all T steps; when that is impossible the recurrence is
 // run one timestep at a time, cuDNN-style, with the batch as the GEMM M dimension:
-//     Q_t   = H_{t-1} Ud            (B x H)(H x G*KH)         gemm_nn_kernel  (fp32 MFMA 32x32x2)
-//     P_t   = Q_t Vd                (B x G*KH)(G*KH x 4*slots) gemm_nn_kernel
+//     Q_t   = H_{t-1} Ud            (B x H)(H x G*KH)         gemm_tile_kernel (fp32 MFMA 32x32x2)
+//     P_t   = Q_t Vd                (B x G*KH)(G*KH x 4*slots) gemm_tile_kernel
 //     gates, c_t, h_t               elementwise                gates_fwd_kernel
 // and in reverse
 //     dpre_t from the tape          elementwise                gates_bwd_kernel
@@ -18,6 +18,16 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// C[M x N] = A[M x K] B[K x N], row-major, any sizes (masked).  64 x 64 tile of C per workgroup of four waves
+// (each a 32 x 32 sub-tile on v_mfma_f32_32x32x2_f32).  K is staged through LDS 128 at a time: every thread
+// issues all of its loads of a stage before the first LDS write, so a stage costs one memory latency, and the 64
+// MFMAs of the stage then run back to back (the products of the step-wise path have K = 128 or are split to
+// about that).  Skinny products with a long K (Q = H Ud, dQ = dpre VdT: 8 tiles, K = 650 / 3072) split K over
+// gridDim.y workgroups: each writes its partial tile (write-through), takes a ticket, and the last one to arrive
+// sums the partials in index order (deterministic whatever the arrival order) and resets the ticket.
+constexpr int GBM = 64, GBN = 64, GBK = 128, GPAD = 4;
+constexpr size_t GEMM_LDS = sizeof(float) * 2 * GBK * (GBM + GPAD);
+
 struct GemmArgs {
   const float* A;
   long long lda;
@@ -26,102 +36,145 @@ struct GemmArgs {
   float* C;
   long long ldc;
   int M, N, K;
+  float* part;   // [gridDim.y][tiles][64 * 64] partial tiles in accumulator order (split K only)
+  int* ticket;   // one per tile, zero on entry and on exit
 };
 
-// C[M x N] = A[M x K] B[K x N], row-major, any sizes (masked).  One 32x32 tile of C per workgroup of SPLIT
-// waves: the waves split K between them (skinny products such as dQ = dpre VdT have few tiles but a long K)
-// and their partial tiles are summed through LDS in wave order (deterministic).
-// Lane l = (lk = l>>5, li = l&31) supplies A[row li][k] and B[k][col li]; within an 8-wide k block MFMA step s
-// contracts k = kb + 4*lk + s, so a lane reads 4 consecutive floats of its A row per block.
-template <int SPLIT, bool VEC>
-__global__ void __launch_bounds__(64 * SPLIT) gemm_nn_kernel(GemmArgs a) {
-  __shared__ float red[SPLIT > 1 ? SPLIT * 1024 : 1];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int tiles_n = (a.N + 31) / 32;
-  const int tile = blockIdx.x;
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-  const int li = lane & 31, lk = lane >> 5;
-  const int row = tm * 32 + li, col = tn * 32 + li;
-  const bool rok = row < a.M, cok = col < a.N;
-  const float* Ar = a.A + (long long)(rok ? row : 0) * a.lda;
-  const float* Bc = a.B + (cok ? col : 0);
-  // this wave's K range, in multiples of 16
-  const int kper = ((a.K + SPLIT - 1) / SPLIT + 15) / 16 * 16;
-  const int k0 = wave * kper, k1 = k0 + kper < a.K ? k0 + kper : a.K;
+__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
+  extern __shared__ float4 gsm4[];
+  float(*As)[GBM + GPAD] = reinterpret_cast<float(*)[GBM + GPAD]>(gsm4);               // [k][m]
+  float(*Bs)[GBN + GPAD] = reinterpret_cast<float(*)[GBN + GPAD]>(As + GBK);            // [k][n]
+  __shared__ int last_flag;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  const int tiles_n = (a.N + GBN - 1) / GBN;
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * GBM, n0 = tn * GBN;
+  const int nz = gridDim.y, kz = blockIdx.y;
+  const int kper = ((a.K + nz - 1) / nz + 15) / 16 * 16;
+  const int k0 = kz * kper, k1 = k0 + kper < a.K ? k0 + kper : a.K;
+  // staging roles.  A tile 64 rows x 128 k: thread -> (row, k = j + 4 i), four lanes cover 16 contiguous bytes of
+  // a row and their LDS writes land in four different banks.  B tile 128 k x 64 n: thread -> (k = kk + 16 i, 4 n).
+  const int ar = tid >> 2, aj = tid & 3;
+  const int bk = tid >> 4, bn = (tid & 15) * 4;
+  const bool arow_ok = m0 + ar < a.M;
+  const float* Ap = a.A + (long long)(arow_ok ? m0 + ar : 0) * a.lda;
+  const bool bvec = (a.ldb % 4 == 0) && ((reinterpret_cast<uintptr_t>(a.B) & 15) == 0) && (n0 + bn + 3 < a.N);
+
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-  constexpr int UB = 4;  // 8-wide k blocks per batch of loads (all loads of a batch are issued together)
-  for (int kb = k0; kb < k1; kb += 8 * UB) {
-    float av[UB][4], bv[UB][4];
+  for (int kb = k0; kb < k1; kb += GBK) {
+    float ra[GBK / 4];
+    float4 rb[GBK / 16];
 #pragma unroll
-    for (int u = 0; u < UB; ++u) {
-      if (VEC) {   // rows of A are 16-byte aligned and K % 4 == 0: one 16-byte load per lane and block
-        const int k = kb + 8 * u + 4 * lk;
-        const bool kok = k < k1;
-        const float4 x = ld4(Ar + (kok ? k : 0));
-        const float m = (kok && rok) ? 1.f : 0.f;
-        av[u][0] = m * x.x, av[u][1] = m * x.y, av[u][2] = m * x.z, av[u][3] = m * x.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const int k = kb + 8 * u + 4 * lk + s;
-        const bool kok = k < k1;
-        const int kc = kok ? k : 0;
-        if (!VEC) {
-          const float x = Ar[kc];
-          av[u][s] = (kok && rok) ? x : 0.f;
-        }
-        const float y = Bc[(long long)kc * a.ldb];
-        bv[u][s] = (kok && cok) ? y : 0.f;
-      }
+    for (int i = 0; i < GBK / 4; ++i) {
+      const int k = kb + aj + 4 * i;
+      ra[i] = (arow_ok && k < k1) ? Ap[k] : 0.f;
     }
 #pragma unroll
-    for (int u = 0; u < UB; ++u)
+    for (int i = 0; i < GBK / 16; ++i) {
+      const int k = kb + bk + 16 * i;
+      rb[i] = f4zero();
+      if (k < k1) {
+        const float* Bp = a.B + (long long)k * a.ldb + n0 + bn;
+        if (bvec)
+          rb[i] = ld4(Bp);
+        else
+          rb[i] = make_float4(n0 + bn + 0 < a.N ? Bp[0] : 0.f, n0 + bn + 1 < a.N ? Bp[1] : 0.f,
+                              n0 + bn + 2 < a.N ? Bp[2] : 0.f, n0 + bn + 3 < a.N ? Bp[3] : 0.f);
+      }
+    }
+    if (kb != k0) __syncthreads();   // the previous stage's MFMAs have read LDS
 #pragma unroll
-      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][s], bv[u][s], acc, 0, 0, 0);
-  }
-  if (SPLIT > 1) {
+    for (int i = 0; i < GBK / 4; ++i) As[aj + 4 * i][ar] = ra[i];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave * 1024 + r * 64 + lane] = acc[r];
+    for (int i = 0; i < GBK / 16; ++i) *reinterpret_cast<float4*>(&Bs[bk + 16 * i][bn]) = rb[i];
     __syncthreads();
-    if (wave != 0) return;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float sum = red[r * 64 + lane];
-      for (int w = 1; w < SPLIT; ++w) sum += red[w * 1024 + r * 64 + lane];
-      acc[r] = sum;
+    const int ks = k1 - kb < GBK ? k1 - kb : GBK;   // multiple of 16 except for the tail of K (zero-filled)
+    const int steps = (ks + 1) / 2;
+#pragma unroll 8
+    for (int s = 0; s < steps; ++s) {
+      const float av = As[2 * s + lk][32 * wm + li];
+      const float bv = Bs[2 * s + lk][32 * wn + li];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
     }
+  }
+  const int col = n0 + 32 * wn + li;
+  const bool cok = col < a.N;
+  if (nz == 1) {
+    if (cok) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int i = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (i < a.M) a.C[(long long)i * a.ldc + col] = acc[r];
+      }
+    }
+    return;
+  }
+  // Split K.  The partial tile goes out in accumulator order (thread-major: 16 consecutive floats per thread, so
+  // both the stores here and the loads of the summing workgroup are full 64-byte accesses), written through to
+  // agent scope so that a workgroup on another XCD sees it once vmcnt has counted the stores; then a ticket.
+  const size_t tile_elems = (size_t)GBM * GBN;
+  float* mine = a.part + ((size_t)kz * gridDim.x + blockIdx.x) * tile_elems + (size_t)tid * 16;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    st4g_agent((gf32*)(mine + 4 * q), make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]));
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(a.ticket + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = t == nz - 1;
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // last arrival: sum the nz partials in index order (agent-scope loads: the lines may never have been in this
+  // XCD's L2, but they must not be served from a stale copy either)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const float* base = a.part + (size_t)blockIdx.x * tile_elems + (size_t)tid * 16;
+#pragma unroll 4
+  for (int z = 0; z < nz; ++z) {
+    const float* src = base + (size_t)z * gridDim.x * tile_elems;
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = __hip_atomic_load(src + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += v[r];
   }
   if (cok) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int i = tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+      const int i = m0 + 32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lk;
       if (i < a.M) a.C[(long long)i * a.ldc + col] = acc[r];
     }
   }
+  if (tid == 0) __hip_atomic_store(a.ticket + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// split-K scratch of one layer call (GenericBuf::part / ticket): room for GEMM_MAX_SPLIT partial copies of the
+// largest skinny product (B x G*KH) and one ticket per tile of it
+constexpr int GEMM_MAX_SPLIT = VG_GEMM_SPLIT;
+
 static int gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                int K, hipStream_t s) {
-  GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K};
-  const int tiles = ((M + 31) / 32) * ((N + 31) / 32);
-  // few tiles and a long K: split K over up to 16 waves of the tile's workgroup
-  const bool vec = (lda % 4 == 0) && (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
-#define GEMM_GO(SP)                                                                              \
-  do {                                                                                           \
-    if (vec)                                                                                     \
-      hipLaunchKernelGGL((gemm_nn_kernel<SP, true>), dim3(tiles), dim3(64 * SP), 0, s, a);       \
-    else                                                                                         \
-      hipLaunchKernelGGL((gemm_nn_kernel<SP, false>), dim3(tiles), dim3(64 * SP), 0, s, a);      \
-  } while (0)
-  if (tiles <= 128 && K >= 256)
-    GEMM_GO(16);
-  else if (tiles <= 512 && K >= 128)
-    GEMM_GO(4);
-  else
-    GEMM_GO(1);
-#undef GEMM_GO
+                int K, float* part, long long part_cap, int* ticket, int ticket_cap, hipStream_t s) {
+  GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K, part, ticket};
+  const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+  int nz = 1;
+  if (tiles < 64 && K >= 256 && part != nullptr && tiles <= ticket_cap) {
+    nz = (K + 127) / 128;   // one 128-wide stage per workgroup where the scratch allows
+    if (nz > GEMM_MAX_SPLIT) nz = GEMM_MAX_SPLIT;
+    while (nz > 1 && (long long)nz * tiles * GBM * GBN > part_cap) --nz;
+    if (nz < 1) nz = 1;
+  }
+  static bool raised = false;
+  if (!raised) {   // 69 KB of dynamic LDS
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
+    if (e != hipSuccess) return (int)e;
+    raised = true;
+  }
+  hipLaunchKernelGGL(gemm_tile_kernel, dim3(tiles, nz), dim3(256), GEMM_LDS, s, a);
   return (int)hipGetLastError();
 }
 
@@ -253,8 +306,10 @@ int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
       A = w.zeros, lda = H;
     }
     float* Qt = w.Qs != nullptr ? w.Qs + (size_t)t * B * GK : w.Qtmp;
-    if ((rc = gemm(A, lda, w.Ud, GK, Qt, GK, B, GK, H, s)) != 0) return rc;
-    if ((rc = gemm(Qt, GK, w.Vd, (long long)NT * 4, w.P, (long long)NT * 4, B, NT * 4, GK, s)) != 0) return rc;
+    if ((rc = gemm(A, lda, w.Ud, GK, Qt, GK, B, GK, H, w.part, w.part_cap, w.ticket, w.ticket_cap, s)) != 0) return rc;
+    if ((rc = gemm(Qt, GK, w.Vd, (long long)NT * 4, w.P, (long long)NT * 4, B, NT * 4, GK, w.part, w.part_cap, w.ticket,
+                   w.ticket_cap, s)) != 0)
+      return rc;
     StepF a;
     a.gx = w.gx, a.P = w.P, a.EH = w.EH, a.h0 = w.h0, a.c0 = w.c0, a.y = w.y, a.hT = w.hT, a.cT = w.cT;
     a.gates = w.gates, a.cs = w.cs, a.ccar = w.ccar, a.t = t;
@@ -279,15 +334,18 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
     hipLaunchKernelGGL(gates_bwd_kernel, egrid, eblock, 0, s, g, a);
     if ((rc = (int)hipGetLastError()) != 0) return rc;
     float* dQt = w.dQs + (size_t)t * B * GK;
-    if ((rc = gemm(w.dpre + (size_t)t * sstride * 4, (long long)NT * 4, w.VdT, GK, dQt, GK, B, GK, NT * 4, s)) != 0)
+    if ((rc = gemm(w.dpre + (size_t)t * sstride * 4, (long long)NT * 4, w.VdT, GK, dQt, GK, B, GK, NT * 4, w.part,
+                   w.part_cap, w.ticket, w.ticket_cap, s)) != 0)
       return rc;
-    if ((rc = gemm(dQt, GK, w.UdT, H, w.dHrec, H, B, H, GK, s)) != 0) return rc;
+    if ((rc = gemm(dQt, GK, w.UdT, H, w.dHrec, H, B, H, GK, w.part, w.part_cap, w.ticket, w.ticket_cap, s)) != 0) return rc;
   }
   hipLaunchKernelGGL(carry_kernel, egrid, eblock, 0, s, g, 1, (const float*)nullptr, (const float*)nullptr, w.dHrec,
                      w.ehterm, w.dcar, w.dh0, w.dc0);
   if ((rc = (int)hipGetLastError()) != 0) return rc;
   // dqx over all rows, then dx
-  if ((rc = gemm(w.dpre, (long long)NT * 4, w.VxT, g.KX, w.dqx, g.KX, T * B, g.KX, NT * 4, s)) != 0) return rc;
+  if ((rc = gemm(w.dpre, (long long)NT * 4, w.VxT, g.KX, w.dqx, g.KX, T * B, g.KX, NT * 4, w.part, w.part_cap, w.ticket,
+                 w.ticket_cap, s)) != 0)
+    return rc;
   if (w.dx != nullptr) {
     const long long total = (long long)T * B * g.I;
     hipLaunchKernelGGL(dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT,

@@ -34,7 +34,8 @@ struct VGeo {
 // float offsets inside the PACK region (parameter images, produced by pack_kernel)
 struct VPack {
   long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
-  long long UD, VD, UDT, VDT, VXTT, total;   // dense group factors + V_x^T, step-wise path only
+  long long UD, VD, UDT, VDT, VXTT;   // dense group factors + V_x^T, step-wise path only
+  long long TKT, total;               // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
 };
 
 #ifdef __HIPCC__
@@ -42,6 +43,9 @@ struct VPack {
 #else
 #define VG_HD inline
 #endif
+
+#define VG_GEMM_TICKETS 64   // tiles a split-K GEMM of the step-wise path may have
+#define VG_GEMM_SPLIT 8     // partial copies its scratch holds
 
 VG_HD int vg_pad8(int v) { return (v + 7) / 8 * 8; }
 
@@ -68,6 +72,7 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   p.UDT = take(g.generic ? GK * g.H : 0);
   p.VDT = take(g.generic ? N4 * GK : 0);
   p.VXTT = take(g.generic ? N4 * g.KX : 0);
+  p.TKT = take(g.generic ? VG_GEMM_TICKETS : 0);
   p.total = o;
   return p;
 }

@@ -30,6 +30,11 @@ struct GenericBuf {
   // backward
   const float *dy, *dhT, *dcT, *UdT, *VdT, *VxT, *UXP, *EXT;
   float *dpre, *dQs, *dHrec, *ehterm, *dcar, *dh0, *dc0, *dqx, *dx;
+  // split-K scratch of the GEMMs: partial products and per-tile tickets (zero between launches)
+  float* part;
+  long long part_cap;
+  int* ticket;
+  int ticket_cap;
 };
 int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s);
 int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s);

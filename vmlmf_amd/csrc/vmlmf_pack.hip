@@ -118,14 +118,14 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
           j = c / g.KH; rr = c % g.KH; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
         }
-      } else {                  // VXTT[slot*4+k][r]
+      } else if (e < L.TKT) {   // VXTT[slot*4+k][r]
         const long long le = e - L.VXTT;
         if (le < (long long)N4 * g.KX) {
           const int i = (int)(le / g.KX);
           rr = (int)(le % g.KX); k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
         }
-      }
+      }                         // else TKT: the split-K tickets start at zero
       if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s
         const int sblk = (g.G == 2 && rr >= g.off1) ? 1 : 0;
         const int dest = (n / g.Hg - sblk + g.G) % g.G;
