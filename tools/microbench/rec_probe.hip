@@ -5,22 +5,24 @@
 #include <cstdlib>
 #include <vector>
 #include "vmlmf_rec_fwd.inc"
+#include "vmlmf_rec_bwd.inc"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
-template <int ABL>
-float run(const VGeo& g, const FwdArgs& a, int iters) {
+template <int ABL, bool XW = false>
+float run(const VGeo& g, const FwdArgs& a, const XwArgs& xw, int iters) {
   constexpr int KQ = 16;
-  const size_t lds = sizeof(float) * ((size_t)2 * g.NW * KQ + (size_t)FWD_NB * g.NT * 4 + (size_t)2 * g.NT * 8 + 256);
+  const size_t lds = sizeof(float) * ((size_t)2 * g.NW * KQ + (size_t)FWD_NB * g.NT * 4 + (size_t)2 * g.NT * 8 + 256 + 4 +
+                                      xwave_lds_floats());
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a, xw);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a, xw);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -28,7 +30,26 @@ float run(const VGeo& g, const FwdArgs& a, int iters) {
   return ms * 1000.f / iters;
 }
 
-int main() {
+template <int ABL>
+float run_bwd(const VGeo& g, const BwdArgs& b, int iters) {
+  const size_t lds = sizeof(float) * ((size_t)2 * g.NW * 16 + (size_t)BWD_NB * g.NT * 6 + (size_t)2 * g.NT * 4 + 256 + 4);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i)
+    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i)
+    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+int main(int argc, char**) {
   VGeo g = {};
   g.variant = 1, g.B = 64, g.T = 128, g.I = 9, g.H = 180, g.rw = 16, g.G = 1, g.Hg = 180, g.W = 3, g.NT = 192,
   g.NW = 3, g.ru0 = 16, g.off1 = 16, g.KX = 16, g.KH = 16, g.NP = 1, g.KQ = 16, g.NPX = 1, g.KQX = 16, g.R = 1,
@@ -55,8 +76,37 @@ int main() {
   a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
   a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
   a.trash = dalloc(256, 0.f);
-  printf("full                         %8.2f us\n", run<0>(g, a, 50));
-  printf("instrumented          (256)  %8.2f us\n", run<256>(g, a, 5));
+  XwArgs xw = {};
+  xw.x = dalloc((size_t)g.B * g.T * g.I, 1.0f);
+  xw.UXP = dalloc((size_t)g.I * g.KX, 0.2f);
+  xw.WXD = dalloc((size_t)4 * g.I * g.NT, 0.2f);
+  xw.BBT = dalloc((size_t)4 * g.H, 0.2f);
+  a.qxw = dalloc((size_t)g.T * g.B * g.KX, 0.f);
+  const bool xwave = argc > 1;
+  a.xwave = xwave ? 1 : 0;
+  if (xwave) {
+    printf("x-wave full                  %8.2f us\n", (run<0, true>(g, a, xw, 50)));
+    printf("x-wave, storer: no stores    %8.2f us\n", (run<1024, true>(g, a, xw, 50)));
+    printf("x-wave, storer idle          %8.2f us\n", (run<2048, true>(g, a, xw, 50)));
+    printf("x-wave without its pk FMAs   %8.2f us\n", (run<4096, true>(g, a, xw, 50)));
+    printf("x-wave without FMAs and qx   %8.2f us\n", (run<12288, true>(g, a, xw, 50)));
+    printf("x-wave instrumented   (256)  %8.2f us\n", (run<256, true>(g, a, xw, 5)));
+  } else {
+    printf("full                         %8.2f us\n", (run<0>(g, a, xw, 50)));
+    printf("storer: no global stores     %8.2f us\n", (run<1024>(g, a, xw, 50)));
+    printf("storer: idle                 %8.2f us\n", (run<2048>(g, a, xw, 50)));
+    printf("instrumented          (256)  %8.2f us\n", (run<256>(g, a, xw, 5)));
+  }
+  {
+    BwdArgs b = {};
+    b.gates = a.gates, b.cs = a.cs, b.dy = nullptr, b.dhT = a.hT, b.dcT = nullptr;
+    b.VR = dalloc((size_t)4 * 16 * g.NT, 0.2f), b.UE = dalloc((size_t)16 * g.NT, 0.2f), b.EH = a.EH;
+    b.dpre = dalloc(TS * 4, 0.f), b.dQs = dalloc((size_t)g.T * g.B * 16, 0.f), b.trash = a.trash;
+    printf("rec_bwd full                 %8.2f us\n", run_bwd<0>(g, b, 50));
+    printf("rec_bwd, storer idle         %8.2f us\n", run_bwd<2048>(g, b, 50));
+    printf("rec_bwd, loader idle         %8.2f us\n", run_bwd<4096>(g, b, 50));
+    printf("rec_bwd, both idle           %8.2f us\n", run_bwd<6144>(g, b, 50));
+  }
   float hbuf[256];
   CK(hipMemcpy(hbuf, a.trash, sizeof(hbuf), hipMemcpyDeviceToHost));
   const char* names[6] = {"reduce+write", "wait+barrier", "lds sum", "fma", "gates+outs", "step total"};
@@ -65,5 +115,6 @@ int main() {
     for (int i = 0; i < 6; ++i) printf("  %s %.0f", names[i], hbuf[64 + w * 8 + i]);
     printf("\n");
   }
+  printf("loader: issue %.0f  vmcnt wait %.0f   storer: busy %.0f   (ticks per step)\n", hbuf[64 + 24], hbuf[64 + 25], hbuf[64 + 26]);
   return 0;
 }

@@ -61,6 +61,11 @@ struct Scope {
 
 long long align64(long long v) { return (v + 63) / 64 * 64; }
 
+const bool g_xwave = []() {
+  const char* e = getenv("VMLMF_XWAVE");
+  return e == nullptr || e[0] != '0';
+}();
+
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (d == nullptr) return fail(VMLMF_E_BADARG, "null descriptor");
@@ -274,7 +279,9 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     Scope sc(0, s);
     if ((rc = hip_fail(launch_pack(g, rp, P, pack, s), "pack")) != 0) return rc;
   }
-  {
+  // narrow-input layers compute the x-projection inside rec_fwd_kernel (VMLMF_XWAVE=0: always the separate launch)
+  const bool xwave = g_xwave && vg_xwave_ok(g);
+  if (!xwave) {
     Scope sc(1, s);
     if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : nullptr, s), "xproj")) != 0)
       return rc;
@@ -301,9 +308,12 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
   a.gates = g.training ? rs + L.r_gates : nullptr;
   a.cs = g.training ? rs + L.r_cs : nullptr;
   a.Qs = g.training ? rs + L.r_Qs : nullptr;
+  XwArgs xw;
+  xw.x = x, xw.UXP = pack + P.UXP, xw.WXD = pack + P.WXD, xw.BBT = pack + P.BBT;
+  a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
   {
     Scope sc(2, s);
-    if ((rc = hip_fail(launch_rec_fwd(g, a, s), "rec_fwd")) != 0) return rc;
+    if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
   }
   return 0;
 }

@@ -115,6 +115,17 @@ __device__ __forceinline__ void st4g_agent(gf32* p, float4 v) {
 __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
+// Stores in the scalar-base + 32-bit vector byte-offset form (global_store ... v_off, v_data, s[base:base+1]).
+// hipcc turns `uniform_ptr[per_lane_index]` into 64-bit per-lane pointers and updates them with vector adds; in
+// the storer waves of the recurrent kernels that arithmetic was most of their ~200 vector instructions per step.
+// Inline asm: invisible to the compiler's waitcnt pass, which is fine for waves that never wait on stores.
+__device__ __forceinline__ void st4_sv(const void* sbase, unsigned voff, float4 v) {
+  const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void st1_sv(const void* sbase, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 // LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base + lane*SIZE).
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef __attribute__((address_space(1))) const void gl_cvoid_t;

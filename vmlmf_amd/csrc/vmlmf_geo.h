@@ -35,7 +35,8 @@ struct VGeo {
 struct VPack {
   long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
   long long UD, VD, UDT, VDT, VXTT;   // dense group factors + V_x^T, step-wise path only
-  long long TKT, total;               // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
+  long long TKT;                      // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
+  long long WXD, total;               // dense x-side matrix W_x[m][k][slot] of the x-projection wave (I <= 16 only)
 };
 
 #ifdef __HIPCC__
@@ -48,6 +49,10 @@ struct VPack {
 #define VG_GEMM_SPLIT 8     // partial copies its scratch holds
 
 VG_HD int vg_pad8(int v) { return (v + 7) / 8 * 8; }
+
+// Shapes whose x-projection rides inside rec_fwd_kernel (its wave NW): one row per workgroup, at most three
+// compute waves, an input narrow enough that the dense x-side matrix fits that wave's registers.
+VG_HD bool vg_xwave_ok(const VGeo& g) { return !g.generic && !g.flat && g.R == 1 && g.NT <= 192 && g.I <= 16; }
 
 VG_HD VPack vg_pack_layout(const VGeo& g) {
   VPack p;
@@ -73,6 +78,7 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   p.VDT = take(g.generic ? N4 * GK : 0);
   p.VXTT = take(g.generic ? N4 * g.KX : 0);
   p.TKT = take(g.generic ? VG_GEMM_TICKETS : 0);
+  p.WXD = take(vg_xwave_ok(g) ? 4LL * g.I * g.NT : 0);
   p.total = o;
   return p;
 }

@@ -7,6 +7,13 @@ struct FwdArgs {
   const float *gx, *VE, *UR, *EH, *h0, *c0;
   float *y, *hT, *cT, *gates, *cs, *Qs;
   float* trash;  // >= 64 floats: target of the redirected stores of inactive lanes (keeps stores unconditional)
+  float* qxw;    // x-projection wave: qx rows for the weight-gradient kernels (written by the storer wave)
+  int xwave;     // 1: wave NW computes the x-projection itself (XwArgs), no gx buffer is read
+};
+// second argument block of rec_fwd_kernel: what its x-projection wave needs (only that wave reads it, straight
+// from the kernel-argument segment, so it costs the recurrent waves no registers)
+struct XwArgs {
+  const float *x, *UXP, *WXD, *BBT;
 };
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
@@ -44,7 +51,7 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s);
 int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s);
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
                  hipStream_t s);
-int launch_rec_fwd(const VGeo& g, const FwdArgs& a, hipStream_t s);
+int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);

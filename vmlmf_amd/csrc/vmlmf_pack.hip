@@ -125,6 +125,26 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
           rr = (int)(le % g.KX); k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
         }
+      } else if (e >= L.WXD) {  // WXD[(m*4+k)][slot] = W_x: x[m] -> pre-activation k of the unit in `slot`
+        const long long le = e - L.WXD;
+        if (le < 4LL * g.I * NT) {
+          const int j = (int)(le / NT), slot = (int)(le % NT), m = j >> 2, kk = j & 3;
+          int nn;
+          if (vg_slot_unit(g, slot, nn)) {
+            if (nn == m) {
+              v = p.dia_x[nn];      // diag(d_x) + (U V^T with its diagonal removed): the diagonal is d_x itself
+            } else {
+              float u[32], w[32];
+#pragma unroll
+              for (int r = 0; r < 32; ++r) {
+                u[r] = ref_ux(g, p, m, r);
+                w[r] = ref_vx(g, p, nn, kk, r);
+              }
+#pragma unroll
+              for (int r = 0; r < 32; ++r) v = fmaf(u[r], w[r], v);
+            }
+          }
+        }
       }                         // else TKT: the split-K tickets start at zero
       if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s
         const int sblk = (g.G == 2 && rr >= g.off1) ? 1 : 0;
