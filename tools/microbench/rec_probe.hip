@@ -95,6 +95,10 @@ int main(int argc, char**) {
     printf("full                         %8.2f us\n", (run<0>(g, a, xw, 50)));
     printf("storer: no global stores     %8.2f us\n", (run<1024>(g, a, xw, 50)));
     printf("storer: idle                 %8.2f us\n", (run<2048>(g, a, xw, 50)));
+    printf("idle storer, no DPP reduce   %8.2f us\n", (run<2048 + 1>(g, a, xw, 50)));
+    printf("idle storer, 1/4 of the FMAs %8.2f us\n", (run<2048 + 2>(g, a, xw, 50)));
+    printf("idle storer, no exp/rcp      %8.2f us\n", (run<2048 + 4>(g, a, xw, 50)));
+    printf("idle storer, all three       %8.2f us\n", (run<2048 + 7>(g, a, xw, 50)));
     printf("instrumented          (256)  %8.2f us\n", (run<256>(g, a, xw, 5)));
   }
   {
