@@ -44,7 +44,7 @@ def test_query_headline_geometry():
     s = _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 512, 128, 9, 180, 16, [16, 16], g=2))
     assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kh) == (1, 256, 512, 32)   # 2 groups x 2 waves
     s = _lib.query(_lib.make_desc(_lib.V1_CELL, 1024, 8, 9, 180, 16, [16]))
-    assert (s.rows_per_wg, s.workgroups) == (2, 512)                                    # two rows per workgroup past B = 512
+    assert (s.rows_per_wg, s.workgroups) == (1, 1024)                                   # one row per workgroup at any batch
     s = _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 81, 24, 77, 180, 8, [2, 4], g=2))  # demo.sh:10
     assert (s.kx, s.kh) == (8, 16)
     # BASELINE config E (PTB group layer): too large for the register-resident kernels -> step-wise path

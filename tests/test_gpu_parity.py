@@ -77,18 +77,18 @@ CASES = [
     (O.V1, 5, 4, 9, 65, 5, [11], True, True),        # one unit into the second wave, odd ranks
     (O.V1, 2, 3, 30, 200, 16, [24], False, False),   # rank 24 (pass of 16 + half pass)
     (O.V1, 3, 4, 12, 130, 32, [32], False, True),    # rank 32
-    (O.V1, 300, 3, 6, 40, 4, [4], False, False),     # B > 256: two rows per workgroup, odd tail
-    (O.V1, 513, 2, 6, 40, 4, [4], False, True),      # odd batch with R = 2
+    (O.V1, 300, 3, 6, 40, 4, [4], False, False),     # more rows than CUs: workgroups queue up
+    (O.V1, 513, 2, 6, 40, 4, [4], False, True),      # odd batch, two workgroups per CU
     (O.V2, 4, 5, 6, 20, 3, [2, 5], False, False),
     (O.V2, 3, 4, 10, 136, 8, [16, 8], False, True),  # two waves per group, second one ragged
-    (O.V2, 260, 2, 5, 24, 3, [4, 4], False, False),  # group cell with R = 2
+    (O.V2, 260, 2, 5, 24, 3, [4, 4], False, False),  # group cell, B > 256
     (O.V3, 6, 5, 24, 24, 4, [6], True, True),
     (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),     # batch != 40 (the reference cannot run this)
     (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
     # 257..512 thread slots: the 8-wave instantiations of the persistent kernels
     (O.V1, 4, 5, 20, 300, 8, [16], False, True),     # 5 compute waves
     (O.V1, 3, 3, 9, 500, 16, [32], False, False),    # 8 compute waves, rank 32
-    (O.V1, 260, 2, 9, 300, 8, [8], False, False),    # ... with two rows per workgroup
+    (O.V1, 260, 2, 9, 300, 8, [8], False, False),    # ... with more rows than CUs
     (O.V2, 3, 4, 12, 280, 8, [8, 16], False, True),  # two groups of three waves (384 slots), rank 8 + 16
     (O.V3, 5, 4, 330, 330, 8, [24], True, True),     # LM layer, 6 waves
     (O.V4, 6, 3, 264, 264, 6, [8, 8], True, True),   # flat layout on 2 x 3 waves

@@ -124,9 +124,10 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // register-resident persistent kernels need <= 32 ranks per unit and <= 512 thread slots; larger layers
   // (e.g. H = 650, ranks [32,32]) run the step-wise path of vmlmf_generic.hip
   g.generic = (g.KH > 32 || g.NT > 512) ? 1 : 0;
-  // rows per workgroup: one while at most two workgroups share a CU (measured at H = 180, T = 128: B = 512 takes
-  // 0.506 ms with one row per workgroup against 0.562 ms with two; at B = 768 the two are equal), then two
-  g.R = (g.B <= 512 || g.flat || g.generic) ? 1 : 2;
+  // One batch row per workgroup, whatever the batch: with more rows than CUs the workgroups queue up, which
+  // measured at least as fast as two rows per workgroup at every size (H = 180, T = 128: B = 512 0.49 vs 0.55 ms,
+  // 768 0.71 vs 0.78, 1024 0.98 vs 0.96, 2048 1.84 vs 2.00); the kernels keep their R template parameter.
+  g.R = 1;
   g.nwg = (g.B + g.R - 1) / g.R;
   g.Bp = g.nwg * g.R;
   if ((long long)g.T * g.Bp * g.NT * 4 >= (1LL << 31) || (long long)g.T * g.B * g.H >= (1LL << 31))
