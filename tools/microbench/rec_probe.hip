@@ -90,6 +90,8 @@ int main(int argc, char**) {
     printf("x-wave, storer idle          %8.2f us\n", (run<2048, true>(g, a, xw, 50)));
     printf("x-wave without its pk FMAs   %8.2f us\n", (run<4096, true>(g, a, xw, 50)));
     printf("x-wave without FMAs and qx   %8.2f us\n", (run<12288, true>(g, a, xw, 50)));
+    printf("no stores AND no x FMAs      %8.2f us\n", (run<1024 + 4096, true>(g, a, xw, 50)));
+    printf("storer idle AND no x FMAs    %8.2f us\n", (run<2048 + 4096, true>(g, a, xw, 50)));
     printf("x-wave instrumented   (256)  %8.2f us\n", (run<256, true>(g, a, xw, 5)));
   } else {
     printf("full                         %8.2f us\n", (run<0>(g, a, xw, 50)));
