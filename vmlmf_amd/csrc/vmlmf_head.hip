@@ -63,9 +63,12 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int C, cons
     if (threadIdx.x < HEAD_CMAX) sdl[0][threadIdx.x] = (int)threadIdx.x < C ? dl[(size_t)blk * C + threadIdx.x] : 0.f;
     __syncthreads();
     for (int n = threadIdx.x; n < H; n += 256) {
+      float wv[HEAD_CMAX];   // every weight load of the column is issued before the first FMA: one latency
+#pragma unroll
+      for (int c = 0; c < HEAD_CMAX; ++c) wv[c] = c < C ? W[(size_t)c * H + n] : 0.f;
       float acc = 0.f;
-#pragma unroll 8
-      for (int c = 0; c < C; ++c) acc = fmaf(sdl[0][c], W[(size_t)c * H + n], acc);
+#pragma unroll
+      for (int c = 0; c < HEAD_CMAX; ++c) acc = fmaf(sdl[0][c], wv[c], acc);   // sdl is zero past C
       dh[(size_t)blk * H + n] = acc;
     }
     return;
