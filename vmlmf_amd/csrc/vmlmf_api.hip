@@ -145,6 +145,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (rc2 < 32) rc2 = 32;
   g.RC2 = rc2;
   g.nchunk = (TB + rc2 - 1) / rc2;
+  g.foldx = (!g.generic && g.I <= g.KX) ? 1 : 0;
   g.NA = 5 * g.KX + 5 * g.KH + 12;
   {
     const long long GK = (long long)g.G * g.KH;
@@ -366,7 +367,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   WgxArgs wx;
   wx.dpre = ws + L.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
   wx.dx = dx, wx.dqx = ws + L.b_dqx;
-  {
+  if (!(g.foldx && dx == nullptr)) {   // with the x-fold dqx only feeds dx
     Scope sc(4, s);
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }

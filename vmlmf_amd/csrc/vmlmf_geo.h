@@ -28,6 +28,9 @@ struct VGeo {
   int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12
   long long sxT, sxB, syT, syB;  // element strides of x/dx and y/dy
   int time_major, training;
+  int foldx;    // 1 (I <= KX): the dV product contracts dpre with x instead of qx = x U_x (same 32-column tile), i.e. it
+                //    yields G = dpre^T x; finish_kernel derives dV_x = G U_x and dU_x = G^T V_x from it, so neither dqx
+                //    nor the x^T dqx product is needed unless the layer's input wants a gradient
   int generic;  // 1: step-wise path (vmlmf_generic.hip): factors do not fit the register-resident kernels
 };
 

@@ -280,7 +280,36 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   const long long n_uh0 = (long long)H * g.ru0, n_vh0 = 4LL * H * g.ru0;
   const long long n_uh1 = g.G == 2 ? (long long)H * g.ru1 : 0, n_vh1 = g.G == 2 ? 4LL * H * g.ru1 : 0;
   long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g.foldx) {
+    // x-fold: the accumulator rows va_vx(k, m), m < I, hold G[k][m](n) = sum_rows dpre[row][n][k] x[row][m].
+    // du_x[m][r] = sum_{n,k} G[k][m](n) vx(n,k,r) - ...: one wave per element, fixed-order butterfly
+    if (e < n_ux * 64) {
+      const long long eo = e >> 6;
+      const int lane = (int)(e & 63), m = (int)(eo / rw), r = (int)(eo % rw);
+      float v = 0.f;
+      for (int n = lane; n < H; n += 64)
+        for (int k = 0; k < 4; ++k) v = fmaf(CG(va_vx(g, k, m), n), ref_vx(g, p, n, k, r), v);
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+      if (lane == 0) {
+        for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
+        o.u_x[eo] = v;
+      }
+      return;
+    }
+    e -= n_ux * 64;
+    if (e < n_vx) {  // dv_x[k*H+n][r] = sum_m G[k][m](n) ux(m,r) - ...
+      const int row = (int)(e / rw), r = (int)(e % rw), k = row / H, n = row % H;
+      float v = 0.f;
+      for (int m = 0; m < I; ++m) v = fmaf(CG(va_vx(g, k, m), n), ref_ux(g, p, m, r), v);
+      if (n < I) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
+      o.v_x[e] = v;
+      return;
+    }
+    e += n_ux;   // fall through to the branches below with the offsets they expect
+  }
   if (e < n_ux) {  // du_x[m][r]
+    if (g.foldx) return;
     const int m = (int)(e / rw), r = (int)(e % rw);
     float v = CG(va_ux(g, r), m);
     for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
@@ -289,6 +318,7 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   }
   e -= n_ux;
   if (e < n_vx) {  // dv_x[k*H+n][r]
+    if (g.foldx) return;
     const int row = (int)(e / rw), r = (int)(e % rw), k = row / H, n = row % H;
     float v = CG(va_vx(g, k, r), n);
     if (n < I) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
@@ -372,7 +402,7 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
 }
 
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s) {
-  long long n = (long long)g.I * g.rw + 4LL * g.H * g.rw + g.I + g.H + 4LL * g.H;
+  long long n = (long long)g.I * g.rw * (g.foldx ? 64 : 1) + 4LL * g.H * g.rw + g.I + g.H + 4LL * g.H;
   n += (long long)g.H * g.ru0 + 4LL * g.H * g.ru0;
   if (g.G == 2) n += (long long)g.H * g.ru1 + 4LL * g.H * g.ru1;
   hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out);

@@ -122,7 +122,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
                                          const int lane, const int half, float* comb) {
   const int B = g.B, H = g.H, NT = g.NT, KX = g.KX, GK = g.G * g.KH;
   const int TB = g.T * B;
-  const int MT2 = (H + 31) / 32, MT3 = (g.I + 31) / 32;
+  const int MT2 = (H + 31) / 32, MT3 = (g.I + 31) / 32;   // (partial layout: the C3 block stays in place with the x-fold)
   const int crow0 = chunk * g.RC2;
   const int crow1 = crow0 + g.RC2 < TB ? crow0 + g.RC2 : TB;
   // halves are cut at an even row so that each MFMA still contracts a (row, row + 1) pair of one half
@@ -145,15 +145,24 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const float* bsrc[NBT];
   unsigned bstr[NBT];
   float bmask[NBT];
+  bool bisx[NBT];   // x-fold: the column is a column of x, addressed by (t, b) strides
 #pragma unroll
   for (int j = 0; j < NBT; ++j) {
     const int c = j * 32 + li;
     const bool okc = j < nbt && c < NB;
     bmask[j] = okc ? 1.f : 0.f;
     const int cc = okc ? c : 0;
+    bisx[j] = false;
     if (MODE == 1) {
-      bsrc[j] = cc < KX ? a.qx + cc : a.Qs + (cc - KX);
-      bstr[j] = cc < KX ? KX : GK;
+      if (g.foldx && cc < KX) {   // G = dpre^T x in the columns qx had (I <= KX; the rest of them stay zero)
+        bisx[j] = true;
+        if (cc >= g.I) bmask[j] = 0.f;
+        bsrc[j] = a.x + (cc < g.I ? cc : 0);
+        bstr[j] = 0;
+      } else {
+        bsrc[j] = cc < KX ? a.qx + cc : a.Qs + (cc - KX);
+        bstr[j] = cc < KX ? KX : GK;
+      }
     } else if (MODE == 2) {
       bsrc[j] = a.dQs + cc;
       bstr[j] = GK;
@@ -211,7 +220,8 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
         hv[u] = 0.f, xv[u] = 0.f;
       }
 #pragma unroll
-      for (int j = 0; j < NBT; ++j) bv[u][j] = bmask[j] * bsrc[j][rc * bstr[j]];
+      for (int j = 0; j < NBT; ++j)
+        bv[u][j] = bmask[j] * bsrc[j][(MODE == 1 && bisx[j]) ? t * usxT + b * usxB : rc * bstr[j]];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -281,7 +291,7 @@ __global__ void __launch_bounds__(SPLIT ? 512 : 256) wgrad_mfma_kernel(VGeo g, A
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = wave & 3, half = wave >> 2;
   const int task = blockIdx.x * 4 + slot;
-  const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
+  const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = g.foldx ? 0 : (g.I + 31) / 32;
   constexpr int NBTM = NBT1 > NBT2 ? NBT1 : NBT2;
   float* comb = reinterpret_cast<float*>(smem4) + (size_t)slot * (16 * NBTM + 3) * 64;
   // every wave of the workgroup takes the same number of barriers: tasks past the end run an empty mode
@@ -341,7 +351,7 @@ __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __r
   } else if (e < oe) {                // C3[m][r]
     const long long e3 = e - o3;
     const int m = (int)(e3 / NB3p), r = (int)(e3 - (long long)m * NB3p);
-    if (m < g.I && r < KX) cgrad[(size_t)va_ux(g, r) * NT + vg_slot(g, m)] = total;
+    if (!g.foldx && m < g.I && r < KX) cgrad[(size_t)va_ux(g, r) * NT + vg_slot(g, m)] = total;
   } else {                            // E[which][(slot,k)]
     const long long e4 = e - oe;
     const int which = (int)(e4 / (NT * 4)), i = (int)(e4 - (long long)which * NT * 4), slot = i >> 2, k = i & 3;
@@ -375,7 +385,7 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   AtbArgs a;
   a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
   a.P = w.wpart;
-  const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.I + 31) / 32;
+  const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
   const int GK = g.G * g.KH, n1 = (g.KX + GK + 31) / 32, n2 = (GK + 31) / 32;
   const dim3 grid((tasks + 3) / 4, g.nchunk);
   // two waves per task while the hand-over buffer stays small (4 tasks x (16 n1 + 3) x 64 floats <= 36 KB)
