@@ -115,9 +115,10 @@ struct AtbArgs {
   float* P;
 };
 
-// SPLIT: two waves share the task, each takes half of the chunk's rows; the second hands its accumulators to the
-// first through `comb` (LDS, [task slot][value][lane]) and the first writes the sum (fixed order: deterministic).
-template <int MODE, int NBT, bool SPLIT>
+// NS (1, 2, 4): that many waves share the task, each takes a part of the chunk's rows; parts 1.. hand their
+// accumulators to part 0 through `comb` (LDS, [task slot][part - 1][value][lane]) and part 0 writes the sum
+// (parts added in index order: deterministic).
+template <int MODE, int NBT, int NS>
 __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const int mt, const int chunk,
                                          const int lane, const int half, float* comb) {
   const int B = g.B, H = g.H, NT = g.NT, KX = g.KX, GK = g.G * g.KH;
@@ -125,10 +126,10 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const int MT2 = (H + 31) / 32, MT3 = (g.I + 31) / 32;   // (partial layout: the C3 block stays in place with the x-fold)
   const int crow0 = chunk * g.RC2;
   const int crow1 = crow0 + g.RC2 < TB ? crow0 + g.RC2 : TB;
-  // halves are cut at an even row so that each MFMA still contracts a (row, row + 1) pair of one half
-  const int cmid = SPLIT ? crow0 + ((crow1 - crow0 + 1) / 2 + 1) / 2 * 2 : crow1;
-  const int row0 = (SPLIT && half == 1) ? (cmid < crow1 ? cmid : crow1) : crow0;
-  const int row1 = (SPLIT && half == 0) ? (cmid < crow1 ? cmid : crow1) : crow1;
+  // parts are cut at even rows so that each MFMA still contracts a (row, row + 1) pair of one part
+  const int plen = ((crow1 - crow0 + NS - 1) / NS + 1) / 2 * 2;
+  const int row0 = crow0 + half * plen < crow1 ? crow0 + half * plen : crow1;
+  const int row1 = row0 + plen < crow1 && half != NS - 1 ? row0 + plen : crow1;
   const int li = lane & 31, lk = lane >> 5;
   const int NB = MODE == 1 ? KX + GK : (MODE == 2 ? GK : KX);     // B columns
   constexpr int nbt = NBT;
@@ -235,26 +236,31 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
     }
   }
 
-  if constexpr (SPLIT) {
+  if constexpr (NS > 1) {
     constexpr int NV = 16 * NBT + 3;
-    if (half == 1) {
+    if (half > 0) {
+      float* mine = comb + (size_t)(half - 1) * NV * 64;
 #pragma unroll
       for (int j = 0; j < NBT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) comb[(j * 16 + r) * 64 + lane] = acc[j][r];
-      comb[(NV - 3) * 64 + lane] = e_h;
-      comb[(NV - 2) * 64 + lane] = e_x;
-      comb[(NV - 1) * 64 + lane] = e_b;
+        for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64 + lane] = acc[j][r];
+      mine[(NV - 3) * 64 + lane] = e_h;
+      mine[(NV - 2) * 64 + lane] = e_x;
+      mine[(NV - 1) * 64 + lane] = e_b;
     }
     __syncthreads();
-    if (half == 1) return;
+    if (half > 0) return;
 #pragma unroll
-    for (int j = 0; j < NBT; ++j)
+    for (int hp = 0; hp < NS - 1; ++hp) {
+      const float* other = comb + (size_t)hp * NV * 64;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] += comb[(j * 16 + r) * 64 + lane];
-    e_h += comb[(NV - 3) * 64 + lane];
-    e_x += comb[(NV - 2) * 64 + lane];
-    e_b += comb[(NV - 1) * 64 + lane];
+      for (int j = 0; j < NBT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += other[(j * 16 + r) * 64 + lane];
+      e_h += other[(NV - 3) * 64 + lane];
+      e_x += other[(NV - 2) * 64 + lane];
+      e_b += other[(NV - 1) * 64 + lane];
+    }
   }
   // partial layout per chunk: C1 [NT*4][NB1p] | C2 [M2p][NB2p] | C3 [M3p][NB3p] | E [3][NT*4]
   const int NB1p = (KX + GK + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
@@ -283,25 +289,25 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
 }
 
 // NBT1 / NBT2: 32-wide tiles of B for mode 1 (KX + G*KH columns) and mode 2 (G*KH columns); mode 3 has one.
-// SPLIT: 8 waves per workgroup, waves w and w + 4 share task w (half the rows each): the kernel is bound by the
-// load -> MFMA latency of each wave's row loop, so halving the loop nearly halves the kernel.
-template <int NBT1, int NBT2, bool SPLIT>
-__global__ void __launch_bounds__(SPLIT ? 512 : 256) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
+// NS: 4 NS waves per workgroup, waves w, w + 4, ... share task w (a part of the rows each): the kernel is bound by
+// the load -> MFMA latency of each wave's row loop, so shortening the loop shortens the kernel.
+template <int NBT1, int NBT2, int NS>
+__global__ void __launch_bounds__(256 * NS) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
   extern __shared__ float4 smem4[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = wave & 3, half = wave >> 2;
   const int task = blockIdx.x * 4 + slot;
   const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = g.foldx ? 0 : (g.I + 31) / 32;
   constexpr int NBTM = NBT1 > NBT2 ? NBT1 : NBT2;
-  float* comb = reinterpret_cast<float*>(smem4) + (size_t)slot * (16 * NBTM + 3) * 64;
+  float* comb = reinterpret_cast<float*>(smem4) + (size_t)slot * (NS - 1) * (16 * NBTM + 3) * 64;
   // every wave of the workgroup takes the same number of barriers: tasks past the end run an empty mode
   if (task < MT1)
-    atb_task<1, NBT1, SPLIT>(g, a, task, blockIdx.y, lane, half, comb);
+    atb_task<1, NBT1, NS>(g, a, task, blockIdx.y, lane, half, comb);
   else if (task < MT1 + MT2)
-    atb_task<2, NBT2, SPLIT>(g, a, task - MT1, blockIdx.y, lane, half, comb);
+    atb_task<2, NBT2, NS>(g, a, task - MT1, blockIdx.y, lane, half, comb);
   else if (task < MT1 + MT2 + MT3)
-    atb_task<3, 1, SPLIT>(g, a, task - MT1 - MT2, blockIdx.y, lane, half, comb);
-  else if (SPLIT)
+    atb_task<3, 1, NS>(g, a, task - MT1 - MT2, blockIdx.y, lane, half, comb);
+  else if (NS > 1)
     __syncthreads();
 }
 
@@ -388,19 +394,18 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
   const int GK = g.G * g.KH, n1 = (g.KX + GK + 31) / 32, n2 = (GK + 31) / 32;
   const dim3 grid((tasks + 3) / 4, g.nchunk);
-  // two waves per task while the hand-over buffer stays small (4 tasks x (16 n1 + 3) x 64 floats <= 36 KB)
+  // two waves per task while the hand-over buffer stays small (four measured slower at the headline shape:
+  // 0.1990 vs 0.1966 ms per step)
   if (n1 <= 2) {
-    const dim3 block(512);
     const size_t lds = sizeof(float) * 4 * (16 * (size_t)n1 + 3) * 64;
-    if (n1 == 1 && n2 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, true>), grid, block, lds, s, g, a);
-    else if (n1 == 2 && n2 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<2, 1, true>), grid, block, lds, s, g, a);
-    else if (n1 == 2 && n2 == 2) hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, true>), grid, block, lds, s, g, a);
-    else return -3;
+    if (n1 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 2>), grid, dim3(512), lds, s, g, a);
+    else if (n2 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<2, 1, 2>), grid, dim3(512), lds, s, g, a);
+    else hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, 2>), grid, dim3(512), lds, s, g, a);
     return (int)hipGetLastError();
   }
   const dim3 block(256);
 #define WG_CASE(A, Bv) \
-  if (n1 == A && n2 == Bv) hipLaunchKernelGGL((wgrad_mfma_kernel<A, Bv, false>), grid, block, 0, s, g, a)
+  if (n1 == A && n2 == Bv) hipLaunchKernelGGL((wgrad_mfma_kernel<A, Bv, 1>), grid, block, 0, s, g, a)
   // n1 = tiles of KX + G*KH (<= 160 columns), n2 = tiles of G*KH (<= 128 columns), n2 <= n1
   WG_CASE(3, 1);
   else WG_CASE(3, 2);
