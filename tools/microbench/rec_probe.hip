@@ -49,11 +49,12 @@ float run_bwd(const VGeo& g, const BwdArgs& b, int iters) {
   return ms * 1000.f / iters;
 }
 
-int main(int argc, char**) {
+int main(int argc, char** argv) {
   VGeo g = {};
   g.variant = 1, g.B = 64, g.T = 128, g.I = 9, g.H = 180, g.rw = 16, g.G = 1, g.Hg = 180, g.W = 3, g.NT = 192,
   g.NW = 3, g.ru0 = 16, g.off1 = 16, g.KX = 16, g.KH = 16, g.NP = 1, g.KQ = 16, g.NPX = 1, g.KQX = 16, g.R = 1,
   g.nwg = 64, g.Bp = 64, g.syT = 180, g.syB = 128 * 180, g.sxT = 9, g.sxB = 128 * 9;
+  if (argc > 2) { g.B = g.Bp = g.nwg = atoi(argv[2]); g.syB = 128 * 180; }   // fewer rows: smaller per-step strides
   const size_t TS = (size_t)g.T * g.Bp * g.NT;
   auto dalloc = [&](size_t n, float scale) {
     std::vector<float> h(n);
@@ -75,7 +76,7 @@ int main(int argc, char**) {
   a.gates = dalloc(TS * 4, 0.f);
   a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
   a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
-  a.trash = dalloc(256, 0.f);
+  a.trash = dalloc(512, 0.f);
   XwArgs xw = {};
   xw.x = dalloc((size_t)g.B * g.T * g.I, 1.0f);
   xw.UXP = dalloc((size_t)g.I * g.KX, 0.2f);
@@ -112,6 +113,14 @@ int main(int argc, char**) {
     printf("rec_bwd, storer idle         %8.2f us\n", run_bwd<2048>(g, b, 50));
     printf("rec_bwd, loader idle         %8.2f us\n", run_bwd<4096>(g, b, 50));
     printf("rec_bwd, both idle           %8.2f us\n", run_bwd<6144>(g, b, 50));
+  }
+  if (xwave) {
+    run<65536, true>(g, a, xw, 1);
+    float tb[64];
+    CK(hipMemcpy(tb, a.trash + 128, sizeof(tb), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 4; ++k)
+      printf("barrier %d arrival (ticks, relative to compute wave 0): w1 %+.0f  w2 %+.0f  storer %+.0f\n", 65 + k,
+             tb[8 + 2 * k] - tb[2 * k], tb[16 + 2 * k] - tb[2 * k], tb[32 + 2 * k] - tb[2 * k]);
   }
   float hbuf[256];
   CK(hipMemcpy(hbuf, a.trash, sizeof(hbuf), hipMemcpyDeviceToHost));
