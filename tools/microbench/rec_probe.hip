@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
   a.y = dalloc((size_t)g.B * g.T * g.H, 0.f);
   a.hT = dalloc((size_t)g.B * g.H, 0.f);
   a.cT = dalloc((size_t)g.B * g.H, 0.f);
-  a.gates = dalloc(TS * 4, 0.f);
+  a.gates = dalloc((TS + (size_t)g.Bp * g.NT) * 4, 0.f);
   a.cs = dalloc(TS + (size_t)g.Bp * g.NT, 0.f);
   a.Qs = dalloc((size_t)g.T * g.B * 16, 0.f);
   a.trash = dalloc(512, 0.f);
