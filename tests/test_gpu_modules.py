@@ -232,3 +232,31 @@ def test_clip_sgd_step_matches_the_lm_loop():
         for a, b in zip(mine, ref):
             assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
             assert float((a.grad - b.grad).abs().max()) <= 2e-6 * max(1.0, float(b.grad.abs().max()))
+
+
+def test_graphed_train_step_matches_the_eager_loop():
+    """GraphedTrainStep (forward + fused CE + backward + fused Adam in one hipGraph) against the same loop eager."""
+    import copy
+    import vmlmf_amd
+    torch.manual_seed(1)
+    a = Net(9, layer_sizes=[40], w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    b = copy.deepcopy(a)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(16, 12, 9, generator=g).cuda() for _ in range(4)]
+    ts = [torch.randint(0, 18, (16,), generator=g).cuda() for _ in range(4)]
+    step = vmlmf_amd.GraphedTrainStep(a, vmlmf_amd.cross_entropy, vmlmf_amd.optim.Adam(a.parameters(), lr=2e-3),
+                                      xs[0], ts[0], warmup=2)
+    opt = vmlmf_amd.optim.Adam(b.parameters(), lr=2e-3)
+    for _ in range(2):                      # the warm-up steps of the graphed loop, eagerly
+        b.zero_grad(set_to_none=True)
+        vmlmf_amd.cross_entropy(b(xs[0]), ts[0]).backward()
+        opt.step()
+    for x, t in zip(xs, ts):
+        la = step(x, t).clone()
+        b.zero_grad(set_to_none=True)
+        lb = vmlmf_amd.cross_entropy(b(x), t)
+        lb.backward()
+        opt.step()
+        assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)

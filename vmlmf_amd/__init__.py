@@ -8,6 +8,7 @@ from .cells import MyVMLMFCell, MyVMLMFCellg2, MyLSTMCell, MyLSTM, Net, TIME_STE
 from .lm import MyVMLSTM, MyVMLSTMGroup
 from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss
 from . import optim
+from .graphed import GraphedTrainStep
 
-__all__ = ["optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
+__all__ = ["GraphedTrainStep", "optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
            "vmlmf_sequence"]
