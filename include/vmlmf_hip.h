@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 1
+#define VMLMF_ABI_VERSION 2
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -25,6 +25,9 @@ extern "C" {
 #define VMLMF_V2_GROUP_CELL 2 /* MyVMLMFCellg2     V/src/models/vmlmf_group.py:37-155  */
 #define VMLMF_V3_LM 3         /* MyVMLSTM          V/src/models/vmlmf_lm.py:178-280    */
 #define VMLMF_V4_LM_GROUP 4   /* MyVMLSTMGroup     V/src/models/vmlmf_lm.py:53-174     */
+/* the reference's comparison cells without the vector multiplication (no dia_*, no diagonal removal) */
+#define VMLMF_V5_LMF_CELL 5   /* MyLSTMCell, low-rank mode   V/src/models/vmlmf.py:159-186,198-224   */
+#define VMLMF_V6_GROUP_NOVM 6 /* MyVMLMFgCellg2 (ablation)   V/src/models/vmlmf_group.py:158-251     */
 
 #define VMLMF_E_BADARG (-1)      /* null pointer / inconsistent descriptor                          */
 #define VMLMF_E_SHAPE (-2)       /* shape the reference itself rejects (I > H, I != H for LM, H % g) */
@@ -36,8 +39,8 @@ typedef struct vmlmf_desc {
   int32_t variant;           /* VMLMF_V*                                                        */
   int32_t B, T, I, H;        /* batch, time steps, input_size, hidden_size                      */
   int32_t w_rank;            /* rank of the input->hidden factorisation  (u_x: I x w_rank)      */
-  int32_t g;                 /* groups of the hidden->hidden path (1 for V1/V3, 2 for V2/V4)    */
-  int32_t u_ranks[VMLMF_MAX_G]; /* rank per shift s (V1/V3: only [0])                           */
+  int32_t g;                 /* groups of the hidden->hidden path (1 for V1/V3/V5, 2 for V2/V4/V6) */
+  int32_t u_ranks[VMLMF_MAX_G]; /* rank per shift s (V1/V3/V5: only [0])                        */
   int32_t time_major;        /* 1: (T,B,*)  LM layers;  0: (B,T,*)  MyLSTM batch_first          */
   int32_t training;          /* 1: forward fills `reserve` for backward; 0: inference            */
 } vmlmf_desc;
@@ -47,17 +50,22 @@ typedef struct vmlmf_desc {
  *   V2: u_x v_x as V1; u_h[s] (g,H/g,ru_s) v_h[s] (g,ru_s,4H/g); b_x=bias_x b_h=bias_h (1,4H)        vmlmf_group.py:61-79
  *   V3: as V1 with v_x=w_x, v_h[0]=w_h                                                               vmlmf_lm.py:200-213
  *   V4: as V2 with v_x=w_x, b_x/b_h (4H)                                                             vmlmf_lm.py:77-91
+ *   V5: u_x=w (I,rw) u_h[0]=u (H,ru); per gate k in (i,f,o,c~) order: w_gate[k]=w{k+1} (rw,H),
+ *       u_gate[k]=u{k+1} (ru,H), b_gate[k]=bias_i/bias_f/bias_o/bias_c (1,H); everything else NULL        vmlmf.py:159-186
+ *   V6: as V2 without dia_x/dia_h (NULL); its x side chunks (f,i,n,o) like its h side                 vmlmf_group.py:183-197,211
  * The same struct (non-const view) receives the gradients in the same layouts. */
 typedef struct vmlmf_params {
   const float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h;
   const float *u_h[VMLMF_MAX_G];
   const float *v_h[VMLMF_MAX_G];
+  const float *w_gate[4], *u_gate[4], *b_gate[4]; /* V5 only (ABI 2) */
 } vmlmf_params;
 
 typedef struct vmlmf_grads {
   float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h;
   float *u_h[VMLMF_MAX_G];
   float *v_h[VMLMF_MAX_G];
+  float *w_gate[4], *u_gate[4], *b_gate[4];       /* V5 only (ABI 2) */
 } vmlmf_grads;
 
 typedef struct vmlmf_sizes {

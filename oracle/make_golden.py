@@ -11,6 +11,10 @@ Reference entry points exercised (V/ = /root/reference/rnn_compression_factoriza
   MyVMLSTM           V/src/models/vmlmf_lm.py:178-280
   MyVMLSTMGroup      V/src/models/vmlmf_lm.py:53-174   (B=40 only: scratch rows hard-coded, 112-113)
   Net                V/src/models/vmlmf.py:319-355 + the train.py:58-65 loop (3 Adam steps)
+  MyLSTMCell         V/src/models/vmlmf.py:127-238     low-rank mode, bare cell and through MyLSTM
+  MyVMLMFgCellg2     V/src/models/vmlmf_group.py:158-251  bare cell and through MyLSTM
+
+`python oracle/make_golden.py NAME...` regenerates only the named fixtures.
 """
 import os
 import sys
@@ -25,8 +29,8 @@ sys.dont_write_bytecode = True
 sys.path.insert(0, REF_SRC)
 sys.path.insert(0, HERE)
 
-from models.vmlmf import MyVMLMFCell, MyLSTM, Net            # noqa: E402  (reference)
-from models.vmlmf_group import MyVMLMFCellg2                 # noqa: E402  (reference)
+from models.vmlmf import MyVMLMFCell, MyLSTMCell, MyLSTM, Net  # noqa: E402  (reference)
+from models.vmlmf_group import MyVMLMFCellg2, MyVMLMFgCellg2   # noqa: E402  (reference)
 from models.vmlmf_lm import MyVMLSTM, MyVMLSTMGroup          # noqa: E402  (reference)
 import vmlmf_oracle as O                                     # noqa: E402
 
@@ -77,7 +81,14 @@ def make_cell(variant, I, H, rw, ru, g=2):
         return MyVMLMFCellg2(I, H, w_rank=rw, u_ranks=ru, g=g)
     if variant == O.V3:
         return MyVMLSTM(I, H, w_rank=rw, u_ranks=ru if not isinstance(ru, list) else ru[0])
+    if variant == O.V5:
+        return MyLSTMCell(I, H, w_rank=rw, u_ranks=ru if not isinstance(ru, list) else ru[0])
+    if variant == O.V6:
+        return MyVMLMFgCellg2(I, H, w_rank=rw, u_ranks=ru, g=g)
     return MyVMLSTMGroup(I, H, w_rank=rw, u_ranks=ru, g=g)
+
+
+HAR_CELL = {O.V1: MyVMLMFCell, O.V2: MyVMLMFCellg2, O.V5: MyLSTMCell, O.V6: MyVMLMFgCellg2}
 
 
 def case_bare_cell(name, variant, B, I, H, rw, ru, seed):
@@ -91,7 +102,7 @@ def case_bare_cell(name, variant, B, I, H, rw, ru, seed):
     c = torch.tensor((0.5 * r.standard_normal((B, H))).astype(np.float32), requires_grad=True)
     dh = r.standard_normal((B, H)).astype(np.float32)
     dc = r.standard_normal((B, H)).astype(np.float32)
-    if variant in (O.V1, O.V2):
+    if variant not in (O.V3, O.V4):
         hn, cn = cell(x, (h, c))
     else:
         hn, cn = cell.lstm_step(x, h, c)
@@ -106,8 +117,7 @@ def case_har_seq(name, variant, B, T, I, H, rw, ru, seed):
     """One layer through the reference MyLSTM (batch-first, zero initial state), full tensors."""
     r = rng_of(seed)
     P = O.make_params(variant, I, H, rw, ru, seed=seed + 1)
-    cellcls = MyVMLMFCell if variant == O.V1 else MyVMLMFCellg2
-    rnn = MyLSTM(I, hidden_layer_sizes=[H], batch_first=True, w_rank=rw, u_ranks=ru, cell=cellcls)
+    rnn = MyLSTM(I, hidden_layer_sizes=[H], batch_first=True, w_rank=rw, u_ranks=ru, cell=HAR_CELL[variant])
     load_into(rnn, P, prefix="rnncells.0.")
     x = torch.tensor(r.standard_normal((B, T, I)).astype(np.float32), requires_grad=True)
     dy = r.standard_normal((B, T, H)).astype(np.float32)
@@ -216,6 +226,24 @@ def case_config_a_group(name="cfgA_v2_uci"):
          dx=x.grad.numpy(), G=grads_of(rnn, P, prefix="rnncells.0."))
 
 
+def case_config_a_novm(name, variant):
+    """UCI-HAR shape with the two comparison cells (plain low-rank LSTM rank 16; group cell without vm [16,16])."""
+    B, T, I, H, rw = 64, 128, 9, 180, 16
+    ru = [16] if variant == O.V5 else [16, 16]
+    P = O.make_params(variant, I, H, rw, ru, seed=3)
+    x_np, _ = O.synthetic_batch(B, T, I, seed=1234)
+    r = rng_of(4321)
+    dy = r.standard_normal((B, T, H)).astype(np.float32)
+    rnn = MyLSTM(I, hidden_layer_sizes=[H], batch_first=True, w_rank=rw, u_ranks=ru, cell=HAR_CELL[variant])
+    load_into(rnn, P, prefix="rnncells.0.")
+    x = torch.tensor(x_np, requires_grad=True)
+    y, hcat = rnn(x)
+    (y * torch.tensor(dy)).sum().backward()
+    save(name, meta=np.array([variant, B, T, I, H, rw] + ru), seeds=np.array([3, 1234, 4321]),
+         y_s=y.detach().numpy()[:, ::16], hT=hcat.detach().numpy(),
+         dx=x.grad.numpy(), G=grads_of(rnn, P, prefix="rnncells.0."))
+
+
 def case_config_c(name="cfgC_v1_opp2"):
     """BASELINE config C shape: Opportunity, 2-layer MyVMLMFCell H=256 r=24, B=128 T=24 I=77 (fp32 reference)."""
     B, T, I, H, rw, ru = 128, 24, 77, 256, 24, 24
@@ -269,6 +297,9 @@ def case_state_dict_names(name="state_dict_names"):
         "net_v2": Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFCellg2),
         "lm_v3": MyVMLSTM(16, 16, w_rank=4, u_ranks=4),
         "lm_v4": MyVMLSTMGroup(16, 16, w_rank=4, u_ranks=[2, 3]),
+        # a list u_rank raises in the reference here (vmlmf.py:177 gets the list through Net.cell, vmlmf.py:349-350)
+        "net_v5": Net(77, layer_sizes=[180], w_rank=8, u_rank=6, model=MyLSTM, cell=MyLSTMCell),
+        "net_v6": Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFgCellg2),
     }
     for tag, m in nets.items():
         for k, v in m.state_dict().items():
@@ -280,31 +311,46 @@ def case_state_dict_names(name="state_dict_names"):
     print(f"{name:28s} ok")
 
 
-def main():
-    os.makedirs(OUT, exist_ok=True)
-    case_bare_cell("cell_v1", O.V1, 4, 5, 8, 3, 3, 11)
-    case_bare_cell("cell_v1_b1", O.V1, 1, 5, 8, 3, 2, 12)
-    case_bare_cell("cell_v1_ieqh", O.V1, 3, 8, 8, 4, 5, 13)
-    case_bare_cell("cell_v2", O.V2, 4, 5, 12, 3, [2, 3], 14)
-    case_bare_cell("cell_v3", O.V3, 4, 8, 8, 3, 3, 15)
-    case_bare_cell("cell_v4", O.V4, 40, 12, 12, 3, [2, 3], 16)
-    case_har_seq("seq_v1", O.V1, 4, 6, 5, 8, 3, [3], 21)
-    case_har_seq("seq_v1_wide", O.V1, 5, 7, 20, 70, 5, [7], 22)       # H not a multiple of 64, odd ranks
-    case_har_seq("seq_v2", O.V2, 4, 6, 5, 12, 3, [2, 3], 23)
-    case_har_seq("seq_v2_demo", O.V2, 6, 8, 77, 180, 8, [2, 4], 24)   # demo.sh:10 shapes, short T
-    case_har_seq("seq_v1_demo", O.V1, 6, 8, 77, 180, 8, [6], 25)      # demo.sh:7 shapes, short T
-    case_lm_seq("seq_v3", O.V3, 4, 6, 8, 3, 3, 31)
-    case_lm_seq("seq_v4", O.V4, 40, 5, 12, 3, [2, 3], 32)
-    case_lm_carry("lm_v3_carry", 41)
-    case_config_a()
-    case_config_a_group()
-    case_config_c()
-    case_net_adam()
+CASES = {
+    "cell_v1": lambda n: case_bare_cell(n, O.V1, 4, 5, 8, 3, 3, 11),
+    "cell_v1_b1": lambda n: case_bare_cell(n, O.V1, 1, 5, 8, 3, 2, 12),
+    "cell_v1_ieqh": lambda n: case_bare_cell(n, O.V1, 3, 8, 8, 4, 5, 13),
+    "cell_v2": lambda n: case_bare_cell(n, O.V2, 4, 5, 12, 3, [2, 3], 14),
+    "cell_v3": lambda n: case_bare_cell(n, O.V3, 4, 8, 8, 3, 3, 15),
+    "cell_v4": lambda n: case_bare_cell(n, O.V4, 40, 12, 12, 3, [2, 3], 16),
+    "cell_v5": lambda n: case_bare_cell(n, O.V5, 4, 5, 8, 3, 3, 17),
+    "cell_v5_iwide": lambda n: case_bare_cell(n, O.V5, 3, 12, 8, 3, 4, 18),   # I > H: fine without vm_x
+    "cell_v6": lambda n: case_bare_cell(n, O.V6, 4, 5, 12, 3, [2, 3], 19),
+    "seq_v1": lambda n: case_har_seq(n, O.V1, 4, 6, 5, 8, 3, [3], 21),
+    "seq_v1_wide": lambda n: case_har_seq(n, O.V1, 5, 7, 20, 70, 5, [7], 22),       # H not a multiple of 64, odd ranks
+    "seq_v2": lambda n: case_har_seq(n, O.V2, 4, 6, 5, 12, 3, [2, 3], 23),
+    "seq_v2_demo": lambda n: case_har_seq(n, O.V2, 6, 8, 77, 180, 8, [2, 4], 24),   # demo.sh:10 shapes, short T
+    "seq_v1_demo": lambda n: case_har_seq(n, O.V1, 6, 8, 77, 180, 8, [6], 25),      # demo.sh:7 shapes, short T
+    "seq_v5": lambda n: case_har_seq(n, O.V5, 4, 6, 5, 8, 3, [3], 26),
+    "seq_v5_wide": lambda n: case_har_seq(n, O.V5, 5, 7, 20, 70, 5, [7], 27),
+    "seq_v6": lambda n: case_har_seq(n, O.V6, 4, 6, 5, 12, 3, [2, 3], 28),
+    "seq_v6_demo": lambda n: case_har_seq(n, O.V6, 6, 8, 77, 180, 8, [2, 4], 29),
+    "seq_v3": lambda n: case_lm_seq(n, O.V3, 4, 6, 8, 3, 3, 31),
+    "seq_v4": lambda n: case_lm_seq(n, O.V4, 40, 5, 12, 3, [2, 3], 32),
+    "lm_v3_carry": lambda n: case_lm_carry(n, 41),
+    "cfgA_v1_uci": lambda n: case_config_a(n),
+    "cfgA_v2_uci": lambda n: case_config_a_group(n),
+    "cfgA_v5_uci": lambda n: case_config_a_novm(n, O.V5),
+    "cfgA_v6_uci": lambda n: case_config_a_novm(n, O.V6),
+    "cfgC_v1_opp2": lambda n: case_config_c(n),
+    "cfgA_net_adam3": lambda n: case_net_adam(n),
     # BASELINE config E shape, one MyVMLSTMGroup layer at the only batch the reference executes (40)
-    case_lm_seq("cfgE_v4_b40", O.V4, 40, 35, 650, 32, [32, 32], 51, scale=0.05, full=False, xscale=0.05)
-    case_lm_seq("cfgE_v3_b64", O.V3, 64, 35, 650, 32, 32, 52, scale=0.05, full=False, xscale=0.05)
-    case_state_dict_names()
+    "cfgE_v4_b40": lambda n: case_lm_seq(n, O.V4, 40, 35, 650, 32, [32, 32], 51, scale=0.05, full=False, xscale=0.05),
+    "cfgE_v3_b64": lambda n: case_lm_seq(n, O.V3, 64, 35, 650, 32, 32, 52, scale=0.05, full=False, xscale=0.05),
+    "state_dict_names": lambda n: case_state_dict_names(n),
+}
+
+
+def main(argv):
+    os.makedirs(OUT, exist_ok=True)
+    for name in (argv or list(CASES)):
+        CASES[name](name)
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

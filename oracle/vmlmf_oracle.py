@@ -27,6 +27,10 @@ import numpy as np
 import torch
 
 V1, V2, V3, V4 = 1, 2, 3, 4  # MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGroup
+# the two "no vector-multiplication" comparison cells of the reference:
+V5, V6 = 5, 6                 # MyLSTMCell in low-rank mode, MyVMLMFgCellg2 (ablation)
+NOVM = (V5, V6)
+GATE_NAMES_V5 = ("i", "f", "o", "c")  # w1/u1 -> i, w2/u2 -> f, w3/u3 -> o, w4/u4 -> c~   (vmlmf.py:223-232)
 
 # ----------------------------------------------------------------------------------------------------
 # parameter containers
@@ -36,6 +40,8 @@ V1, V2, V3, V4 = 1, 2, 3, 4  # MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGro
 #   V2: dia_x dia_h u_x v_x u_h_{s} v_h_{s} bias_x bias_h          (V/src/models/vmlmf_group.py:61-79)
 #   V3: u_x u_h w_x w_h b_x b_h dia_x dia_h                        (V/src/models/vmlmf_lm.py:200-213)
 #   V4: u_x w_x u_h.{s} v_h.{s} b_x b_h dia_x dia_h                (V/src/models/vmlmf_lm.py:77-91)
+#   V5: w w1..w4 u u1..u4 bias_f bias_i bias_c bias_o              (V/src/models/vmlmf.py:159-186, low-rank mode)
+#   V6: u_x v_x u_h_{s} v_h_{s} bias_x bias_h                      (V/src/models/vmlmf_group.py:183-197)
 
 
 def param_shapes(variant, I, H, rw, ru, g=2):
@@ -45,9 +51,18 @@ def param_shapes(variant, I, H, rw, ru, g=2):
         vx, vh = ("v_x", "v_h") if variant == V1 else ("w_x", "w_h")
         return {"u_x": (I, rw), "u_h": (H, r), vx: (4 * H, rw), vh: (4 * H, r),
                 "b_x": (4 * H,), "b_h": (4 * H,), "dia_x": (1, I), "dia_h": (1, H)}
+    if variant == V5:
+        r = ru[0] if isinstance(ru, (list, tuple)) else ru
+        out = {"w": (I, rw)}
+        out.update({f"w{k}": (rw, H) for k in range(1, 5)})
+        out["u"] = (H, r)
+        out.update({f"u{k}": (r, H) for k in range(1, 5)})
+        out.update({f"bias_{n}": (1, H) for n in ("f", "i", "c", "o")})
+        return out
     Hg = H // g
-    if variant == V2:
-        out = {"dia_x": (1, I), "dia_h": (1, H), "u_x": (I, rw), "v_x": (4 * H, rw)}
+    if variant in (V2, V6):
+        out = {"dia_x": (1, I), "dia_h": (1, H), "u_x": (I, rw), "v_x": (4 * H, rw)} if variant == V2 else \
+              {"u_x": (I, rw), "v_x": (4 * H, rw)}
         for s in range(g):
             out[f"u_h_{s}"] = (g, Hg, ru[s])
             out[f"v_h_{s}"] = (g, ru[s], 4 * Hg)
@@ -221,7 +236,41 @@ def literal_step(variant, P, x, h, c, g=2, v4_scratch_rows=None):
         xi, xf, xo, xn = gx.squeeze().chunk(4, 1)
         hi, hf, ho, hn = gh.chunk(4, 1)
         return _lstm_tail(xi + hi, xf + hf, xo + ho, xn + hn, c)
+    if variant == V5:  # V/src/models/vmlmf.py:188-236, low-rank branches (198-207, 215-224)
+        xw = torch.matmul(x, P["w"])
+        w_val1 = torch.matmul(xw, P["w1"])
+        w_val2 = torch.matmul(xw, P["w2"])
+        w_val3 = torch.matmul(xw, P["w3"])
+        w_val4 = torch.matmul(xw, P["w4"])
+        hu = torch.matmul(h, P["u"])
+        u_val1 = torch.matmul(hu, P["u1"])
+        u_val2 = torch.matmul(hu, P["u2"])
+        u_val3 = torch.matmul(hu, P["u3"])
+        u_val4 = torch.matmul(hu, P["u4"])
+        return _lstm_tail(w_val1 + u_val1 + P["bias_i"], w_val2 + u_val2 + P["bias_f"],
+                          w_val3 + u_val3 + P["bias_o"], w_val4 + u_val4 + P["bias_c"], c)
+    if variant == V6:  # V/src/models/vmlmf_group.py:203-251
+        H = P["bias_h"].shape[1] // 4
+        gx = torch.matmul(torch.matmul(x, P["u_x"]), P["v_x"].t()) + P["bias_x"]
+        xf, xi, xn, xo = gx.chunk(4, 1)
+        acc = _rotated_group_product(h, [P[f"u_h_{s}"] for s in range(g)],
+                                     [P[f"v_h_{s}"] for s in range(g)], g, H, B)
+        f_h, i_h, n_h, o_h = acc.chunk(4, dim=2)
+        f_h = f_h.contiguous().view(B, H)
+        i_h = i_h.contiguous().view(B, H)
+        n_h = n_h.contiguous().view(B, H)
+        o_h = o_h.contiguous().view(B, H)
+        hf, hi, hn, ho = P["bias_h"].chunk(4, 1)
+        return _lstm_tail(xi + (hi + i_h), xf + (hf + f_h), xo + (ho + o_h), xn + (hn + n_h), c)
     raise ValueError(f"unknown variant {variant}")
+
+
+def hidden_size_of(variant, P):
+    if variant == V5:
+        return P["u"].shape[0]
+    if variant == V6:
+        return P["bias_h"].shape[1] // 4
+    return P["dia_h"].shape[1]
 
 
 def literal_sequence(variant, P, x, h0=None, c0=None, g=2, time_major=None, v4_scratch_rows=None):
@@ -235,7 +284,7 @@ def literal_sequence(variant, P, x, h0=None, c0=None, g=2, time_major=None, v4_s
         time_major = variant in (V3, V4)
     tdim = 0 if time_major else 1
     B = x.shape[1 - tdim]
-    H = P["dia_h"].shape[1]
+    H = hidden_size_of(variant, P)
     h = torch.zeros(B, H, dtype=x.dtype) if h0 is None else h0
     c = torch.zeros(B, H, dtype=x.dtype) if c0 is None else c0
     outs = []
@@ -275,7 +324,7 @@ class Canon:
 def _group_cols(variant, H, g, k, n):
     """(qsel, column inside the (r_s, 4H/g) matrices of that destination group) for gate k of unit n."""
     Hg = H // g
-    if variant == V2:
+    if variant in (V2, V6):
         return n // Hg, GATE_H_CHUNK_V2[k] * Hg + (n % Hg)
     return divmod(k * H + n, 4 * Hg)  # V4: flat [B, g*4Hg] then chunk(4): vmlmf_lm.py:135,155
 
@@ -284,16 +333,23 @@ def canonicalize(variant, P, g=2, dtype=np.float64):
     P = {k: np.asarray(v.detach().numpy() if isinstance(v, torch.Tensor) else v, dtype=dtype) for k, v in P.items()}
     C = Canon()
     C.variant = variant
-    H = P["dia_h"].shape[1]
-    I = P["dia_x"].shape[1]
-    vx_name = "v_x" if variant in (V1, V2) else "w_x"
-    rw = P["u_x"].shape[1]
+    C.novm = variant in NOVM
+    H = hidden_size_of(variant, P)
+    ux_name = "w" if variant == V5 else "u_x"
+    I, rw = P[ux_name].shape
     C.H, C.I, C.rw = H, I, rw
     C.KX = pad4(rw)
     C.ux = np.zeros((I, C.KX), dtype)
-    C.ux[:, :rw] = P["u_x"]
+    C.ux[:, :rw] = P[ux_name]
     C.vx = np.zeros((H, 4, C.KX), dtype)
-    C.vx[:, :, :rw] = P[vx_name].reshape(4, H, rw).transpose(1, 0, 2)
+    # x-side chunk that canonical gate k reads: V6 chunks gx as (f,i,n,o) (vmlmf_group.py:211)
+    C.xchunk = np.array(GATE_H_CHUNK_V2 if variant == V6 else (0, 1, 2, 3), np.int64)
+    if variant == V5:
+        for k in range(4):
+            C.vx[:, k, :rw] = P[f"w{k + 1}"].T
+    else:
+        vx_name = "v_x" if variant in (V1, V2, V6) else "w_x"
+        C.vx[:, :, :rw] = P[vx_name].reshape(4, H, rw)[C.xchunk].transpose(1, 0, 2)
     if variant in (V1, V3):
         C.g = 1
         vh_name = "v_h" if variant == V1 else "w_h"
@@ -301,13 +357,20 @@ def canonicalize(variant, P, g=2, dtype=np.float64):
         us = [P["u_h"][None]]                      # (1, H, r)
         vs = [P[vh_name].T[None]]                  # (1, r, 4H): column kH+n
         bx, bh = P["b_x"], P["b_h"]
+    elif variant == V5:
+        C.g = 1
+        ru = [P["u"].shape[1]]
+        us = [P["u"][None]]
+        vs = [np.concatenate([P[f"u{k + 1}"] for k in range(4)], axis=1)[None]]   # (1, r, 4H): column kH+n
+        bx = np.concatenate([P[f"bias_{n}"][0] for n in GATE_NAMES_V5])
+        bh = np.zeros_like(bx)
     else:
         C.g = g
-        sep = "_" if variant == V2 else "."
+        sep = "." if variant == V4 else "_"
         us = [P[f"u_h{sep}{s}"] for s in range(g)]
         vs = [P[f"v_h{sep}{s}"] for s in range(g)]
         ru = [u.shape[2] for u in us]
-        bx, bh = (P["bias_x"][0], P["bias_h"][0]) if variant == V2 else (P["b_x"], P["b_h"])
+        bx, bh = (P["bias_x"][0], P["bias_h"][0]) if variant in (V2, V6) else (P["b_x"], P["b_h"])
     G = C.g
     Hg = H // G
     C.ru = ru
@@ -322,7 +385,7 @@ def canonicalize(variant, P, g=2, dtype=np.float64):
     C.col = np.zeros((4, H), np.int64)
     C.hchunk = np.zeros(4, np.int64)
     for k in range(4):
-        C.hchunk[k] = GATE_H_CHUNK_V2[k] if variant == V2 else k
+        C.hchunk[k] = GATE_H_CHUNK_V2[k] if variant in (V2, V6) else k
     for n in range(H):
         grp, m = divmod(n, Hg)
         for s in range(G):
@@ -330,7 +393,7 @@ def canonicalize(variant, P, g=2, dtype=np.float64):
             C.dest[n, s] = j
             C.uc[n, C.off[s]:C.off[s] + ru[s]] = us[s][j, m, :]
         for k in range(4):
-            if variant in (V1, V3):
+            if variant in (V1, V3, V5):
                 q, col = 0, k * H + n
             else:
                 q, col = _group_cols(variant, H, G, k, n)
@@ -338,14 +401,16 @@ def canonicalize(variant, P, g=2, dtype=np.float64):
             for s in range(G):
                 C.vc[n, k, C.off[s]:C.off[s] + ru[s]] = vs[s][q, :, col]
     r0 = ru[0]
-    C.eh = P["dia_h"][0][:, None] - np.einsum("nr,nkr->nk", C.uc[:, :r0], C.vc[:, :, :r0])
+    C.eh = np.zeros((H, 4), dtype)
     C.ex = np.zeros((H, 4), dtype)
-    C.ex[:I] = P["dia_x"][0][:, None] - np.einsum("mr,mkr->mk", C.ux[:, :rw], C.vx[:I, :, :rw])
+    if not C.novm:   # the comparison cells have neither the vector multiplication nor the diagonal removal
+        C.eh = P["dia_h"][0][:, None] - np.einsum("nr,nkr->nk", C.uc[:, :r0], C.vc[:, :, :r0])
+        C.ex[:I] = P["dia_x"][0][:, None] - np.einsum("mr,mkr->mk", C.ux[:, :rw], C.vx[:I, :, :rw])
     if variant in (V3, V4):
         assert I == H, "vmlmf_lm.py:243 tiles vm_x four times: needs input_size == hidden_size"
     C.b = np.zeros((H, 4), dtype)
     for k in range(4):
-        C.b[:, k] = bx[k * H:(k + 1) * H] + bh[C.hchunk[k] * H:(C.hchunk[k] + 1) * H]
+        C.b[:, k] = bx[C.xchunk[k] * H:(C.xchunk[k] + 1) * H] + bh[C.hchunk[k] * H:(C.hchunk[k] + 1) * H]
     return C
 
 
@@ -376,7 +441,7 @@ def unified_forward(C, x, h0, c0):
     Qs = np.zeros((T, B, C.g, C.KH), dt)
     h, c = h0.astype(dt), c0.astype(dt)
     xpad = np.zeros((T, B, H), dt)
-    xpad[:, :, :C.I] = x
+    xpad[:, :, :min(C.I, H)] = x[:, :, :H]      # I > H only occurs for the cells without the x .* ex term
     for t in range(T):
         qx = x[t] @ C.ux                                           # (B, KX)
         Q = _rank_reduce(C, h)
@@ -432,13 +497,16 @@ def unified_backward(C, tape, dy, dhT, dcT):
             G["uc"][:, lo:hi] += np.einsum("bn,bnr->nr", h_prev, dQn)
         qx = x[t] @ C.ux
         dqx = np.einsum("bnk,nkr->br", dpre, C.vx)
-        dx[t] = dqx @ C.ux.T + (dpre[:, :I] * C.ex[None, :I]).sum(-1)
+        dx[t] = dqx @ C.ux.T
+        if not C.novm:
+            dx[t] += (dpre[:, :I] * C.ex[None, :I]).sum(-1)
         G["ux"] += x[t].T @ dqx
         G["vx"] += np.einsum("bnk,br->nkr", dpre, qx)
         for k in range(4):
             G["vc"][:, k, :] += np.einsum("bn,bnr->nr", dpre[:, :, k], Qs[t][:, C.qsel[k], :])
         G["eh"] += np.einsum("bnk,bn->nk", dpre, h_prev)
-        G["ex"][:I] += np.einsum("bnk,bn->nk", dpre[:, :I], x[t])
+        if not C.novm:
+            G["ex"][:I] += np.einsum("bnk,bn->nk", dpre[:, :I], x[t])
         G["b"] += dpre.sum(0)
     return dx, dh_rec, dc, G
 
@@ -450,23 +518,34 @@ def uncanonicalize_grads(C, G, P_like):
     r0 = C.ru[0]
     duc, dvc = G["uc"].copy(), G["vc"].copy()
     dux, dvx = G["ux"].copy(), G["vx"].copy()
-    ddia_h = G["eh"].sum(1)
-    duc[:, :r0] -= np.einsum("nk,nkr->nr", G["eh"], C.vc[:, :, :r0])
-    dvc[:, :, :r0] -= G["eh"][:, :, None] * C.uc[:, None, :r0]
-    ddia_x = G["ex"][:I].sum(1)
-    dux[:, :rw] -= np.einsum("mk,mkr->mr", G["ex"][:I], C.vx[:I, :, :rw])
-    dvx[:I, :, :rw] -= G["ex"][:I, :, None] * C.ux[:, None, :rw]
-    out = {}
-    vx_name = "v_x" if variant in (V1, V2) else "w_x"
-    out["u_x"] = dux[:, :rw]
-    out[vx_name] = dvx[:, :, :rw].transpose(1, 0, 2).reshape(4 * H, rw)
-    out["dia_x"] = ddia_x[None]
-    out["dia_h"] = ddia_h[None]
     db = G["b"]                                                     # (H,4)
-    dbx = db.T.reshape(4 * H)
+    if variant == V5:   # per-gate tensors, (rank, H) each
+        out = {"w": dux[:, :rw], "u": duc[:, :r0]}
+        for k in range(4):
+            out[f"w{k + 1}"] = dvx[:, k, :rw].T
+            out[f"u{k + 1}"] = dvc[:, k, :r0].T
+            out[f"bias_{GATE_NAMES_V5[k]}"] = db[:, k][None]
+        return out
+    out = {}
+    if not C.novm:
+        ddia_h = G["eh"].sum(1)
+        duc[:, :r0] -= np.einsum("nk,nkr->nr", G["eh"], C.vc[:, :, :r0])
+        dvc[:, :, :r0] -= G["eh"][:, :, None] * C.uc[:, None, :r0]
+        ddia_x = G["ex"][:I].sum(1)
+        dux[:, :rw] -= np.einsum("mk,mkr->mr", G["ex"][:I], C.vx[:I, :, :rw])
+        dvx[:I, :, :rw] -= G["ex"][:I, :, None] * C.ux[:, None, :rw]
+        out["dia_x"] = ddia_x[None]
+        out["dia_h"] = ddia_h[None]
+    vx_name = "v_x" if variant in (V1, V2, V6) else "w_x"
+    out["u_x"] = dux[:, :rw]
+    dvx_ref = np.zeros((4, H, rw), dvx.dtype)
+    dbx = np.zeros(4 * H, db.dtype)
     dbh = np.zeros(4 * H, db.dtype)
     for k in range(4):
+        dvx_ref[C.xchunk[k]] = dvx[:, k, :rw]
+        dbx[C.xchunk[k] * H:(C.xchunk[k] + 1) * H] = db[:, k]
         dbh[C.hchunk[k] * H:(C.hchunk[k] + 1) * H] = db[:, k]
+    out[vx_name] = dvx_ref.reshape(4 * H, rw)
     if variant in (V1, V3):
         vh_name = "v_h" if variant == V1 else "w_h"
         out["u_h"] = duc[:, :r0]
@@ -475,7 +554,7 @@ def uncanonicalize_grads(C, G, P_like):
         return out
     g = C.g
     Hg = H // g
-    sep = "_" if variant == V2 else "."
+    sep = "." if variant == V4 else "_"
     for s in range(g):
         du = np.zeros((g, Hg, C.ru[s]), duc.dtype)
         dv = np.zeros((g, C.ru[s], 4 * Hg), duc.dtype)
@@ -487,7 +566,7 @@ def uncanonicalize_grads(C, G, P_like):
                 dv[C.qsel[k, n], :, C.col[k, n]] = dvc[n, k, lo:lo + C.ru[s]]
         out[f"u_h{sep}{s}"] = du
         out[f"v_h{sep}{s}"] = dv
-    if variant == V2:
+    if variant in (V2, V6):
         out["bias_x"], out["bias_h"] = dbx[None], dbh[None]
     else:
         out["b_x"], out["b_h"] = dbx, dbh

@@ -11,14 +11,18 @@ ORDER = {
     O.V2: ["dia_x", "dia_h", "u_x", "v_x", "bias_x", "bias_h", "u_h_0", "v_h_0", "u_h_1", "v_h_1"],
     O.V3: ["dia_x", "dia_h", "u_x", "w_x", "b_x", "b_h", "u_h", "w_h"],
     O.V4: ["dia_x", "dia_h", "u_x", "w_x", "b_x", "b_h", "u_h.0", "v_h.0", "u_h.1", "v_h.1"],
+    O.V5: ["w", "u", "w1", "w2", "w3", "w4", "u1", "u2", "u3", "u4", "bias_i", "bias_f", "bias_o", "bias_c"],
+    O.V6: ["u_x", "v_x", "bias_x", "bias_h", "u_h_0", "v_h_0", "u_h_1", "v_h_1"],
 }
 
 
 def ranks_of(variant, P):
+    if variant == O.V5:
+        return P["w"].shape[1], [P["u"].shape[1]], 1
     rw = P["u_x"].shape[1]
     if variant in (O.V1, O.V3):
         return rw, [P["u_h"].shape[1]], 1
-    sep = "_" if variant == O.V2 else "."
+    sep = "." if variant == O.V4 else "_"
     return rw, [P[f"u_h{sep}0"].shape[2], P[f"u_h{sep}1"].shape[2]], 2
 
 

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in declared_functions():
         assert hasattr(handle, name), f"missing export {name}"
     lib = _lib.lib()
-    assert lib.vmlmf_abi_version() == 1
+    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 2
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
         "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",
@@ -50,6 +50,11 @@ def test_query_headline_geometry():
     # BASELINE config E (PTB group layer): too large for the register-resident kernels -> step-wise path
     s = _lib.query(_lib.make_desc(_lib.V4_LM_GROUP, 256, 35, 650, 650, 32, [32, 32], g=2, time_major=True))
     assert (s.kx, s.kh, s.threads_per_wg) == (32, 64, 768)
+    # the cells without vm share the geometry of their vm counterparts
+    s = _lib.query(_lib.make_desc(_lib.V5_LMF_CELL, 64, 128, 9, 180, 16, [16]))
+    assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kx, s.kh) == (1, 192, 64, 16, 16)
+    s = _lib.query(_lib.make_desc(_lib.V6_GROUP_NOVM, 64, 128, 9, 180, 16, [16, 16], g=2))
+    assert (s.threads_per_wg, s.kh) == (256, 32)
 
 
 @pytest.mark.parametrize("desc,code", [
@@ -57,6 +62,8 @@ def test_query_headline_geometry():
     (dict(variant=_lib.V3_LM, B=4, T=3, I=6, H=8, w_rank=3, u_ranks=[3]), _lib.E_SHAPE),          # vmlmf_lm.py:243
     (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=9, w_rank=3, u_ranks=[2, 2], g=2), _lib.E_SHAPE),
     (dict(variant=7, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
+    (dict(variant=_lib.V5_LMF_CELL, B=4, T=3, I=10, H=8, w_rank=3, u_ranks=[3]), _lib.E_UNSUPPORTED),  # valid in the reference
+    (dict(variant=_lib.V6_GROUP_NOVM, B=4, T=3, I=4, H=9, w_rank=3, u_ranks=[2, 2], g=2), _lib.E_SHAPE),
     (dict(variant=_lib.V1_CELL, B=0, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
     (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[0]), _lib.E_BADARG),
     (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=12, w_rank=3, u_ranks=[2, 2, 2], g=3), _lib.E_UNSUPPORTED),
@@ -78,3 +85,7 @@ def test_forward_refuses_null_buffers_without_touching_the_gpu():
                                0, None)
     assert rc == _lib.E_BADARG
     assert b"null" in lib.vmlmf_last_error()
+    d5 = _lib.make_desc(_lib.V5_LMF_CELL, 4, 3, 4, 8, 3, [3])
+    rc = lib.vmlmf_seq_forward(ctypes.byref(d5), ctypes.byref(p), None, None, None, None, None, None, None, None,
+                               0, None)
+    assert rc == _lib.E_BADARG and b"null pointer in params" in lib.vmlmf_last_error()

@@ -260,3 +260,53 @@ def test_graphed_train_step_matches_the_eager_loop():
         assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["seq_v5_wide", "seq_v6_demo"])
+def test_comparison_cells_through_mylstm_vs_reference(name):
+    """MyLSTM(cell=MyLSTMCell, low-rank) and MyLSTM(cell=MyVMLMFgCellg2) are one sequence
+    pipeline per layer on the same kernels; gradients land on the reference's own parameter tensors."""
+    from vmlmf_amd import MyLSTMCell, MyVMLMFgCellg2
+    d = load_golden(name)
+    meta = [int(v) for v in d["meta"]]
+    variant, B, T, I, H, rw = meta[:6]
+    ru = meta[6:]
+    cellcls = MyLSTMCell if variant == O.V5 else MyVMLMFgCellg2
+    rnn = MyLSTM(I, hidden_layer_sizes=[H], batch_first=True, w_rank=rw, u_ranks=ru, cell=cellcls)
+    load_cell(rnn.rnncells[0], d["P"])
+    rnn = rnn.to(DEV)
+    x = torch.tensor(d["x"], device=DEV, requires_grad=True)
+    y, hcat = rnn(x)
+    ((y * torch.tensor(d["dy"], device=DEV)).sum() + (hcat * torch.tensor(d["dhT"], device=DEV)).sum()).backward()
+    assert_out(y.detach().cpu().numpy(), d["y"], "y")
+    assert_out(hcat.detach().cpu().numpy(), d["hT"], "hT")
+    assert_grad(x.grad.cpu().numpy(), d["dx"], "dx")
+    named = dict(rnn.rnncells[0].named_parameters())
+    for k, v in d["G"].items():
+        p = named[k] if k in named else named["layers." + k]
+        assert_grad(p.grad.cpu().numpy(), v, "G." + k)
+
+
+@pytest.mark.parametrize("name", ["cell_v5", "cell_v6"])
+def test_comparison_cells_single_step_call(name):
+    """cell(x, (h, c)) -> (h', c'), the signature MyLSTM's loop in the reference uses (vmlmf.py:306)."""
+    from vmlmf_amd import MyLSTMCell, MyVMLMFgCellg2
+    d = load_golden(name)
+    meta = [int(v) for v in d["meta"]]
+    variant, B, _, I, H, rw = meta[:6]
+    ru = meta[6:]
+    cell = MyLSTMCell(I, H, w_rank=rw, u_ranks=ru[0]) if variant == O.V5 else MyVMLMFgCellg2(I, H, w_rank=rw, u_ranks=ru)
+    load_cell(cell, d["P"])
+    cell = cell.to(DEV)
+    h1, c1 = cell(torch.tensor(d["x"], device=DEV), (torch.tensor(d["h0"], device=DEV), torch.tensor(d["c0"], device=DEV)))
+    assert_out(h1.detach().cpu().numpy(), d["h1"], "h1")
+    assert_out(c1.detach().cpu().numpy(), d["c1"], "c1")
+
+
+def test_vanilla_baseline_cell_keeps_stock_ops_on_gpu():
+    """MyLSTMCell without ranks (dense gate matrices) is not on the HIP path: stock GEMMs, reference loop."""
+    from vmlmf_amd import MyLSTMCell
+    torch.manual_seed(3)
+    rnn = MyLSTM(9, hidden_layer_sizes=[32], cell=MyLSTMCell).to(DEV)
+    y, h = rnn(torch.randn(4, 6, 9, device=DEV))
+    assert y.shape == (4, 6, 32) and torch.isfinite(y).all()

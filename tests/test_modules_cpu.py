@@ -5,7 +5,8 @@ import pytest
 import torch
 
 import vmlmf_amd
-from vmlmf_amd import MyLSTM, MyLSTMCell, MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGroup, Net
+from vmlmf_amd import (MyLSTM, MyLSTMCell, MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyVMLSTM, MyVMLSTMGroup,
+                       Net)
 from conftest import load_golden
 
 
@@ -16,6 +17,8 @@ def test_state_dict_names_and_shapes_match_reference():
         "net_v2": Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFCellg2),
         "lm_v3": MyVMLSTM(16, 16, w_rank=4, u_ranks=4),
         "lm_v4": MyVMLSTMGroup(16, 16, w_rank=4, u_ranks=[2, 3]),
+        "net_v5": Net(77, layer_sizes=[180], w_rank=8, u_rank=6, model=MyLSTM, cell=MyLSTMCell),
+        "net_v6": Net(77, layer_sizes=[180], w_rank=8, u_rank=[2, 4], model=MyLSTM, cell=MyVMLMFgCellg2),
     }
     for tag, m in nets.items():
         mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
@@ -74,10 +77,30 @@ def test_product_package_never_imports_the_oracle():
 
 
 def test_baseline_cell_still_runs_inside_mylstm_on_cpu():
-    """MyLSTMCell is not the hot path (stock GEMMs): it keeps the reference's Python loop."""
+    """MyLSTMCell keeps the reference's Python loop of stock ops wherever it is not the HIP path: vanilla mode
+    anywhere, low-rank mode on CPU tensors (on a HIP device low-rank mode runs the sequence kernels)."""
     rnn = MyLSTM(5, hidden_layer_sizes=[8, 8], w_rank=3, u_ranks=[3], cell=MyLSTMCell)
     y, hc = rnn(torch.randn(2, 4, 5))
     assert y.shape == (2, 4, 8) and hc.shape == (2, 16)
+    vanilla = MyLSTM(5, hidden_layer_sizes=[8], cell=MyLSTMCell)
+    assert vanilla(torch.randn(2, 4, 5))[0].shape == (2, 4, 8)
+    with pytest.raises(RuntimeError, match="vanilla cell is not on the HIP path"):
+        vanilla.rnncells[0].sequence(torch.randn(2, 4, 5))
+
+
+def test_low_rank_baseline_cell_rejects_a_rank_list_like_the_reference():
+    """vmlmf.py:177: torch.randn([hidden_size, u_ranks]) with the raw list argument raises TypeError; through
+    MyLSTM a one-element list is unwrapped first (vmlmf.py:269) and works."""
+    with pytest.raises(TypeError):
+        MyLSTMCell(5, 8, w_rank=3, u_ranks=[3])
+    MyLSTMCell(5, 8, w_rank=3, u_ranks=3)
+
+
+def test_ablation_group_cell_has_no_cpu_path():
+    rnn = MyLSTM(5, hidden_layer_sizes=[8], w_rank=3, u_ranks=[2, 2], cell=MyVMLMFgCellg2)
+    assert not any("dia" in k for k in rnn.state_dict())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rnn(torch.randn(2, 4, 5))
 
 
 def test_widened_rows_have_no_cpu_path_either():

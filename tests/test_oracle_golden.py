@@ -34,7 +34,8 @@ def grad_close(Ga, Gb, what, rel=1e-4):
         assert np.abs(a - b).max() <= rel * scale + 1e-6, f"{what}.{k}: {np.abs(a - b).max():.3e} vs scale {scale:.3e}"
 
 
-CELLS = ["cell_v1", "cell_v1_b1", "cell_v1_ieqh", "cell_v2", "cell_v3", "cell_v4"]
+CELLS = ["cell_v1", "cell_v1_b1", "cell_v1_ieqh", "cell_v2", "cell_v3", "cell_v4", "cell_v5", "cell_v5_iwide",
+         "cell_v6"]
 
 
 @pytest.mark.parametrize("name", CELLS)
@@ -69,7 +70,8 @@ def test_unified_cell_matches_reference(name):
     grad_close(G, d["G"], name)
 
 
-HAR_SEQS = ["seq_v1", "seq_v1_wide", "seq_v2", "seq_v2_demo", "seq_v1_demo"]
+HAR_SEQS = ["seq_v1", "seq_v1_wide", "seq_v2", "seq_v2_demo", "seq_v1_demo", "seq_v5", "seq_v5_wide", "seq_v6",
+            "seq_v6_demo"]
 
 
 @pytest.mark.parametrize("name", HAR_SEQS)
@@ -167,6 +169,23 @@ def test_config_a_unified_fp64_vs_reference():
     close(hT, d["hT"], 2e-5, 1e-4, "hT")
     close(dx.transpose(1, 0, 2), d["dx"], 5e-5, 1e-4, "dx")
     grad_close(G, d["G"], "cfgA")
+
+
+@pytest.mark.parametrize("name", ["cfgA_v5_uci", "cfgA_v6_uci"])
+def test_config_a_comparison_cells_unified_fp64_vs_reference(name):
+    """The two cells without vm (plain low-rank LSTM, group ablation) at the UCI-HAR shape."""
+    d = load_golden(name)
+    variant, B, T, I, H, rw = (int(v) for v in d["meta"][:6])
+    ru = ru_of(d["meta"])
+    P = O.make_params(variant, I, H, rw, ru, seed=int(d["seeds"][0]))
+    x, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][2]))).standard_normal((B, T, H)).astype(np.float32)
+    z = np.zeros((B, H))
+    y, hT, cT, dx, _, _, G = O.unified_run(variant, P, x.transpose(1, 0, 2), z, z, dy.transpose(1, 0, 2), z, z)
+    close(y.transpose(1, 0, 2)[:, ::16], d["y_s"], 2e-5, 1e-4, "y")
+    close(hT, d["hT"], 2e-5, 1e-4, "hT")
+    close(dx.transpose(1, 0, 2), d["dx"], 5e-5, 1e-4, "dx")
+    grad_close(G, d["G"], name)
 
 
 def test_net_adam_three_steps_literal():

@@ -6,7 +6,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import numpy as np
 import torch
 import vmlmf_oracle as O
-from vmlmf_amd import MyLSTM, MyVMLMFCell, MyVMLMFCellg2, MyVMLSTM, MyVMLSTMGroup
+from vmlmf_amd import MyLSTM, MyLSTMCell, MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyVMLSTM, MyVMLSTMGroup
 
 DEV = "cuda"
 
@@ -56,7 +56,7 @@ def har(name, cellcls, B, T, I, layers, rw, ru, variant, cpu=True):
         Ps = []
         in_size = I
         for H in layers:
-            Ps.append(O.to_torch(O.make_params(variant, in_size, H, rw, ru if variant == O.V2 else ru[0]), requires_grad=True))
+            Ps.append(O.to_torch(O.make_params(variant, in_size, H, rw, ru if variant in (O.V2, O.V6) else ru[0]), requires_grad=True))
             in_size = H
         xc = x.cpu()
         def cpu_step():
@@ -114,5 +114,9 @@ if __name__ == "__main__":
     har("D@1GPU: UCI V1 B=512", MyVMLMFCell, 512, 128, 9, [180], 16, [16], O.V1, cpu=False)
     har("demo.sh: OPP V1 H=180 w8 u6 B=81 T=24", MyVMLMFCell, 81, 24, 77, [180], 8, [6], O.V1)
     har("demo.sh: OPP V2 H=180 w8 u[2,4] B=81", MyVMLMFCellg2, 81, 24, 77, [180], 8, [2, 4], O.V2)
+    if "--compare" in sys.argv:   # the reference's compression-vs-speed comparison: same shape, cells without vm
+        har("A-lmf: UCI MyLSTMCell low-rank H=180 r=16 B=64", MyLSTMCell, 64, 128, 9, [180], 16, [16], O.V5)
+        har("A-group-novm: UCI MyVMLMFgCellg2 H=180 r=[16,16] B=64", MyVMLMFgCellg2, 64, 128, 9, [180], 16, [16, 16], O.V6)
+        sys.exit(0)
     lm("E: PTB V4 group H=650 r=32/[32,32] B=256 T=35 (2 layers)", MyVMLSTMGroup, O.V4, 256, 35, 650, 32, [32, 32], 2, cpu_B=40)
     lm("E-shape: PTB V3 H=650 r=32 B=256 T=35 (2 layers)", MyVMLSTM, O.V3, 256, 35, 650, 32, 32, 2, cpu_B=64)

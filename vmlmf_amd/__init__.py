@@ -4,11 +4,11 @@ MI355X (gfx950), behind the reference's own nn.Module API.
     from vmlmf_amd import MyVMLMFCell, MyVMLMFCellg2, MyLSTM, Net      # HAR   (models/vmlmf*.py)
     from vmlmf_amd import MyVMLSTM, MyVMLSTMGroup                      # LM    (models/vmlmf_lm.py)
 """
-from .cells import MyVMLMFCell, MyVMLMFCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
+from .cells import MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
 from .lm import MyVMLSTM, MyVMLSTMGroup
 from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss
 from . import optim
 from .graphed import GraphedTrainStep
 
-__all__ = ["GraphedTrainStep", "optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
+__all__ = ["GraphedTrainStep", "optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyVMLMFgCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
            "vmlmf_sequence"]

@@ -16,7 +16,8 @@ MAX_G = 2
 NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
-V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP = 1, 2, 3, 4
+V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
+ABI_VERSION = 2
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
 
 _fp = ctypes.POINTER(ctypes.c_float)
@@ -32,7 +33,8 @@ class Desc(ctypes.Structure):
 class Params(ctypes.Structure):
     _fields_ = [("dia_x", ctypes.c_void_p), ("dia_h", ctypes.c_void_p), ("u_x", ctypes.c_void_p),
                 ("v_x", ctypes.c_void_p), ("b_x", ctypes.c_void_p), ("b_h", ctypes.c_void_p),
-                ("u_h", ctypes.c_void_p * MAX_G), ("v_h", ctypes.c_void_p * MAX_G)]
+                ("u_h", ctypes.c_void_p * MAX_G), ("v_h", ctypes.c_void_p * MAX_G),
+                ("w_gate", ctypes.c_void_p * 4), ("u_gate", ctypes.c_void_p * 4), ("b_gate", ctypes.c_void_p * 4)]
 
 
 class Sizes(ctypes.Structure):
@@ -99,7 +101,7 @@ def lib():
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(handle, name)  # AttributeError if the export is missing
             fn.restype, fn.argtypes = res, args
-        if handle.vmlmf_abi_version() != 1:
+        if handle.vmlmf_abi_version() != ABI_VERSION:
             raise RuntimeError("libvmlmf_hip.so ABI version mismatch: rebuild")
         _lib = handle
     return _lib

@@ -3,7 +3,9 @@
 Same constructor signatures, forward signatures, attribute names and parameter names/shapes as
   MyVMLMFCell    V/src/models/vmlmf.py:38-125
   MyVMLMFCellg2  V/src/models/vmlmf_group.py:37-155
-  MyLSTMCell     V/src/models/vmlmf.py:127-238   (baseline cell: stock GEMMs, not the hot path)
+  MyVMLMFgCellg2 V/src/models/vmlmf_group.py:158-251   (ablation: the group cell without vm)
+  MyLSTMCell     V/src/models/vmlmf.py:127-238   (baseline cell; its low-rank mode runs the same kernels,
+                                                  its vanilla mode is stock GEMMs and not the hot path)
   MyLSTM         V/src/models/vmlmf.py:241-316
   Net            V/src/models/vmlmf.py:319-355
 so a reference checkpoint loads with load_state_dict and train.py / test.py run unchanged.
@@ -127,9 +129,51 @@ class MyVMLMFCellg2(nn.Module):
         return h_next, c_next
 
 
+class MyVMLMFgCellg2(MyVMLMFCellg2):
+    """The group cell without the vector multiplication (the reference's ablation): no dia_x / dia_h, no
+    diagonal removal, and BOTH sides chunk their pre-activations as (f, i, n, o) (vmlmf_group.py:211,232)."""
+
+    variant = _lib.V6_GROUP_NOVM
+
+    def __init__(self, input_size, hidden_size, w_rank=None, u_ranks=None, g=2,
+                 recurrent_init=None, hidden_init=None):
+        nn.Module.__init__(self)
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.recurrent_init = recurrent_init
+        self.hidden_init = hidden_init
+        self.w_rank = w_rank
+        self.u_ranks = u_ranks
+        self.g = g
+        self.layers = nn.ParameterDict()
+        self.layers['u_x'] = nn.Parameter(0.1 * torch.randn([input_size, w_rank]))
+        self.layers['v_x'] = nn.Parameter(0.1 * torch.randn([4 * hidden_size, w_rank]))
+        for s in range(self.g):
+            self.layers[f'u_h_{s}'] = nn.Parameter(0.1 * torch.randn([g, int(hidden_size / g), u_ranks[s]]))
+            self.layers[f'v_h_{s}'] = nn.Parameter(0.1 * torch.randn([g, u_ranks[s], 4 * int(hidden_size / g)]))
+        for vec in ['x', 'h']:
+            self.layers[f'bias_{vec}'] = nn.Parameter(torch.ones([1, 4 * hidden_size]))
+
+    def __repr__(self):
+        return (f"LSTM VM Group (input:{self.input_size}, hidden:{self.hidden_size}, "
+                f"w_rank:{self.w_rank}, u_ranks:{self.u_ranks})")
+
+    def kernel_params(self):
+        L = self.layers
+        out = [L['u_x'], L['v_x'], L['bias_x'], L['bias_h']]
+        for s in range(self.g):
+            out += [L[f'u_h_{s}'], L[f'v_h_{s}']]
+        return tuple(out)
+
+
 class MyLSTMCell(nn.Module):
-    """Vanilla / plain low-rank LSTM cell of the reference (baseline, dense GEMMs through rocBLAS).
-    Outside the VMLMF hot path; kept so that MyLSTM(cell=MyLSTMCell) and Net's default keep working."""
+    """Vanilla / plain low-rank LSTM cell of the reference (the baselines VMLMF is compared with).
+
+    Low-rank mode (w_rank and u_ranks given) is the VMLMF recurrence with d = 0 and no diagonal removal: on a HIP
+    device it runs the same sequence kernels (variant 5, per-gate V factors passed as they are).  Vanilla mode
+    (dense (I,H)/(H,H) gate matrices) is outside the hot path and stays stock GEMMs through rocBLAS."""
+
+    variant = _lib.V5_LMF_CELL
 
     def __init__(self, input_size, hidden_size, w_rank=None, u_ranks=None,
                  recurrent_init=None, hidden_init=None):
@@ -153,7 +197,7 @@ class MyLSTMCell(nn.Module):
         if u_ranks is None:
             self.u1, self.u2, self.u3, self.u4 = mk(H, H), mk(H, H), mk(H, H), mk(H, H)
         else:
-            r = self.u_ranks
+            r = u_ranks   # the raw argument, as the reference does: a list raises TypeError here (vmlmf.py:177)
             self.u = mk(H, r)
             self.u1, self.u2, self.u3, self.u4 = mk(r, H), mk(r, H), mk(r, H), mk(r, H)
         self.bias_f = nn.Parameter(torch.ones([1, H]))
@@ -161,8 +205,32 @@ class MyLSTMCell(nn.Module):
         self.bias_c = nn.Parameter(torch.ones([1, H]))
         self.bias_o = nn.Parameter(torch.ones([1, H]))
 
+    @property
+    def low_rank(self):
+        return self.w_rank is not None and self.u_ranks is not None
+
+    def kernel_params(self):
+        return (self.w, self.u, self.w1, self.w2, self.w3, self.w4, self.u1, self.u2, self.u3, self.u4,
+                self.bias_i, self.bias_f, self.bias_o, self.bias_c)
+
+    def kernel_cfg(self):
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1)
+
+    def sequence(self, x, h0=None, c0=None, time_major=False):
+        """Whole-sequence evaluation on the HIP kernels (low-rank mode only): (y, hT, cT)."""
+        if not self.low_rank:
+            raise RuntimeError("vmlmf_amd: MyLSTMCell.sequence needs w_rank and u_ranks (the vanilla cell is "
+                               "not on the HIP path)")
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+                              **self.kernel_cfg())
+
     def forward(self, x, hidden_states):
         (h, c) = hidden_states
+        if self.low_rank and x.is_cuda:
+            if x.dim() == 1:
+                x = x.unsqueeze(0)
+            _, h_next, c_next = self.sequence(x.unsqueeze(1), h, c)
+            return h_next, c_next
         xin = x if self.w_rank is None else torch.matmul(x, self.w)
         hin = h if self.u_ranks is None else torch.matmul(h, self.u)
         pre = [torch.matmul(xin, w) + torch.matmul(hin, u)
@@ -176,8 +244,9 @@ class MyLSTMCell(nn.Module):
 
 
 class MyLSTM(nn.Module):
-    """Stack of layers over a sequence.  VMLMF cells run one fused sequence pipeline per layer; any other
-    cell class falls back to the reference's per-timestep loop over that cell's own forward."""
+    """Stack of layers over a sequence.  VMLMF cells (and the low-rank baseline cell on a HIP device) run one fused
+    sequence pipeline per layer; any other cell class keeps the reference's per-timestep loop over that cell's
+    own forward."""
 
     def __init__(self, input_size, hidden_layer_sizes=None, batch_first=True,
                  recurrent_inits=None, hidden_inits=None, w_rank=None, u_ranks=None,
@@ -208,7 +277,8 @@ class MyLSTM(nn.Module):
         """(output sequence of the last layer, [final h of every layer])."""
         hiddens = []
         for i, cell in enumerate(self.rnncells):
-            if hasattr(cell, "sequence"):
+            fused = hasattr(cell, "sequence") and (not isinstance(cell, MyLSTMCell) or (cell.low_rank and x.is_cuda))
+            if fused:
                 x, h, _ = cell.sequence(x, None, None, time_major=not self.batch_first)
             else:
                 B = x.size(self.batch_index)

@@ -77,18 +77,25 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.I = d->I;
   g.H = d->H;
   g.rw = d->w_rank;
-  if (g.variant < 1 || g.variant > 4) return fail(VMLMF_E_BADARG, "variant must be 1..4");
+  if (g.variant < 1 || g.variant > 6) return fail(VMLMF_E_BADARG, "variant must be 1..6");
   if (g.B < 1 || g.T < 1 || g.I < 1 || g.H < 1 || g.rw < 1)
     return fail(VMLMF_E_BADARG, "B, T, I, H, w_rank must be positive");
-  const bool grouped = g.variant == VMLMF_V2_GROUP_CELL || g.variant == VMLMF_V4_LM_GROUP;
+  const bool grouped = g.variant == VMLMF_V2_GROUP_CELL || g.variant == VMLMF_V4_LM_GROUP ||
+                       g.variant == VMLMF_V6_GROUP_NOVM;
   const bool lm = g.variant == VMLMF_V3_LM || g.variant == VMLMF_V4_LM_GROUP;
+  g.novm = (g.variant == VMLMF_V5_LMF_CELL || g.variant == VMLMF_V6_GROUP_NOVM) ? 1 : 0;
+  g.pergate = g.variant == VMLMF_V5_LMF_CELL ? 1 : 0;
+  g.xperm = g.variant == VMLMF_V6_GROUP_NOVM ? 1 : 0;
   g.G = grouped ? d->g : 1;
   if (grouped && g.G < 1) return fail(VMLMF_E_BADARG, "g must be positive");
   if (g.G > VMLMF_MAX_G)
     return fail(VMLMF_E_UNSUPPORTED, "g > 2 is not covered by the HIP kernels (the reference never builds it)");
   if (g.H % g.G != 0) return fail(VMLMF_E_SHAPE, "hidden_size must be divisible by g (vmlmf_group.py:73)");
   // the reference fails on these shapes too (vmlmf.py:94 / vmlmf_lm.py:243)
-  if (!lm && g.I > g.H) return fail(VMLMF_E_SHAPE, "input_size > hidden_size: the reference cell raises (vmlmf.py:94,103)");
+  if (!lm && !g.novm && g.I > g.H)
+    return fail(VMLMF_E_SHAPE, "input_size > hidden_size: the reference cell raises (vmlmf.py:94,103)");
+  if (g.novm && g.I > g.H)
+    return fail(VMLMF_E_UNSUPPORTED, "input_size > hidden_size is not covered by the HIP kernels (cells without vm)");
   if (lm && g.I != g.H) return fail(VMLMF_E_SHAPE, "LM layers need input_size == hidden_size (vmlmf_lm.py:243)");
   g.ru0 = d->u_ranks[0];
   g.ru1 = g.G == 2 ? d->u_ranks[1] : 0;
@@ -105,7 +112,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.NPX = (g.KX + 15) / 16;
   g.KQX = g.NPX * 16;
   g.flat = g.variant == VMLMF_V4_LM_GROUP ? 1 : 0;
-  g.hperm = g.variant == VMLMF_V2_GROUP_CELL ? 1 : 0;
+  g.hperm = (g.variant == VMLMF_V2_GROUP_CELL || g.variant == VMLMF_V6_GROUP_NOVM) ? 1 : 0;
   g.time_major = d->time_major ? 1 : 0;
   g.training = d->training ? 1 : 0;
   if (g.time_major) {
@@ -213,16 +220,28 @@ RefP to_refp(const vmlmf_params* p) {
   RefP r;
   r.dia_x = p->dia_x, r.dia_h = p->dia_h, r.u_x = p->u_x, r.v_x = p->v_x, r.b_x = p->b_x, r.b_h = p->b_h;
   r.u_h0 = p->u_h[0], r.u_h1 = p->u_h[1], r.v_h0 = p->v_h[0], r.v_h1 = p->v_h[1];
+  for (int k = 0; k < 4; ++k) r.wg[k] = p->w_gate[k], r.ug[k] = p->u_gate[k], r.bg[k] = p->b_gate[k];
   return r;
 }
 
-int check_params(const VGeo& g, const vmlmf_params* p) {
-  if (p == nullptr) return fail(VMLMF_E_BADARG, "null params");
-  if (!p->dia_x || !p->dia_h || !p->u_x || !p->v_x || !p->b_x || !p->b_h || !p->u_h[0] || !p->v_h[0])
-    return fail(VMLMF_E_BADARG, "null parameter pointer");
-  if (g.G == 2 && (!p->u_h[1] || !p->v_h[1])) return fail(VMLMF_E_BADARG, "group variant needs u_h[1], v_h[1]");
+// vmlmf_params and vmlmf_grads have the same members; one check serves both
+template <class P>
+int check_pointers(const VGeo& g, const P* p, const char* what) {
+  if (p == nullptr) return fail(VMLMF_E_BADARG, std::string("null ") + what);
+  bool ok = p->u_x && p->u_h[0];
+  if (g.pergate) {
+    for (int k = 0; k < 4; ++k) ok = ok && p->w_gate[k] && p->u_gate[k] && p->b_gate[k];
+  } else {
+    ok = ok && p->v_x && p->b_x && p->b_h && p->v_h[0];
+    if (!g.novm) ok = ok && p->dia_x && p->dia_h;
+  }
+  if (!ok) return fail(VMLMF_E_BADARG, std::string("null pointer in ") + what);
+  if (g.G == 2 && (!p->u_h[1] || !p->v_h[1]))
+    return fail(VMLMF_E_BADARG, std::string(what) + ": group variant needs u_h[1], v_h[1]");
   return 0;
 }
+
+int check_params(const VGeo& g, const vmlmf_params* p) { return check_pointers(g, p, "params"); }
 
 int hip_fail(int rc, const char* what) {
   if (rc == 0) return 0;
@@ -330,9 +349,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || reserve == nullptr || workspace == nullptr || gr == nullptr)
     return fail(VMLMF_E_BADARG, "null x / y / reserve / workspace / grads");
-  if (!gr->dia_x || !gr->dia_h || !gr->u_x || !gr->v_x || !gr->b_x || !gr->b_h || !gr->u_h[0] || !gr->v_h[0] ||
-      (g.G == 2 && (!gr->u_h[1] || !gr->v_h[1])))
-    return fail(VMLMF_E_BADARG, "null gradient pointer");
+  if ((rc = check_pointers(g, gr, "grads")) != 0) return rc;
   const VPack P = vg_pack_layout(g);
   const Layout L = make_layout(g, P);
   if (workspace_bytes < (size_t)L.b_total * sizeof(float))
@@ -386,6 +403,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   RefG og;
   og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
   og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+  for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   {
     Scope sc(7, s);
     if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, s), "finish")) != 0) return rc;

@@ -8,9 +8,11 @@
 // Parameter pointers in the reference's layouts (include/vmlmf_hip.h: vmlmf_params).
 struct RefP {
   const float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h, *u_h0, *u_h1, *v_h0, *v_h1;
+  const float *wg[4], *ug[4], *bg[4];   // V5: per-gate tensors
 };
 struct RefG {
   float *dia_x, *dia_h, *u_x, *v_x, *b_x, *b_h, *u_h0, *u_h1, *v_h0, *v_h1;
+  float *wg[4], *ug[4], *bg[4];
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -161,12 +163,18 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
 // canonical element <- reference layouts (oracle/vmlmf_oracle.py: canonicalize)
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int vg_hchunk(const VGeo& g, int k) { return g.hperm ? (k ^ 1) : k; }
+__device__ __forceinline__ int vg_xchunk(const VGeo& g, int k) { return g.xperm ? (k ^ 1) : k; }
+// per-gate pointer picked without indexing the kernel-argument array dynamically
+template <class T>
+__device__ __forceinline__ T* vg_gate(T* const (&a)[4], int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
 
 __device__ inline float ref_ux(const VGeo& g, const RefP& p, int m, int r) {
   return r < g.rw ? p.u_x[(size_t)m * g.rw + r] : 0.f;
 }
 __device__ inline float ref_vx(const VGeo& g, const RefP& p, int n, int k, int r) {
-  return r < g.rw ? p.v_x[((size_t)k * g.H + n) * g.rw + r] : 0.f;
+  if (r >= g.rw) return 0.f;
+  if (g.pergate) return vg_gate(p.wg, k)[(size_t)r * g.H + n];
+  return p.v_x[((size_t)vg_xchunk(g, k) * g.H + n) * g.rw + r];
 }
 // unit n's contribution weight to rank rr of the concatenated rank space
 __device__ inline float ref_uc(const VGeo& g, const RefP& p, int n, int rr) {
@@ -196,6 +204,7 @@ __device__ inline float ref_vc(const VGeo& g, const RefP& p, int n, int k, int r
   const int r = rr - (s ? g.off1 : 0);
   const int rus = s ? g.ru1 : g.ru0;
   if (r >= rus) return 0.f;
+  if (g.pergate) return vg_gate(p.ug, k)[(size_t)r * g.H + n];
   const float* v = s ? p.v_h1 : p.v_h0;
   if (g.G == 1) return v[((size_t)k * g.H + n) * rus + r];
   int q, col;
@@ -203,12 +212,14 @@ __device__ inline float ref_vc(const VGeo& g, const RefP& p, int n, int k, int r
   return v[((size_t)q * rus + r) * (4 * g.Hg) + col];
 }
 __device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
-  return p.b_x[k * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
+  if (g.pergate) return vg_gate(p.bg, k)[n];
+  return p.b_x[vg_xchunk(g, k) * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
 }
 // hoisted diagonal-removal vectors (vmlmf.py:102-106 recomputes them every timestep).
 // All loads are issued before the first FMA (fixed trip count 32 = the rank limit, predicated): a
 // run-time-bounded loop would serialise 2 dependent global loads per rank (~1 us each) in pack_kernel.
 __device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
+  if (g.novm) return 0.f;
   float acc = 0.f;
   for (int r0 = 0; r0 < g.ru0; r0 += 32) {   // ranks in blocks of 32: loads of a block are issued together
     float u[32], v[32];
@@ -223,7 +234,7 @@ __device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
   return p.dia_h[n] - acc;
 }
 __device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {
-  if (n >= g.I) return 0.f;
+  if (n >= g.I || g.novm) return 0.f;
   float u[32], v[32];
 #pragma unroll
   for (int r = 0; r < 32; ++r) {

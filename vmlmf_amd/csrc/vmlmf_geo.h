@@ -16,7 +16,10 @@ struct VGeo {
   int ru0, ru1, off1;
   int KX, KH, NP, KQ, NPX, KQX;
   int flat;   // V4: [B, g*4Hg] flattened then chunked (vmlmf_lm.py:135,155): gate k picks Q[k / 2]
-  int hperm;  // V2: h-side chunks are (f,i,n,o) (vmlmf_group.py:134,149-152)
+  int hperm;  // V2, V6: h-side chunks are (f,i,n,o) (vmlmf_group.py:134,149-152)
+  int xperm;  // V6: so are the x-side chunks (vmlmf_group.py:211)
+  int novm;   // V5, V6: no dia_x / dia_h and no diagonal removal: ex = eh = 0, nothing folds back in finish_kernel
+  int pergate;  // V5: V factors and biases come as four (rank, H) / (1, H) tensors, one per gate (vmlmf.py:159-186)
   int R;      // batch rows per workgroup
   int nwg;    // workgroups of the recurrent kernels
   int Bp;     // nwg * R: batch rows of the internal (slot-padded) buffers [T][Bp][NT]

@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
           const int j = (int)(le / NT), slot = (int)(le % NT), m = j >> 2, kk = j & 3;
           int nn;
           if (vg_slot_unit(g, slot, nn)) {
-            if (nn == m) {
+            if (nn == m && !g.novm) {
               v = p.dia_x[nn];      // diag(d_x) + (U V^T with its diagonal removed): the diagonal is d_x itself
             } else {
               float u[32], w[32];
@@ -283,6 +283,22 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
 // ---------------------------------------------------------------------------------------------------
 // finish: canonical gradients -> reference layouts (oracle: uncanonicalize_grads)
 // ---------------------------------------------------------------------------------------------------
+// element e of the x-side V gradient -> (gate k, unit n, rank r) and where the reference keeps it
+__device__ __forceinline__ float* vx_dest(const VGeo& g, const RefG& o, long long e, int& k, int& n, int& r) {
+  if (g.pergate) {  // w{k+1}[r][n]
+    k = (int)(e / ((long long)g.rw * g.H));
+    const int rem = (int)(e % ((long long)g.rw * g.H));
+    r = rem / g.H;
+    n = rem % g.H;
+    return vg_gate(o.wg, k) + rem;
+  }
+  const int row = (int)(e / g.rw), c = row / g.H;
+  r = (int)(e % g.rw);
+  k = vg_xchunk(g, c);   // chunk c of the reference's (4H, rw) matrix holds canonical gate c ^ xperm
+  n = row % g.H;
+  return o.v_x + e;
+}
+
 __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
   auto CG = [&](int a, int n) { return cg[(size_t)a * NT + vg_slot(g, n)]; };
@@ -302,18 +318,20 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
       if (lane == 0) {
-        for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
+        if (!g.novm)
+          for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
         o.u_x[eo] = v;
       }
       return;
     }
     e -= n_ux * 64;
     if (e < n_vx) {  // dv_x[k*H+n][r] = sum_m G[k][m](n) ux(m,r) - ...
-      const int row = (int)(e / rw), r = (int)(e % rw), k = row / H, n = row % H;
+      int k, n, r;
+      float* dst = vx_dest(g, o, e, k, n, r);
       float v = 0.f;
       for (int m = 0; m < I; ++m) v = fmaf(CG(va_vx(g, k, m), n), ref_ux(g, p, m, r), v);
-      if (n < I) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
-      o.v_x[e] = v;
+      if (n < I && !g.novm) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
+      *dst = v;
       return;
     }
     e += n_ux;   // fall through to the branches below with the offsets they expect
@@ -322,27 +340,31 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
     if (g.foldx) return;
     const int m = (int)(e / rw), r = (int)(e % rw);
     float v = CG(va_ux(g, r), m);
-    for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
+    if (!g.novm)
+      for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
     o.u_x[e] = v;
     return;
   }
   e -= n_ux;
   if (e < n_vx) {  // dv_x[k*H+n][r]
     if (g.foldx) return;
-    const int row = (int)(e / rw), r = (int)(e % rw), k = row / H, n = row % H;
+    int k, n, r;
+    float* dst = vx_dest(g, o, e, k, n, r);
     float v = CG(va_vx(g, k, r), n);
-    if (n < I) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
-    o.v_x[e] = v;
+    if (n < I && !g.novm) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
+    *dst = v;
     return;
   }
   e -= n_vx;
   if (e < n_dx) {
+    if (g.novm) return;
     const int m = (int)e;
     o.dia_x[m] = (CG(va_ex(g, 0), m) + CG(va_ex(g, 1), m)) + (CG(va_ex(g, 2), m) + CG(va_ex(g, 3), m));
     return;
   }
   e -= n_dx;
   if (e < n_dh) {
+    if (g.novm) return;
     const int n = (int)e;
     o.dia_h[n] = (CG(va_eh(g, 0), n) + CG(va_eh(g, 1), n)) + (CG(va_eh(g, 2), n) + CG(va_eh(g, 3), n));
     return;
@@ -351,8 +373,12 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   if (e < n_b) {
     const int k = (int)(e / H), n = (int)(e % H);
     const float v = CG(va_b(g, k), n);
-    o.b_x[k * H + n] = v;
-    o.b_h[vg_hchunk(g, k) * H + n] = v;
+    if (g.pergate) {
+      vg_gate(o.bg, k)[n] = v;
+    } else {
+      o.b_x[vg_xchunk(g, k) * H + n] = v;
+      o.b_h[vg_hchunk(g, k) * H + n] = v;
+    }
     return;
   }
   e -= n_b;
@@ -374,7 +400,7 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
         n = ((j + s) % g.G) * Hg + m;
       }
       float v = CG(va_uc(g, base + r), n);
-      if (s == 0)
+      if (s == 0 && !g.novm)
         for (int k = 0; k < 4; ++k) v -= CG(va_eh(g, k), n) * ref_vc(g, p, n, k, r);
       ou[e] = v;
       return;
@@ -382,7 +408,14 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
     e -= n_u;
     if (e < n_v) {
       int n, k, r;
-      if (g.G == 1) {
+      float* dst = ov + e;
+      if (g.pergate) {  // u{k+1}[r][n]
+        k = (int)(e / ((long long)rus * H));
+        const int rem = (int)(e % ((long long)rus * H));
+        r = rem / H;
+        n = rem % H;
+        dst = vg_gate(o.ug, k) + rem;
+      } else if (g.G == 1) {
         const int row = (int)(e / rus);
         r = (int)(e % rus);
         k = row / H;
@@ -403,8 +436,8 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
         }
       }
       float v = CG(va_vc(g, k, base + r), n);
-      if (s == 0) v -= CG(va_eh(g, k), n) * ref_uc(g, p, n, r);
-      ov[e] = v;
+      if (s == 0 && !g.novm) v -= CG(va_eh(g, k), n) * ref_uc(g, p, n, r);
+      *dst = v;
       return;
     }
     e -= n_v;

@@ -12,7 +12,9 @@ import torch
 from . import _lib
 
 # order in which parameter tensors are passed to VmlmfSeqFn (and gradients come back)
-#   dia_x dia_h u_x v_x b_x b_h u_h[0] v_h[0] (u_h[1] v_h[1])
+#   V1-V4: dia_x dia_h u_x v_x b_x b_h u_h[0] v_h[0] (u_h[1] v_h[1])
+#   V6:    u_x v_x b_x b_h u_h[0] v_h[0] u_h[1] v_h[1]                       (no vm vectors)
+#   V5:    w u w1 w2 w3 w4 u1 u2 u3 u4 bias_i bias_f bias_o bias_c          (gate order of the kernels: i, f, o, c~)
 N_FIXED = 6
 
 
@@ -20,15 +22,32 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _params_struct(tensors, g):
+def _params_struct(tensors, g, variant=_lib.V1_CELL):
     p = _lib.Params()
+    if variant == _lib.V5_LMF_CELL:
+        p.u_x, p.u_h[0] = tensors[0].data_ptr(), tensors[1].data_ptr()
+        for k in range(4):
+            p.w_gate[k] = tensors[2 + k].data_ptr()
+            p.u_gate[k] = tensors[6 + k].data_ptr()
+            p.b_gate[k] = tensors[10 + k].data_ptr()
+        return p
     names = ["dia_x", "dia_h", "u_x", "v_x", "b_x", "b_h"]
-    for name, t in zip(names, tensors[:N_FIXED]):
+    if variant == _lib.V6_GROUP_NOVM:
+        names = names[2:]
+    for name, t in zip(names, tensors[:len(names)]):
         setattr(p, name, t.data_ptr())
     for s in range(g):
-        p.u_h[s] = tensors[N_FIXED + 2 * s].data_ptr()
-        p.v_h[s] = tensors[N_FIXED + 2 * s + 1].data_ptr()
+        p.u_h[s] = tensors[len(names) + 2 * s].data_ptr()
+        p.v_h[s] = tensors[len(names) + 2 * s + 1].data_ptr()
     return p
+
+
+def _hidden_size(variant, params):
+    if variant == _lib.V5_LMF_CELL:
+        return params[1].shape[0]              # u (H, ru)
+    if variant == _lib.V6_GROUP_NOVM:
+        return params[2].shape[-1] // 4        # bias_x (1, 4H)
+    return params[1].shape[-1]                 # dia_h (1, H)
 
 
 # (variant, g, w_rank, u_ranks, time_major, B, T, I, H, training) -> (Desc, Sizes): host-side descriptor cache
@@ -85,7 +104,7 @@ class VmlmfSeqFn(torch.autograd.Function):
             T, B, I = x.shape
         else:
             B, T, I = x.shape
-        H = params[1].shape[-1]
+        H = _hidden_size(variant, params)
         training = bool(any(ctx.needs_input_grad))   # False under torch.no_grad(): inference kernels
         desc, sizes = _desc_for(cfg, B, T, I, H, training)
         dev = x.device
@@ -96,7 +115,7 @@ class VmlmfSeqFn(torch.autograd.Function):
         reserve = torch.empty(sizes.reserve_bytes, device=dev, dtype=torch.uint8) if training else None
         h0c = None if h0 is None else h0.contiguous()
         c0c = None if c0 is None else c0.contiguous()
-        ps = _params_struct(params, g)
+        ps = _params_struct(params, g, variant)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().vmlmf_seq_forward(
@@ -138,8 +157,8 @@ class VmlmfSeqFn(torch.autograd.Function):
             o += p.numel()
         grads = tuple(grads)
         ws = _workspace(dev, sizes.workspace_bytes)
-        ps = _params_struct(params, g)
-        gs = _params_struct(grads, g)
+        ps = _params_struct(params, g, variant)
+        gs = _params_struct(grads, g, variant)
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().vmlmf_seq_backward(
@@ -153,7 +172,8 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
-    each in the reference's layout.  Returns (y, hT, cT).
+    each in the reference's layout (the cells without vm: see the table at the top of this file).
+    Returns (y, hT, cT).
     """
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major))
