@@ -311,6 +311,29 @@ def case_state_dict_names(name="state_dict_names"):
     print(f"{name:28s} ok")
 
 
+def case_flop_counts(name="flop_counts"):
+    """Numbers and printed text of the harness reports (V/src/utils/compression_cal.py), as main.py:143-157 calls them."""
+    import contextlib
+    import io
+    import types
+    from utils import compression_cal as CC
+    rows, texts = [], []
+    grid = [("vmlmf", MyVMLMFCell, 9, [180], 16, [16], 64, 128), ("vmlmf", MyVMLMFCell, 77, [256, 256], 24, [24], 128, 24),
+            ("mylstm", MyLSTMCell, 9, [180], None, None, 64, 128), ("vmlmf", MyVMLMFCell, 77, [180], 8, [6], 81, 24)]
+    for tag, cell, I, layers, rw, ru, B, T in grid:
+        net = Net(I, layer_sizes=layers, w_rank=rw, u_rank=ru, model=MyLSTM, cell=cell)
+        args = types.SimpleNamespace(batch_size=B, model=tag)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            CC.print_model_parm_nums(net)
+            CC.print_model_parm_flops(net, T, args, modeltype="mylstm" if tag == "mylstm" else "vmmodel")
+        rows.append([CC.count_lstm(net, T, B, tag), CC.count_linear(net, 18), sum(p.numel() for p in net.parameters())])
+        texts.append(buf.getvalue())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), counts=np.array(rows, dtype=np.int64),
+                        text=np.array(texts))
+    print(f"{name:28s} ok")
+
+
 CASES = {
     "cell_v1": lambda n: case_bare_cell(n, O.V1, 4, 5, 8, 3, 3, 11),
     "cell_v1_b1": lambda n: case_bare_cell(n, O.V1, 1, 5, 8, 3, 2, 12),
@@ -343,6 +366,7 @@ CASES = {
     "cfgE_v4_b40": lambda n: case_lm_seq(n, O.V4, 40, 35, 650, 32, [32, 32], 51, scale=0.05, full=False, xscale=0.05),
     "cfgE_v3_b64": lambda n: case_lm_seq(n, O.V3, 64, 35, 650, 32, 32, 52, scale=0.05, full=False, xscale=0.05),
     "state_dict_names": lambda n: case_state_dict_names(n),
+    "flop_counts": lambda n: case_flop_counts(n),
 }
 
 

@@ -119,3 +119,27 @@ def test_widened_rows_have_no_cpu_path_either():
         vmlmf_amd.optim.Adam([p]).step()
     with pytest.raises(RuntimeError, match="no CPU path"):
         vmlmf_amd.optim.clip_sgd_step([p], lr=0.1, max_norm=1.0)
+
+
+def test_harness_reports_match_reference_numbers_and_text(capsys):
+    """compression_cal.py:33-145 counterparts: parameter count, FLOP accounting, printed lines (main.py:143-157)."""
+    import types
+    from vmlmf_amd import compression_cal as CC
+    ref = load_golden("flop_counts")
+    grid = [("vmlmf", MyVMLMFCell, 9, [180], 16, [16], 64, 128), ("vmlmf", MyVMLMFCell, 77, [256, 256], 24, [24], 128, 24),
+            ("mylstm", MyLSTMCell, 9, [180], None, None, 64, 128), ("vmlmf", MyVMLMFCell, 77, [180], 8, [6], 81, 24)]
+    for row, (tag, cell, I, layers, rw, ru, B, T) in enumerate(grid):
+        net = Net(I, layer_sizes=layers, w_rank=rw, u_rank=ru, model=MyLSTM, cell=cell)
+        args = types.SimpleNamespace(batch_size=B, model=tag)
+        capsys.readouterr()
+        CC.print_model_parm_nums(net)
+        CC.print_model_parm_flops(net, T, args, modeltype="mylstm" if tag == "mylstm" else "vmmodel")
+        assert capsys.readouterr().out == str(ref["text"][row])
+        got = [CC.count_lstm(net, T, B, tag), CC.count_linear(net, 18), sum(p.numel() for p in net.parameters())]
+        assert got == [int(v) for v in ref["counts"][row]]
+    # the uncounted model types: message, no number (and the reference's TypeError when only args.model says so)
+    net = Net(9, layer_sizes=[16], w_rank=4, u_rank=[2, 2], model=MyLSTM, cell=MyVMLMFCellg2)
+    CC.print_model_parm_flops(net, 8, types.SimpleNamespace(batch_size=2, model="vmlmf_group"), modeltype="vmlmf_group")
+    assert capsys.readouterr().out == "Not Implemented\n"
+    with pytest.raises(TypeError):
+        CC.print_model_parm_flops(net, 8, types.SimpleNamespace(batch_size=2, model="vmlmf_group"))
