@@ -311,6 +311,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     GenericBuf w;
     memset(&w, 0, sizeof(w));
     w.gx = gx, w.EH = pack + P.EH, w.h0 = h0, w.c0 = c0, w.Ud = pack + P.UD, w.Vd = pack + P.VD;
+    w.UdT = pack + P.UDT;   // the skinny products read both operands along k
     w.zeros = ws + L.f_zeros, w.y = y, w.hT = hT, w.cT = cT;
     w.gates = g.training ? rs + L.r_gates : nullptr, w.cs = g.training ? rs + L.r_cs : nullptr;
     w.Qs = g.training ? rs + L.r_Qs : nullptr, w.Qtmp = ws + L.f_Qtmp, w.P = ws + L.f_P, w.ccar = ws + L.f_ccar;
@@ -363,7 +364,7 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
     memset(&w, 0, sizeof(w));
     w.EH = pack + P.EH, w.gates = const_cast<float*>(rs + L.r_gates), w.cs = const_cast<float*>(rs + L.r_cs);
     w.dy = dy, w.dhT = dhT, w.dcT = dcT, w.UdT = pack + P.UDT, w.VdT = pack + P.VDT, w.VxT = pack + P.VXTT;
-    w.UXP = pack + P.UXP, w.EXT = pack + P.EXT;
+    w.UXP = pack + P.UXP, w.EXT = pack + P.EXT, w.Vd = pack + P.VD;
     w.dpre = ws + L.b_dpre, w.dQs = ws + L.b_dQs, w.dHrec = ws + L.b_dHrec, w.ehterm = ws + L.b_ehterm;
     w.dcar = ws + L.b_dcar, w.dh0 = dh0, w.dc0 = dc0, w.dqx = ws + L.b_dqx, w.dx = dx;
     w.part = ws + L.b_part, w.part_cap = (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64);

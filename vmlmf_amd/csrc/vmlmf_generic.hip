@@ -3,20 +3,144 @@
 //
 // The persistent kernels keep U_h/V_h in registers for all T steps; when that is impossible the recurrence is
 // run one timestep at a time, cuDNN-style, with the batch as the GEMM M dimension:
-//     Q_t   = H_{t-1} Ud            (B x H)(H x G*KH)         gemm_tile_kernel (fp32 MFMA 32x32x2)
-//     P_t   = Q_t Vd                (B x G*KH)(G*KH x 4*slots) gemm_tile_kernel
-//     gates, c_t, h_t               elementwise                gates_fwd_kernel
+//     Q_t   = H_{t-1} Ud            (B x H)(H x G*KH)         gemm_skinny_kernel (fp32 MFMA 16x16x4, K split in-workgroup)
+//     P_t   = Q_t Vd                (B x G*KH)(G*KH x 4*slots) gemm_tile_kernel<1> (fp32 MFMA 32x32x2), whose epilogue is
+//     gates, c_t, h_t               elementwise                the forward gate math (gates_fwd_one)
 // and in reverse
 //     dpre_t from the tape          elementwise                gates_bwd_kernel
-//     dQ_t  = dpre_t VdT            (B x 4*slots)(4*slots x G*KH)
-//     dH_{t-1} = dQ_t UdT           (B x G*KH)(G*KH x H)
+//     dQ_t  = dpre_t VdT            (B x 4*slots)(4*slots x G*KH)   gemm_skinny_kernel
+//     dH_{t-1} = dQ_t UdT           (B x G*KH)(G*KH x H)            gemm_tile_kernel<0>
 // Ud/Vd are the group structure written out densely (zeros where a unit does not feed / read a rank-space
 // vector); they are produced by pack_kernel.  The non-recurrent kernels (xproj, wgrad_mfma, reduce, finish)
 // are shared with the persistent path; dqx / dx use the same GEMM kernel over all T*B rows.
 // Same arithmetic, same tape layout ([t][B][slot]), so the parity tests cover both paths with one oracle.
 #include "vmlmf_launch.h"
+#include <stdlib.h>
+#include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// element-wise halves of a timestep, per (batch row b, thread slot): stand-alone kernels for the first / only step
+// and epilogues of the wide GEMMs for the rest (gemm_tile_kernel<EPI>)
+struct StepF {
+  const float *gx, *P, *EH, *h0, *c0;
+  float *y, *hT, *cT, *gates, *cs, *ccar;
+  int t;
+};
+
+// inputs of one (b, slot) element of the forward gate math; loading is kept apart from computing so that a thread
+// with several elements has all of its loads in flight before its first store (the pointers may alias for all
+// the compiler knows, so it would not reorder them itself)
+struct FwdIn {
+  float4 gx4;
+  float hp, cp, e0, e1, e2, e3;
+  int n;
+  bool valid;
+};
+
+__device__ __forceinline__ FwdIn gates_fwd_load(const VGeo& g, const StepF& a, int b, int slot) {
+  FwdIn v;
+  v.valid = vg_slot_unit(g, slot, v.n);
+  const int t = a.t, NT = g.NT, H = g.H, n = v.n;
+  const size_t so = (size_t)b * NT + slot;
+  v.gx4 = ld4(a.gx + ((size_t)t * g.Bp * NT + so) * 4);
+  v.hp = 0.f;
+  if (v.valid) v.hp = t > 0 ? a.y[(size_t)(t - 1) * g.syT + (size_t)b * g.syB + n] : (a.h0 != nullptr ? a.h0[(size_t)b * H + n] : 0.f);
+  if (t == 0)
+    v.cp = (v.valid && a.c0 != nullptr) ? a.c0[(size_t)b * H + n] : 0.f;
+  else
+    v.cp = a.ccar[so];
+  v.e0 = a.EH[0 * NT + slot], v.e1 = a.EH[1 * NT + slot], v.e2 = a.EH[2 * NT + slot], v.e3 = a.EH[3 * NT + slot];
+  return v;
+}
+
+__device__ __forceinline__ void gates_fwd_finish(const VGeo& g, const StepF& a, int b, int slot, const FwdIn& v, float4 p4) {
+  const int t = a.t, NT = g.NT, H = g.H, n = v.n;
+  const size_t so = (size_t)b * NT + slot;
+  const float ig = fast_sigmoid(v.gx4.x + p4.x + v.hp * v.e0);
+  const float fg = fast_sigmoid(v.gx4.y + p4.y + v.hp * v.e1);
+  const float og = fast_sigmoid(v.gx4.z + p4.z + v.hp * v.e2);
+  const float ng = fast_tanh(v.gx4.w + p4.w + v.hp * v.e3);
+  const float c = fmaf(fg, v.cp, ig * ng);
+  const float h = og * fast_tanh(c);
+  a.ccar[so] = c;
+  if (v.valid) {
+    a.y[(size_t)t * g.syT + (size_t)b * g.syB + n] = h;
+    if (t == g.T - 1) {
+      if (a.hT != nullptr) a.hT[(size_t)b * H + n] = h;
+      if (a.cT != nullptr) a.cT[(size_t)b * H + n] = c;
+    }
+  }
+  if (a.gates != nullptr) {
+    const size_t sstride = (size_t)g.Bp * NT;
+    st4(a.gates + ((size_t)t * sstride + so) * 4, make_float4(ig, fg, og, ng));
+    if (t == 0) a.cs[so] = v.cp;
+    a.cs[(size_t)(t + 1) * sstride + so] = c;
+  }
+}
+
+__device__ __forceinline__ void gates_fwd_one(const VGeo& g, const StepF& a, int b, int slot, float4 p4) {
+  gates_fwd_finish(g, a, b, slot, gates_fwd_load(g, a, b, slot), p4);
+}
+
+struct StepB {
+  const float *gates, *cs, *dy, *EH;
+  float *dpre, *dHrec, *ehterm, *dcar;
+  int t;
+};
+
+struct BwdIn {
+  float4 g4;
+  float ccur, cprv, eht, dcar, dy;
+};
+
+__device__ __forceinline__ BwdIn gates_bwd_load(const VGeo& g, const StepB& a, int b, int slot, bool valid, int n) {
+  BwdIn v;
+  const int t = a.t, NT = g.NT;
+  const size_t so = (size_t)b * NT + slot, sstride = (size_t)g.Bp * NT;
+  v.g4 = ld4(a.gates + ((size_t)t * sstride + so) * 4);
+  v.ccur = a.cs[(size_t)(t + 1) * sstride + so], v.cprv = a.cs[(size_t)t * sstride + so];
+  v.eht = a.ehterm[so], v.dcar = a.dcar[so];
+  v.dy = (valid && a.dy != nullptr) ? a.dy[(size_t)t * g.syT + (size_t)b * g.syB + n] : 0.f;
+  return v;
+}
+
+// dhrec: the recurrent part of dh for this unit (dHrec[b][n]); pad slots (never valid) only keep dpre at zero.
+// eh: EH[k][slot], k = 0..3
+__device__ __forceinline__ void gates_bwd_finish(const VGeo& g, const StepB& a, int b, int slot, bool valid, const BwdIn& v,
+                                                 float dhrec, float4 eh) {
+  const int t = a.t, NT = g.NT;
+  const size_t so = (size_t)b * NT + slot, sstride = (size_t)g.Bp * NT;
+  float dh = v.eht;
+  if (valid) {
+    dh += dhrec;
+    if (a.dy != nullptr) dh += v.dy;
+  }
+  const float ig = v.g4.x, fg = v.g4.y, og = v.g4.z, ng = v.g4.w;
+  const float tc = fast_tanh(v.ccur);
+  const float dct = fmaf(dh * og, 1.f - tc * tc, v.dcar);
+  float dp0 = dct * ng * ig * (1.f - ig), dp1 = dct * v.cprv * fg * (1.f - fg);
+  float dp2 = dh * tc * og * (1.f - og), dp3 = dct * ig * (1.f - ng * ng);
+  if (!valid) dp0 = dp1 = dp2 = dp3 = 0.f;
+  a.dcar[so] = dct * fg;
+  st4(a.dpre + ((size_t)t * sstride + so) * 4, make_float4(dp0, dp1, dp2, dp3));
+  a.ehterm[so] = (dp0 * eh.x + dp1 * eh.y) + (dp2 * eh.z + dp3 * eh.w);
+}
+
+__device__ __forceinline__ void gates_bwd_one(const VGeo& g, const StepB& a, int b, int slot, bool valid, int n,
+                                              float dhrec) {
+  const int NT = g.NT;
+  const float4 eh = make_float4(a.EH[0 * NT + slot], a.EH[1 * NT + slot], a.EH[2 * NT + slot], a.EH[3 * NT + slot]);
+  gates_bwd_finish(g, a, b, slot, valid, gates_bwd_load(g, a, b, slot, valid, n), dhrec, eh);
+}
+
+struct EpiArgs {
+  VGeo g;
+  StepF f;
+  StepB b;
+};
+
 
 // C[M x N] = A[M x K] B[K x N], row-major, any sizes (masked).  64 x 64 tile of C per workgroup of four waves
 // (each a 32 x 32 sub-tile on v_mfma_f32_32x32x2_f32).  K is staged through LDS 128 at a time: every thread
@@ -27,6 +151,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // sums the partials in index order (deterministic whatever the arrival order) and resets the ticket.
 constexpr int GBM = 64, GBN = 64, GBK = 128, GPAD = 4;
 constexpr size_t GEMM_LDS = sizeof(float) * 2 * GBK * (GBM + GPAD);
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order; a speed matter only), each with an L2 of its own.  Logical tile
+// ids are handed out so that an XCD gets a contiguous range of them: with ids running along the smaller operand's
+// dimension first, the larger operand is then fetched into one L2 instead of all eight.
+__device__ __forceinline__ int xcd_tile_id(int bid, int total) {
+  return (total & 7) == 0 ? (bid & 7) * (total >> 3) + (bid >> 3) : bid;
+}
 
 struct GemmArgs {
   const float* A;
@@ -40,15 +171,24 @@ struct GemmArgs {
   int* ticket;   // one per tile, zero on entry and on exit
 };
 
-__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
+// EPI 1: C = P_t is not stored; each (row, slot) of the tile goes straight through the forward gate math.
+// EPI 2: C = dH_rec is not stored; each (row, unit) of the tile continues into the gate derivatives of step e.b.t.
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a, EpiArgs e) {
   extern __shared__ float4 gsm4[];
   float(*As)[GBM + GPAD] = reinterpret_cast<float(*)[GBM + GPAD]>(gsm4);               // [k][m]
   float(*Bs)[GBN + GPAD] = reinterpret_cast<float(*)[GBN + GPAD]>(As + GBK);            // [k][n]
   __shared__ int last_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lk = lane >> 5, wm = wave & 1, wn = wave >> 1;
-  const int tiles_n = (a.N + GBN - 1) / GBN;
-  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int tiles_n = (a.N + GBN - 1) / GBN, tiles_m = (a.M + GBM - 1) / GBM;
+  const int lid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  if (a.N > a.M) {   // B is the larger operand: an XCD owns a range of its columns, for every row tile
+    tn = lid / tiles_m, tm = lid - tn * tiles_m;
+  } else {
+    tm = lid / tiles_n, tn = lid - tm * tiles_n;
+  }
   const int m0 = tm * GBM, n0 = tn * GBN;
   const int nz = gridDim.y, kz = blockIdx.y;
   const int kper = ((a.K + nz - 1) / nz + 15) / 16 * 16;
@@ -102,6 +242,47 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
   }
   const int col = n0 + 32 * wn + li;
   const bool cok = col < a.N;
+  if (EPI != 0) {   // K is a single-workgroup product here (nz == 1): tile -> LDS -> element-wise continuation
+    float(*Ct)[GBN + GPAD] = reinterpret_cast<float(*)[GBN + GPAD]>(gsm4);
+    __syncthreads();   // every wave is done reading the staging buffers
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Ct[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lk][32 * wn + li] = acc[r];
+    __syncthreads();
+    if (EPI == 1) {   // thread -> slot (n0/4 + tid % 16) of rows tid/16 + 16 i
+      const int sl = tid & 15, slot = (n0 >> 2) + sl;
+      if (slot < e.g.NT) {
+        FwdIn in[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int b = m0 + (tid >> 4) + 16 * i;
+          if (b < a.M) in[i] = gates_fwd_load(e.g, e.f, b, slot);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = (tid >> 4) + 16 * i, b = m0 + row;
+          if (b < a.M) gates_fwd_finish(e.g, e.f, b, slot, in[i], *reinterpret_cast<const float4*>(&Ct[row][4 * sl]));
+        }
+      }
+    } else {          // thread -> unit n0 + tid % 64 of rows tid/64 + 4 i
+      const int cn = tid & 63, n = n0 + cn;
+      if (n < a.N) {
+        const int slot = vg_slot(e.g, n), NT = e.g.NT;
+        const float4 eh = make_float4(e.b.EH[0 * NT + slot], e.b.EH[1 * NT + slot], e.b.EH[2 * NT + slot], e.b.EH[3 * NT + slot]);
+        BwdIn in[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int b = m0 + (tid >> 6) + 4 * i;
+          if (b < a.M) in[i] = gates_bwd_load(e.g, e.b, b, slot, true, n);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int row = (tid >> 6) + 4 * i, b = m0 + row;
+          if (b < a.M) gates_bwd_finish(e.g, e.b, b, slot, true, in[i], Ct[row][cn], eh);
+        }
+      }
+    }
+    return;
+  }
   if (nz == 1) {
     if (cok) {
 #pragma unroll
@@ -152,13 +333,155 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a) {
   if (tid == 0) __hip_atomic_store(a.ticket + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// C[M x N] = A[M x K] B[K x N] for a skinny C and a long K (Q = H Ud: 256 x 128, K = 650; dQ = dpre VdT: K = 3072).
+// With 64 x 64 tiles such a product has eight tiles: either eight CUs grind through K on the slow fp32 MFMA
+// (64 cycles per 32x32x2) or K is split across workgroups and pays a cross-XCD hand-over (write-through partials,
+// ticket, agent-scope reads: 20-35 us measured).  Here a workgroup owns one 16 x 16 tile of C (128 of them for
+// 256 x 128) and its NWV waves split K among themselves: every lane issues all loads of its slice up front (A as
+// one 16-byte load per 16 k, B as 64-byte rows shared by 16 lanes), runs its v_mfma_f32_16x16x4_f32 chain from
+// registers -- no LDS staging, one memory latency -- and the partial tiles meet in LDS, summed in wave order.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+// four consecutive floats p[0..3] of a row, `n` of them inside the slice; cls = widest load the row alignment allows
+__device__ __forceinline__ void sk_load4(const float* p, int cls, int n, float (&v)[4]) {
+  if (n >= 4 && cls == 4) {
+    const float4 t = ld4(p);
+    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
+  } else if (n >= 4 && cls == 2) {
+    const float2 t0 = *reinterpret_cast<const float2*>(p), t1 = *reinterpret_cast<const float2*>(p + 2);
+    v[0] = t0.x, v[1] = t0.y, v[2] = t1.x, v[3] = t1.y;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = j < n ? p[j] : 0.f;
+  }
+}
+__host__ __device__ inline int sk_align_class(const float* base, long long ld) {
+  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
+  if (ld % 4 == 0 && (b & 15) == 0) return 4;
+  if (ld % 2 == 0 && (b & 7) == 0) return 2;
+  return 1;
+}
+
+// BT: `B` points at B^T (N x K row-major, ldb its row stride): both operands are then read along k, 16 bytes per lane
+// and load (the step-wise path keeps every factor in both orientations); otherwise B is K x N and a lane fetches its
+// column element row by row (four 64-byte segments per load instruction: 3x slower at K = 3072).
+template <int NWV, bool BT, int SK_CH>
+__global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
+  __shared__ float4 red[NWV - 1][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int tiles_n = (a.N + 15) / 16, tiles_m = (a.M + 15) / 16;
+  const int lid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
+  int tm, tn;
+  if (a.N > a.M) {
+    tn = lid / tiles_m, tm = lid - tn * tiles_m;
+  } else {
+    tm = lid / tiles_n, tn = lid - tm * tiles_n;
+  }
+  const int m0 = tm * 16, n0 = tn * 16;
+  const int nblk = (a.K + 15) / 16, per = (nblk + NWV - 1) / NWV;
+  const int kb0 = wave * per * 16;
+  const int kb1 = kb0 + per * 16 < a.K ? kb0 + per * 16 : a.K;
+  const bool row_ok = m0 + r < a.M, col_ok = n0 + r < a.N;
+  const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
+  const float* Bp = BT ? a.B + (long long)(col_ok ? n0 + r : 0) * a.ldb : a.B + (col_ok ? n0 + r : 0);
+  const int acls = sk_align_class(a.A, a.lda), bcls = sk_align_class(a.B, a.ldb);
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = kb0; kb < kb1; kb += 16 * SK_CH) {
+    float av[SK_CH][4], bv[SK_CH][4];
+#pragma unroll
+    for (int c = 0; c < SK_CH; ++c) {
+      const int k = kb + 16 * c + 4 * q;
+      const int n = kb1 - k;   // elements of this quad inside the slice (<= 0: none)
+      sk_load4(Ap + k, acls, row_ok ? n : 0, av[c]);
+      if (BT) {
+        sk_load4(Bp + k, bcls, col_ok ? n : 0, bv[c]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[c][j] = (col_ok && j < n) ? Bp[(long long)(k + j) * a.ldb] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < SK_CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[c][j], acc, 0, 0, 0);
+  }
+  if (wave > 0) red[wave - 1][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < NWV - 1; ++w) {
+      const float4 v = red[w][lane];
+      acc[0] += v.x, acc[1] += v.y, acc[2] += v.z, acc[3] += v.w;
+    }
+    if (col_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * q + i;
+        if (row < a.M) a.C[(long long)row * a.ldc + n0 + r] = acc[i];
+      }
+    }
+  }
+}
+
 // split-K scratch of one layer call (GenericBuf::part / ticket): room for GEMM_MAX_SPLIT partial copies of the
 // largest skinny product (B x G*KH) and one ticket per tile of it
 constexpr int GEMM_MAX_SPLIT = VG_GEMM_SPLIT;
+// VMLMF_SKINNY=0 keeps the split-K tiles for those products (A/B measurements)
+static const int g_skinny_mode = []() {
+  const char* e = getenv("VMLMF_SKINNY");
+  return e == nullptr ? 1 : atoi(e);
+}();
+static const bool g_skinny = g_skinny_mode != 0;
+// VMLMF_FUSE_GATES=0: element-wise halves of a step as kernels of their own (A/B measurements)
+static const int g_fuse_mode = []() {
+  const char* e = getenv("VMLMF_FUSE_GATES");
+  return e == nullptr ? 1 : atoi(e);
+}();
+static const bool g_fuse = g_fuse_mode != 0;       // forward: gate math as the epilogue of P_t = Q_t Vd
+static const bool g_fuse_bwd = g_fuse_mode == 2;   // backward: measured slower (44 tiles carry all of the element-wise work)
 
+// Bt / ldbt: the same factor stored transposed (N x K), or nullptr
 static int gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
-                int K, float* part, long long part_cap, int* ticket, int ticket_cap, hipStream_t s) {
+                int K, float* part, long long part_cap, int* ticket, int ticket_cap, hipStream_t s,
+                const float* Bt = nullptr, long long ldbt = 0, int epi = 0, const EpiArgs* ea = nullptr) {
   GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K, part, ticket};
+  static bool raised = false;
+  if (!raised) {   // 69 KB of dynamic LDS
+    for (const void* f : {reinterpret_cast<const void*>(gemm_tile_kernel<0>), reinterpret_cast<const void*>(gemm_tile_kernel<1>),
+                          reinterpret_cast<const void*>(gemm_tile_kernel<2>)}) {
+      const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
+      if (e != hipSuccess) return (int)e;
+    }
+    raised = true;
+  }
+  if (epi != 0) {   // fused element-wise continuation: one workgroup per tile, whole K (<= a few stages)
+    const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
+    if (epi == 1)
+      hipLaunchKernelGGL(gemm_tile_kernel<1>, dim3(tiles, 1), dim3(256), GEMM_LDS, s, a, *ea);
+    else
+      hipLaunchKernelGGL(gemm_tile_kernel<2>, dim3(tiles, 1), dim3(256), GEMM_LDS, s, a, *ea);
+    return (int)hipGetLastError();
+  }
+  if (N <= 128 && K >= 256 && g_skinny) {   // skinny output, long K: 16 x 16 tiles, K split inside the workgroup
+    const int t16 = ((M + 15) / 16) * ((N + 15) / 16);
+    if (Bt != nullptr && g_skinny_mode == 4) {
+      a.B = Bt, a.ldb = ldbt;
+      if (K >= 1536)
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 12>), dim3(t16), dim3(512), 0, s, a);
+      else
+        hipLaunchKernelGGL((gemm_skinny_kernel<4, true, 12>), dim3(t16), dim3(256), 0, s, a);
+    } else if (K >= 1536) {
+      if (g_skinny_mode == 2)
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 24>), dim3(t16), dim3(512), 0, s, a);
+      else if (g_skinny_mode == 3)
+        hipLaunchKernelGGL((gemm_skinny_kernel<16, false, 12>), dim3(t16), dim3(1024), 0, s, a);
+      else
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12>), dim3(t16), dim3(512), 0, s, a);
+    } else {
+      hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12>), dim3(t16), dim3(256), 0, s, a);
+    }
+    return (int)hipGetLastError();
+  }
   const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
   int nz = 1;
   if (tiles < 64 && K >= 256 && part != nullptr && tiles <= ticket_cap) {
@@ -167,94 +490,35 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
     while (nz > 1 && (long long)nz * tiles * GBM * GBN > part_cap) --nz;
     if (nz < 1) nz = 1;
   }
-  static bool raised = false;
-  if (!raised) {   // 69 KB of dynamic LDS
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
-    if (e != hipSuccess) return (int)e;
-    raised = true;
-  }
-  hipLaunchKernelGGL(gemm_tile_kernel, dim3(tiles, nz), dim3(256), GEMM_LDS, s, a);
+  EpiArgs none;
+  memset(&none, 0, sizeof(none));
+  hipLaunchKernelGGL(gemm_tile_kernel<0>, dim3(tiles, nz), dim3(256), GEMM_LDS, s, a, none);
   return (int)hipGetLastError();
 }
-
-// ---------------------------------------------------------------------------------------------------
-struct StepF {
-  const float *gx, *P, *EH, *h0, *c0;
-  float *y, *hT, *cT, *gates, *cs, *ccar;
-  int t;
-};
 
 // one thread per (batch row, thread slot)
 __global__ void __launch_bounds__(256) gates_fwd_kernel(VGeo g, StepF a) {
   const int slot = blockIdx.y * 256 + threadIdx.x, b = blockIdx.x;
   if (slot >= g.NT) return;
-  int n;
-  const bool valid = vg_slot_unit(g, slot, n);
-  const int t = a.t, NT = g.NT, H = g.H;
-  const size_t so = (size_t)b * NT + slot;
-  const float4 gx4 = ld4(a.gx + ((size_t)t * g.Bp * NT + so) * 4);
-  const float4 p4 = ld4(a.P + so * 4);
-  float hp = 0.f;
-  if (valid) hp = t > 0 ? a.y[(size_t)(t - 1) * g.syT + (size_t)b * g.syB + n] : (a.h0 != nullptr ? a.h0[(size_t)b * H + n] : 0.f);
-  float cp;
-  if (t == 0)
-    cp = (valid && a.c0 != nullptr) ? a.c0[(size_t)b * H + n] : 0.f;
-  else
-    cp = a.ccar[so];
-  const float e0 = a.EH[0 * NT + slot], e1 = a.EH[1 * NT + slot], e2 = a.EH[2 * NT + slot], e3 = a.EH[3 * NT + slot];
-  const float ig = fast_sigmoid(gx4.x + p4.x + hp * e0);
-  const float fg = fast_sigmoid(gx4.y + p4.y + hp * e1);
-  const float og = fast_sigmoid(gx4.z + p4.z + hp * e2);
-  const float ng = fast_tanh(gx4.w + p4.w + hp * e3);
-  const float c = fmaf(fg, cp, ig * ng);
-  const float h = og * fast_tanh(c);
-  a.ccar[so] = c;
-  if (valid) {
-    a.y[(size_t)t * g.syT + (size_t)b * g.syB + n] = h;
-    if (t == g.T - 1) {
-      if (a.hT != nullptr) a.hT[(size_t)b * H + n] = h;
-      if (a.cT != nullptr) a.cT[(size_t)b * H + n] = c;
-    }
-  }
-  if (a.gates != nullptr) {
-    const size_t sstride = (size_t)g.Bp * NT;
-    st4(a.gates + ((size_t)t * sstride + so) * 4, make_float4(ig, fg, og, ng));
-    if (t == 0) a.cs[so] = cp;
-    a.cs[(size_t)(t + 1) * sstride + so] = c;
-  }
+  gates_fwd_one(g, a, b, slot, ld4(a.P + ((size_t)b * g.NT + slot) * 4));
 }
-
-struct StepB {
-  const float *gates, *cs, *dy, *EH;
-  float *dpre, *dHrec, *ehterm, *dcar;
-  int t;
-};
 
 __global__ void __launch_bounds__(256) gates_bwd_kernel(VGeo g, StepB a) {
   const int slot = blockIdx.y * 256 + threadIdx.x, b = blockIdx.x;
   if (slot >= g.NT) return;
   int n;
   const bool valid = vg_slot_unit(g, slot, n);
-  const int t = a.t, NT = g.NT, H = g.H;
-  const size_t so = (size_t)b * NT + slot, sstride = (size_t)g.Bp * NT;
-  const float4 g4 = ld4(a.gates + ((size_t)t * sstride + so) * 4);
-  const float ccur = a.cs[(size_t)(t + 1) * sstride + so], cprv = a.cs[(size_t)t * sstride + so];
-  float dh = a.ehterm[so];
-  if (valid) {
-    dh += a.dHrec[(size_t)b * H + n];
-    if (a.dy != nullptr) dh += a.dy[(size_t)t * g.syT + (size_t)b * g.syB + n];
+  gates_bwd_one(g, a, b, slot, valid, n, valid ? a.dHrec[(size_t)b * g.H + n] : 0.f);
+}
+
+// dpre of the pad slots (thread slots without a hidden unit) for every timestep: the fused backward epilogue only
+// visits real units, and the products that contract over slots must not meet stale workspace contents there
+__global__ void __launch_bounds__(256) zero_pad_dpre_kernel(VGeo g, float* __restrict__ dpre) {
+  const size_t row = blockIdx.x;   // (t, b)
+  for (int slot = threadIdx.x; slot < g.NT; slot += 256) {
+    int n;
+    if (!vg_slot_unit(g, slot, n)) st4(dpre + (row * g.NT + slot) * 4, f4zero());
   }
-  const float ig = g4.x, fg = g4.y, og = g4.z, ng = g4.w;
-  const float tc = fast_tanh(ccur);
-  const float dct = fmaf(dh * og, 1.f - tc * tc, a.dcar[so]);
-  float dp0 = dct * ng * ig * (1.f - ig), dp1 = dct * cprv * fg * (1.f - fg);
-  float dp2 = dh * tc * og * (1.f - og), dp3 = dct * ig * (1.f - ng * ng);
-  if (!valid) dp0 = dp1 = dp2 = dp3 = 0.f;
-  a.dcar[so] = dct * fg;
-  st4(a.dpre + ((size_t)t * sstride + so) * 4, make_float4(dp0, dp1, dp2, dp3));
-  a.ehterm[so] = (dp0 * a.EH[0 * NT + slot] + dp1 * a.EH[1 * NT + slot]) +
-                 (dp2 * a.EH[2 * NT + slot] + dp3 * a.EH[3 * NT + slot]);
 }
 
 // mode 0: initialise the backward carries from (dhT, dcT);  mode 1: emit dh0 = dHrec + ehterm, dc0 = dcar
@@ -306,13 +570,23 @@ int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
       A = w.zeros, lda = H;
     }
     float* Qt = w.Qs != nullptr ? w.Qs + (size_t)t * B * GK : w.Qtmp;
-    if ((rc = gemm(A, lda, w.Ud, GK, Qt, GK, B, GK, H, w.part, w.part_cap, w.ticket, w.ticket_cap, s)) != 0) return rc;
+    if ((rc = gemm(A, lda, w.Ud, GK, Qt, GK, B, GK, H, w.part, w.part_cap, w.ticket, w.ticket_cap, s, w.UdT, H)) != 0)
+      return rc;
+    EpiArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.g = g;
+    StepF& a = ea.f;
+    a.gx = w.gx, a.P = w.P, a.EH = w.EH, a.h0 = w.h0, a.c0 = w.c0, a.y = w.y, a.hT = w.hT, a.cT = w.cT;
+    a.gates = w.gates, a.cs = w.cs, a.ccar = w.ccar, a.t = t;
+    if (g_fuse) {   // P_t = Q_t Vd never reaches memory: the gate math is the epilogue of its tiles
+      if ((rc = gemm(Qt, GK, w.Vd, (long long)NT * 4, nullptr, 0, B, NT * 4, GK, nullptr, 0, nullptr, 0, s, nullptr, 0, 1,
+                     &ea)) != 0)
+        return rc;
+      continue;
+    }
     if ((rc = gemm(Qt, GK, w.Vd, (long long)NT * 4, w.P, (long long)NT * 4, B, NT * 4, GK, w.part, w.part_cap, w.ticket,
                    w.ticket_cap, s)) != 0)
       return rc;
-    StepF a;
-    a.gx = w.gx, a.P = w.P, a.EH = w.EH, a.h0 = w.h0, a.c0 = w.c0, a.y = w.y, a.hT = w.hT, a.cT = w.cT;
-    a.gates = w.gates, a.cs = w.cs, a.ccar = w.ccar, a.t = t;
     hipLaunchKernelGGL(gates_fwd_kernel, egrid, eblock, 0, s, g, a);
     if ((rc = (int)hipGetLastError()) != 0) return rc;
   }
@@ -327,16 +601,30 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
                      (float*)nullptr, (float*)nullptr);
   if ((rc = (int)hipGetLastError()) != 0) return rc;
   const size_t sstride = (size_t)g.Bp * NT;
+  if (g_fuse_bwd && NT > H) {
+    hipLaunchKernelGGL(zero_pad_dpre_kernel, dim3((unsigned)(T * g.Bp)), dim3(256), 0, s, g, w.dpre);
+    if ((rc = (int)hipGetLastError()) != 0) return rc;
+  }
   for (int t = T - 1; t >= 0; --t) {
-    StepB a;
+    EpiArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    ea.g = g;
+    StepB& a = ea.b;
     a.gates = w.gates, a.cs = w.cs, a.dy = w.dy, a.EH = w.EH, a.dpre = w.dpre, a.dHrec = w.dHrec;
     a.ehterm = w.ehterm, a.dcar = w.dcar, a.t = t;
-    hipLaunchKernelGGL(gates_bwd_kernel, egrid, eblock, 0, s, g, a);
-    if ((rc = (int)hipGetLastError()) != 0) return rc;
+    if (!g_fuse_bwd || t == T - 1) {   // fused: dpre_t of every later step comes out of the previous dH_rec product
+      hipLaunchKernelGGL(gates_bwd_kernel, egrid, eblock, 0, s, g, a);
+      if ((rc = (int)hipGetLastError()) != 0) return rc;
+    }
     float* dQt = w.dQs + (size_t)t * B * GK;
     if ((rc = gemm(w.dpre + (size_t)t * sstride * 4, (long long)NT * 4, w.VdT, GK, dQt, GK, B, GK, NT * 4, w.part,
-                   w.part_cap, w.ticket, w.ticket_cap, s)) != 0)
+                   w.part_cap, w.ticket, w.ticket_cap, s, w.Vd, (long long)NT * 4)) != 0)
       return rc;
+    if (g_fuse_bwd && t > 0) {   // dH_rec = dQ_t UdT continues into the gate derivatives of step t - 1 inside the tiles
+      a.t = t - 1;
+      if ((rc = gemm(dQt, GK, w.UdT, H, nullptr, 0, B, H, GK, nullptr, 0, nullptr, 0, s, nullptr, 0, 2, &ea)) != 0) return rc;
+      continue;
+    }
     if ((rc = gemm(dQt, GK, w.UdT, H, w.dHrec, H, B, H, GK, w.part, w.part_cap, w.ticket, w.ticket_cap, s)) != 0) return rc;
   }
   hipLaunchKernelGGL(carry_kernel, egrid, eblock, 0, s, g, 1, (const float*)nullptr, (const float*)nullptr, w.dHrec,
