@@ -136,6 +136,18 @@ int vmlmf_ce_backward(int B, int C, const float *logits, const int64_t *target, 
                       const float *lse, const float *nvalid, const float *dloss, float *dlogits, void *stream);
 
 /*
+ * Softmax negative log-likelihood of the language-model loop (nll_loss, V/src/train_test/lm_test.py:140-153) —
+ * SURVEY §8f rank 3.  scores (R,V) dense fp32 with R = T*B rows, y (R) int64 targets in row order.
+ *   loss = scale * sum_r (logsumexp(scores[r]) - scores[r][y[r]])        (the reference: scale = batch_size / R)
+ * Forward writes loss (1), lse (R) and rowloss (R) and reads scores once; backward writes
+ * dscores = dloss * scale * (softmax(scores) - onehot(y)) from scores, lse and the device scalar dloss.
+ */
+int vmlmf_nll_forward(int R, int V, const float *scores, const int64_t *y, float scale, float *loss, float *lse,
+                      float *rowloss, void *stream);
+int vmlmf_nll_backward(int R, int V, const float *scores, const int64_t *y, float scale, const float *lse,
+                       const float *dloss, float *dscores, void *stream);
+
+/*
  * Optimizer steps of the reference's two training loops, one launch over every parameter tensor.
  * vmlmf_tensor_list carries up to VMLMF_MAX_TENSORS (param, grad, numel, state_offset, step_index) entries; larger
  * models are stepped in several calls.  All tensors fp32, dense.

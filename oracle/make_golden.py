@@ -334,6 +334,56 @@ def case_flop_counts(name="flop_counts"):
     print(f"{name:28s} ok")
 
 
+def case_lm_model(name="lm_model_v3"):
+    """The whole LM network of lm_test.py (vmlmf_lm.py:366-440, lstm_type "vmlmf", dropout 0) on two consecutive
+    minibatches of the training loop (lm_test.py:196-209): scores, nll_loss, gradients, clip + SGD step, carried states."""
+    from models.vmlmf_lm import Model
+    from train_test.lm_test import nll_loss
+    V, H, L, B, T = 60, 16, 2, 4, 5
+    torch.manual_seed(7)
+    model = Model(V, H, L, 0.0, 0.1, w_rank=4, u_ranks=[5], lstm_type="vmlmf")
+    init = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    r = rng_of(61)
+    out = dict(meta=np.array([V, H, L, B, T, 4, 5]), init=init)
+    states = model.state_init(B)
+    lr, max_norm = 1.0, 0.25
+    for i in range(2):
+        x = torch.tensor(r.integers(0, V, size=(T, B)))
+        y = torch.tensor(r.integers(0, V, size=(T, B)))
+        model.zero_grad()
+        states = model.detach(states)
+        scores, states = model(x, states)
+        loss = nll_loss(scores, y)
+        loss.backward()
+        out[f"x{i}"], out[f"y{i}"] = x.numpy(), y.numpy()
+        out[f"scores{i}"], out[f"loss{i}"] = scores.detach().numpy(), np.array([loss.item()])
+        out[f"G{i}"] = {k: p.grad.numpy().copy() for k, p in model.named_parameters()}
+        with torch.no_grad():
+            norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+            for p in model.parameters():
+                p -= lr * p.grad
+        out[f"norm{i}"] = np.array([float(norm)])
+    out["final"] = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
+    out["hT"] = np.stack([s[0].detach().numpy() for s in states])
+    save(name, **out)
+
+
+def case_nll(name="nll_v10000"):
+    """nll_loss (lm_test.py:140-153) at the PTB vocabulary width: R = T*B = 70 rows of 10 000 scores (seeded; the
+    fixture keeps the loss and a strided sample of the autograd gradient)."""
+    from train_test.lm_test import nll_loss
+    T, B, V = 7, 10, 10000
+    r = rng_of(71)
+    scores = torch.tensor((2.0 * r.standard_normal((T * B, V))).astype(np.float32), requires_grad=True)
+    y = torch.tensor(r.integers(0, V, size=(T, B)))
+    loss = nll_loss(scores, y)
+    (3.0 * loss).backward()
+    g = scores.grad.numpy()
+    rows = np.arange(T * B)
+    save(name, meta=np.array([T, B, V, 71]), loss=np.array([loss.item()]), y=y.numpy(), g_s=g[:, ::97],
+         g_target=g[rows, y.numpy().reshape(-1)], upstream=np.array([3.0]))
+
+
 CASES = {
     "cell_v1": lambda n: case_bare_cell(n, O.V1, 4, 5, 8, 3, 3, 11),
     "cell_v1_b1": lambda n: case_bare_cell(n, O.V1, 1, 5, 8, 3, 2, 12),
@@ -367,6 +417,8 @@ CASES = {
     "cfgE_v3_b64": lambda n: case_lm_seq(n, O.V3, 64, 35, 650, 32, 32, 52, scale=0.05, full=False, xscale=0.05),
     "state_dict_names": lambda n: case_state_dict_names(n),
     "flop_counts": lambda n: case_flop_counts(n),
+    "lm_model_v3": lambda n: case_lm_model(n),
+    "nll_v10000": lambda n: case_nll(n),
 }
 
 

@@ -604,3 +604,43 @@ def synthetic_batch(B, T, I, seed=1234, classes=6, dtype=np.float32):
     x = rng.standard_normal((B, T, I)).astype(dtype)
     tgt = rng.integers(0, classes, size=(B,)).astype(np.int64)
     return x, tgt
+
+
+# ----------------------------------------------------------------------------------------------------
+# language-model network around the LM layers
+# ----------------------------------------------------------------------------------------------------
+
+def nll_loss_literal(scores, y):
+    """``nll_loss`` of the LM loop, op for op (V/src/train_test/lm_test.py:140-153)."""
+    batch_size = y.size(1)
+    expscores = scores.exp()
+    probabilities = expscores / expscores.sum(1, keepdim=True)
+    answerprobs = probabilities[range(len(y.reshape(-1))), y.reshape(-1)]
+    return torch.mean(-torch.log(answerprobs) * batch_size)
+
+
+def nll_loss_stable(scores, y, dtype=np.float64):
+    """The same quantity around the row maximum (numpy): (loss, dloss/dscores).  Specification of the fused kernels."""
+    z = np.asarray(scores, dtype)
+    t = np.asarray(y).reshape(-1)
+    R = z.shape[0]
+    batch_size = np.asarray(y).shape[1]
+    m = z.max(1, keepdims=True)
+    lse = m[:, 0] + np.log(np.exp(z - m).sum(1))
+    loss = (lse - z[np.arange(R), t]).sum() * batch_size / R
+    g = np.exp(z - lse[:, None])
+    g[np.arange(R), t] -= 1.0
+    return loss, g * batch_size / R
+
+
+def literal_lm_forward(sd, x, states, layer_num):
+    """``Model.forward`` with lstm_type "vmlmf" and dropout 0 (V/src/models/vmlmf_lm.py:434-440) on a state-dict style
+    mapping name -> tensor: embed.w[x] -> MyVMLSTM layers -> addmm(fc.b, ., fc.w^T).  Returns (scores, states)."""
+    h = sd["embed.w"][x]
+    out_states = []
+    for i in range(layer_num):
+        P = {k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"rnns.{i}.")}
+        h, hT, cT = literal_sequence(V3, P, h, states[i][0], states[i][1], time_major=True)
+        out_states.append((hT, cT))
+    scores = torch.addmm(sd["fc.b"], h.view(-1, h.size(2)), sd["fc.w"].t())
+    return scores, out_states

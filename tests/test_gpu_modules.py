@@ -310,3 +310,63 @@ def test_vanilla_baseline_cell_keeps_stock_ops_on_gpu():
     rnn = MyLSTM(9, hidden_layer_sizes=[32], cell=MyLSTMCell).to(DEV)
     y, h = rnn(torch.randn(4, 6, 9, device=DEV))
     assert y.shape == (4, 6, 32) and torch.isfinite(y).all()
+
+
+def test_nll_loss_vs_reference_at_ptb_vocabulary():
+    """lm_test.py:140-153 on the fused kernels: loss and gradient against values captured from the reference."""
+    from vmlmf_amd import nll_loss
+    d = load_golden("nll_v10000")
+    T, B, V, seed = (int(v) for v in d["meta"])
+    r = np.random.Generator(np.random.PCG64(seed))
+    z = torch.tensor((2.0 * r.standard_normal((T * B, V))).astype(np.float32), device=DEV, requires_grad=True)
+    y = torch.tensor(r.integers(0, V, size=(T, B)), device=DEV)
+    loss = nll_loss(z, y)
+    (float(d["upstream"][0]) * loss).backward()
+    assert abs(loss.item() - float(d["loss"][0])) < 1e-4 * abs(float(d["loss"][0]))
+    g = z.grad.cpu().numpy()
+    assert_grad(g[:, ::97], d["g_s"], "dscores sample")
+    assert_grad(g[np.arange(T * B), d["y"].reshape(-1)], d["g_target"], "dscores at targets")
+
+
+@pytest.mark.parametrize("R,B,V", [(6, 3, 1003), (8, 4, 20000), (35, 5, 16384), (4, 2, 7)])
+def test_nll_loss_shapes_vs_oracle(R, B, V):
+    """Rows that are not a multiple of four wide (scalar path), wider than the register-resident limit (two-pass
+    path), exactly at it, and tiny; scores large enough that the reference's plain exp would overflow."""
+    from vmlmf_amd import nll_loss
+    r = np.random.Generator(np.random.PCG64(R + V))
+    z = (30.0 * r.standard_normal((R, V))).astype(np.float32)      # row maxima around 100: exp overflows in fp32
+    y = r.integers(0, V, size=(R // B, B))
+    want, gwant = O.nll_loss_stable(z, y)
+    zt = torch.tensor(z, device=DEV, requires_grad=True)
+    loss = nll_loss(zt, torch.tensor(y, device=DEV))
+    loss.backward()
+    assert np.isfinite(loss.item()) and abs(loss.item() - want) < 1e-4 * abs(want)
+    assert_grad(zt.grad.cpu().numpy(), gwant, "dscores")
+
+
+def test_lm_network_two_minibatches_vs_reference():
+    """The LM loop of lm_test.py:196-209 on this package: Model(lstm_type="vmlmf") -> nll_loss -> backward ->
+    clip_sgd_step, two minibatches with detached state carry, against the reference's own run."""
+    from vmlmf_amd import Model, nll_loss, optim
+    d = load_golden("lm_model_v3")
+    V, H, L, B, T, rw, ru = (int(v) for v in d["meta"])
+    model = Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[ru], lstm_type="vmlmf")
+    model.load_state_dict({k: torch.tensor(v) for k, v in d["init"].items()})
+    model = model.to(DEV)
+    states = model.state_init(B)
+    for i in range(2):
+        model.zero_grad()
+        states = model.detach(states)
+        scores, states = model(torch.tensor(d[f"x{i}"], device=DEV), states)
+        loss = nll_loss(scores, torch.tensor(d[f"y{i}"], device=DEV))
+        loss.backward()
+        assert_out(scores.detach().cpu().numpy(), d[f"scores{i}"], f"scores{i}")
+        assert abs(loss.item() - float(d[f"loss{i}"][0])) < 1e-4 * float(d[f"loss{i}"][0])
+        for k, p in model.named_parameters():
+            assert_grad(p.grad.cpu().numpy(), d[f"G{i}"][k], f"G{i}.{k}")
+        norm = optim.clip_sgd_step(model.parameters(), lr=1.0, max_norm=0.25)
+        assert abs(float(norm) - float(d[f"norm{i}"][0])) < 1e-4 * float(d[f"norm{i}"][0])
+    sd = model.state_dict()
+    for k, v in d["final"].items():
+        assert_out(sd[k].cpu().numpy(), v, "final." + k, atol=2e-5, rtol=1e-3)
+    assert_out(torch.stack([s[0].detach() for s in states]).cpu().numpy(), d["hT"], "hT")

@@ -143,3 +143,29 @@ def test_harness_reports_match_reference_numbers_and_text(capsys):
     assert capsys.readouterr().out == "Not Implemented\n"
     with pytest.raises(TypeError):
         CC.print_model_parm_flops(net, 8, types.SimpleNamespace(batch_size=2, model="vmlmf_group"))
+
+
+def test_lm_network_surface_matches_reference():
+    """Model / Embed / Linear / LSTM of vmlmf_lm.py: names, shapes, registration order, constructor quirks."""
+    from vmlmf_amd import Model, nll_loss
+    d = load_golden("lm_model_v3")
+    V, H, L, B, T, rw, ru = (int(v) for v in d["meta"])
+    torch.manual_seed(7)
+    m = Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[ru], lstm_type="vmlmf")
+    assert list(m.state_dict()) == list(d["init"])
+    for k, v in m.state_dict().items():          # same creation order + reset_parameters => same seeded values
+        assert np.array_equal(v.numpy(), d["init"][k]), k
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(T, B, dtype=torch.int64), m.state_init(B))
+    # the reference's constructor quirks (vmlmf_lm.py:390-402)
+    with pytest.raises(TypeError):
+        Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vmgroup")
+    assert type(Model(V, H, 1, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vm_group").rnns[0]) is torch.nn.LSTM
+    # the dense baseline runs on CPU in stock ops, and so does the loss there
+    c = Model(V, H, L, 0.0, 0.1, lstm_type="custom")
+    scores, st = c(torch.tensor(d["x0"]), c.state_init(B))
+    assert scores.shape == (T * B, V) and st[0][0].shape == (B, H)
+    z = torch.randn(T * B, V)
+    y = torch.tensor(d["y0"])
+    want = -torch.log_softmax(z, 1)[torch.arange(T * B), y.reshape(-1)].mean() * B
+    assert torch.allclose(nll_loss(z, y), want, rtol=1e-5)

@@ -207,3 +207,47 @@ def test_net_adam_three_steps_literal():
     assert int(d["unused_cell_has_grad"][0]) == 0   # Net.cell duplicate never receives a gradient
     for k, v in d["final"].items():
         close(P[k.split(".")[-1]].detach(), v, 2e-5, 1e-3, "param " + k)
+
+
+def test_nll_loss_restatements_vs_reference():
+    """lm_test.py:140-153 at the PTB vocabulary width: literal (torch) and stable (numpy fp64) restatements."""
+    d = load_golden("nll_v10000")
+    T, B, V, seed = (int(v) for v in d["meta"])
+    r = np.random.Generator(np.random.PCG64(seed))
+    z = (2.0 * r.standard_normal((T * B, V))).astype(np.float32)
+    y = r.integers(0, V, size=(T, B))
+    assert np.array_equal(y, d["y"])
+    zt = torch.tensor(z, requires_grad=True)
+    loss = O.nll_loss_literal(zt, torch.tensor(y))
+    (float(d["upstream"][0]) * loss).backward()
+    assert abs(loss.item() - float(d["loss"][0])) < 1e-5
+    close(zt.grad.numpy()[:, ::97], d["g_s"], 1e-9, 1e-5, "literal grad sample")
+    l2, g2 = O.nll_loss_stable(z, y)
+    assert abs(l2 - float(d["loss"][0])) < 1e-4 * abs(l2)
+    close(float(d["upstream"][0]) * g2[:, ::97], d["g_s"], 1e-8, 1e-4, "stable grad sample")
+    close(float(d["upstream"][0]) * g2[np.arange(T * B), y.reshape(-1)], d["g_target"], 1e-8, 1e-4, "stable grad at targets")
+
+
+def test_lm_network_literal_two_minibatches():
+    """Model (lstm_type "vmlmf") + nll_loss + clip/SGD over two minibatches with carried state (lm_test.py:196-209)."""
+    d = load_golden("lm_model_v3")
+    V, H, L, B, T, rw, ru = (int(v) for v in d["meta"])
+    sd = {k: torch.tensor(v, requires_grad=True) for k, v in d["init"].items()}
+    states = [(torch.zeros(B, H), torch.zeros(B, H)) for _ in range(L)]
+    for i in range(2):
+        for p in sd.values():
+            p.grad = None
+        states = [(h.detach(), c.detach()) for h, c in states]
+        scores, states = O.literal_lm_forward(sd, torch.tensor(d[f"x{i}"]), states, L)
+        loss = O.nll_loss_literal(scores, torch.tensor(d[f"y{i}"]))
+        loss.backward()
+        close(scores.detach(), d[f"scores{i}"], 2e-6, 1e-5, f"scores{i}")
+        assert abs(loss.item() - float(d[f"loss{i}"][0])) < 1e-5
+        grad_close({k: v.grad.numpy() for k, v in sd.items()}, d[f"G{i}"], f"lm G{i}")
+        with torch.no_grad():
+            norm = torch.nn.utils.clip_grad_norm_(list(sd.values()), 0.25)
+            for p in sd.values():
+                p -= 1.0 * p.grad
+        assert abs(float(norm) - float(d[f"norm{i}"][0])) < 1e-4 * float(norm)
+    for k, v in d["final"].items():
+        close(sd[k].detach(), v, 2e-6, 1e-4, "final " + k)

@@ -2,13 +2,14 @@
 MI355X (gfx950), behind the reference's own nn.Module API.
 
     from vmlmf_amd import MyVMLMFCell, MyVMLMFCellg2, MyLSTM, Net      # HAR   (models/vmlmf*.py)
-    from vmlmf_amd import MyVMLSTM, MyVMLSTMGroup                      # LM    (models/vmlmf_lm.py)
+    from vmlmf_amd import MyVMLSTM, MyVMLSTMGroup, Model               # LM    (models/vmlmf_lm.py)
+    from vmlmf_amd import nll_loss                                     #       (train_test/lm_test.py)
 """
 from .cells import MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
-from .lm import MyVMLSTM, MyVMLSTMGroup
-from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss
+from .lm import MyVMLSTM, MyVMLSTMGroup, Embed, LSTM, Linear, Model
+from .functional import vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss, nll_loss
 from . import optim
 from .graphed import GraphedTrainStep
 
 __all__ = ["GraphedTrainStep", "optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyVMLMFgCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
-           "vmlmf_sequence"]
+           "Embed", "LSTM", "Linear", "Model", "nll_loss", "vmlmf_sequence"]

@@ -64,6 +64,8 @@ SYMBOLS = {
     "vmlmf_head_backward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_ce_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
     "vmlmf_ce_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
+    "vmlmf_nll_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),
+    "vmlmf_nll_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),
     "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),

@@ -461,6 +461,22 @@ int vmlmf_ce_backward(int B, int C, const float* logits, const int64_t* target, 
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 
+int vmlmf_nll_forward(int R, int V, const float* scores, const int64_t* y, float scale, float* loss, float* lse,
+                      float* rowloss, void* stream) {
+  if (R < 1 || V < 1) return fail(VMLMF_E_BADARG, "nll: R and V must be >= 1");
+  if (!scores || !y || !loss || !lse || !rowloss) return fail(VMLMF_E_BADARG, "nll: null pointer");
+  hipError_t e = launch_nll_fwd(R, V, scores, (const long long*)y, scale, loss, lse, rowloss, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
+int vmlmf_nll_backward(int R, int V, const float* scores, const int64_t* y, float scale, const float* lse,
+                       const float* dloss, float* dscores, void* stream) {
+  if (R < 1 || V < 1) return fail(VMLMF_E_BADARG, "nll: R and V must be >= 1");
+  if (!scores || !y || !lse || !dloss || !dscores) return fail(VMLMF_E_BADARG, "nll: null pointer");
+  hipError_t e = launch_nll_bwd(R, V, scores, (const long long*)y, scale, lse, dloss, dscores, (hipStream_t)stream);
+  return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
+}
+
 int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int k = 0; k < NKERN; ++k) {

@@ -365,11 +365,14 @@ __host__ __device__ inline int sk_align_class(const float* base, long long ld) {
 // BT: `B` points at B^T (N x K row-major, ldb its row stride): both operands are then read along k, 16 bytes per lane
 // and load (the step-wise path keeps every factor in both orientations); otherwise B is K x N and a lane fetches its
 // column element row by row (four 64-byte segments per load instruction: 3x slower at K = 3072).
-template <int NWV, bool BT, int SK_CH>
+// NSUB: 16-column sub-tiles per workgroup (2: a 16 x 32 tile whose two MFMA chains share the A operand -- for tall
+// products such as dqx = dpre VxT (8960 x 32, K = 3072), where A is the 110 MB operand and should be read once).
+template <int NWV, bool BT, int SK_CH, int NSUB>
 __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
-  __shared__ float4 red[NWV - 1][64];
+  __shared__ float4 red[NSUB][NWV - 1][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
-  const int tiles_n = (a.N + 15) / 16, tiles_m = (a.M + 15) / 16;
+  constexpr int TN = 16 * NSUB;
+  const int tiles_n = (a.N + TN - 1) / TN, tiles_m = (a.M + 15) / 16;
   const int lid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
   int tm, tn;
   if (a.N > a.M) {
@@ -377,47 +380,68 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
   } else {
     tm = lid / tiles_n, tn = lid - tm * tiles_n;
   }
-  const int m0 = tm * 16, n0 = tn * 16;
+  const int m0 = tm * 16, n0 = tn * TN;
   const int nblk = (a.K + 15) / 16, per = (nblk + NWV - 1) / NWV;
   const int kb0 = wave * per * 16;
   const int kb1 = kb0 + per * 16 < a.K ? kb0 + per * 16 : a.K;
-  const bool row_ok = m0 + r < a.M, col_ok = n0 + r < a.N;
+  const bool row_ok = m0 + r < a.M;
+  bool col_ok[NSUB];
+  const float* Bp[NSUB];
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) {
+    col_ok[u] = n0 + 16 * u + r < a.N;
+    const int c = col_ok[u] ? n0 + 16 * u + r : 0;
+    Bp[u] = BT ? a.B + (long long)c * a.ldb : a.B + c;
+  }
   const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
-  const float* Bp = BT ? a.B + (long long)(col_ok ? n0 + r : 0) * a.ldb : a.B + (col_ok ? n0 + r : 0);
   const int acls = sk_align_class(a.A, a.lda), bcls = sk_align_class(a.B, a.ldb);
-  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4v acc[NSUB];
+#pragma unroll
+  for (int u = 0; u < NSUB; ++u) acc[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
   for (int kb = kb0; kb < kb1; kb += 16 * SK_CH) {
-    float av[SK_CH][4], bv[SK_CH][4];
+    float av[SK_CH][4], bv[NSUB][SK_CH][4];
 #pragma unroll
     for (int c = 0; c < SK_CH; ++c) {
       const int k = kb + 16 * c + 4 * q;
       const int n = kb1 - k;   // elements of this quad inside the slice (<= 0: none)
       sk_load4(Ap + k, acls, row_ok ? n : 0, av[c]);
-      if (BT) {
-        sk_load4(Bp + k, bcls, col_ok ? n : 0, bv[c]);
-      } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bv[c][j] = (col_ok && j < n) ? Bp[(long long)(k + j) * a.ldb] : 0.f;
+      for (int u = 0; u < NSUB; ++u) {
+        if (BT) {
+          sk_load4(Bp[u] + k, bcls, col_ok[u] ? n : 0, bv[u][c]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bv[u][c][j] = (col_ok[u] && j < n) ? Bp[u][(long long)(k + j) * a.ldb] : 0.f;
+        }
       }
     }
 #pragma unroll
     for (int c = 0; c < SK_CH; ++c)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[c][j], acc, 0, 0, 0);
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u)
+          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[u][c][j], acc[u], 0, 0, 0);
   }
-  if (wave > 0) red[wave - 1][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+  if (wave > 0) {
+#pragma unroll
+    for (int u = 0; u < NSUB; ++u) red[u][wave - 1][lane] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
+  }
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int w = 0; w < NWV - 1; ++w) {
-      const float4 v = red[w][lane];
-      acc[0] += v.x, acc[1] += v.y, acc[2] += v.z, acc[3] += v.w;
-    }
-    if (col_ok) {
+    for (int u = 0; u < NSUB; ++u) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int row = m0 + 4 * q + i;
-        if (row < a.M) a.C[(long long)row * a.ldc + n0 + r] = acc[i];
+      for (int w = 0; w < NWV - 1; ++w) {
+        const float4 v = red[u][w][lane];
+        acc[u][0] += v.x, acc[u][1] += v.y, acc[u][2] += v.z, acc[u][3] += v.w;
+      }
+      if (col_ok[u]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = m0 + 4 * q + i;
+          if (row < a.M) a.C[(long long)row * a.ldc + n0 + 16 * u + r] = acc[u][i];
+        }
       }
     }
   }
@@ -464,21 +488,19 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
   }
   if (N <= 128 && K >= 256 && g_skinny) {   // skinny output, long K: 16 x 16 tiles, K split inside the workgroup
     const int t16 = ((M + 15) / 16) * ((N + 15) / 16);
-    if (Bt != nullptr && g_skinny_mode == 4) {
+    if (Bt != nullptr && g_skinny_mode == 4) {   // both operands along k (measured slower: rows 12 KB apart)
       a.B = Bt, a.ldb = ldbt;
       if (K >= 1536)
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 12>), dim3(t16), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 12, 1>), dim3(t16), dim3(512), 0, s, a);
       else
-        hipLaunchKernelGGL((gemm_skinny_kernel<4, true, 12>), dim3(t16), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<4, true, 12, 1>), dim3(t16), dim3(256), 0, s, a);
     } else if (K >= 1536) {
-      if (g_skinny_mode == 2)
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 24>), dim3(t16), dim3(512), 0, s, a);
-      else if (g_skinny_mode == 3)
-        hipLaunchKernelGGL((gemm_skinny_kernel<16, false, 12>), dim3(t16), dim3(1024), 0, s, a);
+      if (N % 32 == 0 && t16 >= 1024)   // tall: plenty of tiles, read A once per pair of column tiles
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 2>), dim3(t16 / 2), dim3(512), 0, s, a);
       else
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12>), dim3(t16), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 1>), dim3(t16), dim3(512), 0, s, a);
     } else {
-      hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12>), dim3(t16), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12, 1>), dim3(t16), dim3(256), 0, s, a);
     }
     return (int)hipGetLastError();
   }
@@ -540,18 +562,54 @@ __global__ void __launch_bounds__(256) carry_kernel(VGeo g, int mode, const floa
 }
 
 // dx[row][m] = dqx[row] . ux[m] + sum_k dpre[row][slot(m)][k] * ex[m][k]
+// A workgroup owns DXR consecutive (t, b) rows: their dqx vectors sit in LDS (broadcast reads), a thread keeps the U_x
+// row of its input m in registers and walks the rows, so U_x is fetched once per DXR rows and the stores run along m.
+// (One thread per output with both factors read from memory took 570 us at T*B = 8960, I = 650.)
+constexpr int DXR = 16;
+
+template <int KX>
 __global__ void __launch_bounds__(256) dx_kernel(VGeo g, const float* __restrict__ dqx, const float* __restrict__ dpre,
                                                  const float* __restrict__ uxp, const float* __restrict__ ext,
                                                  float* __restrict__ dx) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  const long long total = (long long)g.T * g.B * g.I;
-  if (e >= total) return;
-  const int row = (int)(e / g.I), m = (int)(e - (long long)row * g.I);
-  const int t = row / g.B, b = row - t * g.B;
-  const float4 d = ld4(dpre + ((size_t)(t * g.Bp + b) * g.NT + vg_slot(g, m)) * 4);
-  float acc = (d.x * ext[0 * g.H + m] + d.y * ext[1 * g.H + m]) + (d.z * ext[2 * g.H + m] + d.w * ext[3 * g.H + m]);
-  for (int r = 0; r < g.KX; ++r) acc = fmaf(dqx[(size_t)row * g.KX + r], uxp[(size_t)m * g.KX + r], acc);
-  dx[(size_t)t * g.sxT + (size_t)b * g.sxB + m] = acc;
+  __shared__ __attribute__((aligned(16))) float sq[DXR][KX];
+  const int row0 = blockIdx.x * DXR, nrows = g.T * g.B;
+  for (int e = threadIdx.x; e < DXR * KX; e += 256) {
+    const int r = e / KX, row = row0 + r;
+    sq[r][e - r * KX] = row < nrows ? dqx[(size_t)row * KX + (e - r * KX)] : 0.f;
+  }
+  __syncthreads();
+  for (int m = threadIdx.x; m < g.I; m += 256) {
+    float u[KX];
+#pragma unroll
+    for (int q = 0; q < KX / 4; ++q) {
+      const float4 v = ld4(uxp + (size_t)m * KX + 4 * q);
+      u[4 * q] = v.x, u[4 * q + 1] = v.y, u[4 * q + 2] = v.z, u[4 * q + 3] = v.w;
+    }
+    const float e0 = ext[0 * g.H + m], e1 = ext[1 * g.H + m], e2 = ext[2 * g.H + m], e3 = ext[3 * g.H + m];
+    const int slot = vg_slot(g, m);
+    float4 d[DXR];
+#pragma unroll
+    for (int r = 0; r < DXR; ++r) {
+      const int row = row0 + r, t = row / g.B, b = row - t * g.B;
+      d[r] = row < nrows ? ld4(dpre + ((size_t)(t * g.Bp + b) * g.NT + slot) * 4) : f4zero();
+    }
+#pragma unroll
+    for (int r = 0; r < DXR; ++r) {
+      const int row = row0 + r;
+      if (row >= nrows) break;
+      float acc = (d[r].x * e0 + d[r].y * e1) + (d[r].z * e2 + d[r].w * e3);
+#pragma unroll
+      for (int q = 0; q < KX / 4; ++q) {
+        const float4 s4 = *reinterpret_cast<const float4*>(&sq[r][4 * q]);
+        acc = fmaf(s4.x, u[4 * q], acc);
+        acc = fmaf(s4.y, u[4 * q + 1], acc);
+        acc = fmaf(s4.z, u[4 * q + 2], acc);
+        acc = fmaf(s4.w, u[4 * q + 3], acc);
+      }
+      const int t = row / g.B, b = row - t * g.B;
+      dx[(size_t)t * g.sxT + (size_t)b * g.sxB + m] = acc;
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -635,9 +693,14 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
                  w.ticket_cap, s)) != 0)
     return rc;
   if (w.dx != nullptr) {
-    const long long total = (long long)T * B * g.I;
-    hipLaunchKernelGGL(dx_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT,
-                       w.dx);
+    const dim3 dgrid((unsigned)((T * B + DXR - 1) / DXR));
+    switch (g.KX) {
+      case 8: hipLaunchKernelGGL(dx_kernel<8>, dgrid, dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT, w.dx); break;
+      case 16: hipLaunchKernelGGL(dx_kernel<16>, dgrid, dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT, w.dx); break;
+      case 24: hipLaunchKernelGGL(dx_kernel<24>, dgrid, dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT, w.dx); break;
+      case 32: hipLaunchKernelGGL(dx_kernel<32>, dgrid, dim3(256), 0, s, g, w.dqx, w.dpre, w.UXP, w.EXT, w.dx); break;
+      default: return -3;
+    }
     if ((rc = (int)hipGetLastError()) != 0) return rc;
   }
   return 0;

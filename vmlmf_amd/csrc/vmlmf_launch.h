@@ -70,5 +70,11 @@ hipError_t launch_ce_fwd(int B, int C, const float* z, const long long* tgt, lon
 hipError_t launch_ce_bwd(int B, int C, const float* z, const long long* tgt, long long ignore_index,
                          const float* lse, const float* nvalid, const float* dloss, float* dz, hipStream_t s);
 
+// softmax negative log-likelihood over the vocabulary (vmlmf_nll.hip)
+hipError_t launch_nll_fwd(int R, int V, const float* scores, const long long* y, float scale, float* loss, float* lse,
+                          float* rowloss, hipStream_t s);
+hipError_t launch_nll_bwd(int R, int V, const float* scores, const long long* y, float scale, const float* lse,
+                          const float* dloss, float* dscores, hipStream_t s);
+
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

@@ -288,3 +288,54 @@ class CrossEntropyLoss(torch.nn.Module):
 
     def forward(self, input, target):
         return cross_entropy(input, target, self.ignore_index)
+
+
+class NllLossFn(torch.autograd.Function):
+    """loss = mean over rows of -log softmax(scores)[row, y[row]] * batch_size (lm_test.py:140-153), one read of
+    `scores` forward, one read and one write backward."""
+
+    @staticmethod
+    def forward(ctx, scores, y, batch_size):
+        ctx.set_materialize_grads(False)
+        _require_hip(scores, "scores")
+        scores = scores.contiguous()
+        yrow = y.reshape(-1).contiguous()
+        R, V = scores.shape
+        scale = float(batch_size) / float(R)
+        stats = torch.empty(1 + 2 * R, device=scores.device, dtype=torch.float32)   # loss | lse | rowloss
+        stream = ctypes.c_void_p(torch.cuda.current_stream(scores.device).cuda_stream)
+        base = stats.data_ptr()
+        with torch.cuda.device(scores.device):
+            _lib.check(_lib.lib().vmlmf_nll_forward(R, V, _ptr(scores), _ptr(yrow), scale, base, base + 4,
+                                                    base + 4 * (1 + R), stream))
+        ctx.save_for_backward(scores, yrow, stats)
+        ctx.scale = scale
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        if dloss is None:
+            return None, None, None
+        scores, yrow, stats = ctx.saved_tensors
+        R, V = scores.shape
+        dloss = dloss.contiguous()
+        dz = torch.empty_like(scores)
+        stream = ctypes.c_void_p(torch.cuda.current_stream(scores.device).cuda_stream)
+        with torch.cuda.device(scores.device):
+            _lib.check(_lib.lib().vmlmf_nll_backward(R, V, _ptr(scores), _ptr(yrow), ctx.scale, stats.data_ptr() + 4,
+                                                     _ptr(dloss), _ptr(dz), stream))
+        return dz, None, None
+
+
+def nll_loss(scores, y):
+    """Drop-in for the reference's language-model loss `nll_loss(scores, y)` (V/src/train_test/lm_test.py:140-153):
+    scores (T*B, V) fp32, y (T, B) int64 -> scalar, scaled by batch_size as there.  On a HIP device the fused
+    kernels run (stable around the row maximum: where the reference's plain exp overflows, this does not);
+    CPU tensors take the reference's own formulation in stock ops."""
+    batch_size = y.size(1)
+    if scores.is_cuda and scores.dim() == 2 and scores.dtype == torch.float32 and y.dtype == torch.int64:
+        return NllLossFn.apply(scores, y, batch_size)
+    expscores = scores.exp()
+    probabilities = expscores / expscores.sum(1, keepdim=True)
+    answerprobs = probabilities[range(len(y.reshape(-1))), y.reshape(-1)]
+    return torch.mean(-torch.log(answerprobs) * batch_size)

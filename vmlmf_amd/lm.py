@@ -3,6 +3,10 @@
   MyVMLSTM       V/src/models/vmlmf_lm.py:178-280   forward(x:(T,B,X), (h,c)) -> (y, (h,c))
   MyVMLSTMGroup  V/src/models/vmlmf_lm.py:53-174    (the reference only runs at batch 40: its scratch is
                                                      hard-coded, 112-113; this implementation has no limit)
+  Embed, LSTM, Linear, Model   V/src/models/vmlmf_lm.py:33-51, 283-343, 345-364, 366-440: the rest of the LM network
+                               around those layers.  Embedding lookup, the vocabulary
+                               projection (one library GEMM) and the dense baseline LSTM are stock ops; the loss that
+                               consumes the scores is vmlmf_amd.nll_loss (fused kernels).
 Parameter names, shapes and registration order follow the reference (state_dict compatible).
 """
 from __future__ import annotations
@@ -101,3 +105,125 @@ class MyVMLSTMGroup(nn.Module):
         h, c = states
         y, hT, cT = self._run(x, h, c)
         return y, (hT, cT)
+
+
+class Embed(nn.Module):
+    """Embedding table indexed by token id (vmlmf_lm.py:33-51)."""
+
+    def __init__(self, vocab_size, embed_size):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.embed_size = embed_size
+        self.w = nn.Parameter(torch.zeros(vocab_size, embed_size))
+
+    def forward(self, x):
+        return self.w[x]
+
+    def __repr__(self):
+        return f"Embedding(vocab: {self.vocab_size}, embedding: {self.embed_size})"
+
+
+class LSTM(nn.Module):
+    """The reference's dense "custom" LSTM layer (vmlmf_lm.py:283-343): the uncompressed baseline, stock GEMMs in
+    the reference's per-timestep loop.  Not the VMLMF path."""
+
+    def __init__(self, input_size, hidden_size, dropout=0):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.dropout = dropout
+        self.w_x = nn.Parameter(torch.zeros(4 * hidden_size, input_size))
+        self.w_h = nn.Parameter(torch.zeros(4 * hidden_size, hidden_size))
+        self.b_x = nn.Parameter(torch.zeros(4 * hidden_size))
+        self.b_h = nn.Parameter(torch.zeros(4 * hidden_size))
+
+    def __repr__(self):
+        return f"LSTM(input: {self.input_size}, hidden: {self.hidden_size})"
+
+    def lstm_step(self, x, h, c, w_x, w_h, b_x, b_h):
+        gx = torch.addmm(b_x, x, w_x.t())
+        gh = torch.addmm(b_h, h, w_h.t())
+        xi, xf, xo, xn = gx.chunk(4, 1)
+        hi, hf, ho, hn = gh.chunk(4, 1)
+        c = torch.sigmoid(xf + hf) * c + torch.sigmoid(xi + hi) * torch.tanh(xn + hn)
+        h = torch.sigmoid(xo + ho) * torch.tanh(c)
+        return h, c
+
+    def forward(self, x, states):
+        h, c = states
+        outputs = []
+        for x_t in x.unbind(0):
+            h, c = self.lstm_step(x_t, h, c, self.w_x, self.w_h, self.b_x, self.b_h)
+            outputs.append(h)
+        return torch.stack(outputs), (h, c)
+
+
+class Linear(nn.Module):
+    """Vocabulary projection (vmlmf_lm.py:345-364): (T, B, H) -> (T*B, V) scores, one library GEMM."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size = input_size
+        self.hidden_size = hidden_size
+        self.w = nn.Parameter(torch.zeros(hidden_size, input_size))
+        self.b = nn.Parameter(torch.zeros(hidden_size))
+
+    def forward(self, x):
+        return torch.addmm(self.b, x.view(-1, x.size(2)), self.w.t())
+
+    def __repr__(self):
+        return f"FC(input: {self.input_size}, output: {self.hidden_size})"
+
+
+class Model(nn.Module):
+    """The language model of lm_test.py (vmlmf_lm.py:366-440): Embed -> dropout -> layer_num x (LSTM layer ->
+    dropout) -> Linear.  Constructor logic is the reference's, quirks included: `u_ranks` is reduced to its last
+    element unless lstm_type is the string "vm_group", while the group layers are only built for the string
+    "vmgroup" -- so, as in the reference, "vmgroup" with a rank list fails in MyVMLSTMGroup's constructor and
+    "vm_group" silently builds torch.nn.LSTM layers.  Build MyVMLSTMGroup layers directly for the group variant."""
+
+    def __init__(self, vocab_size, hidden_size, layer_num, dropout, winit, w_rank=None, u_ranks=None,
+                 lstm_type="pytorch"):
+        super().__init__()
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.layer_num = layer_num
+        self.winit = winit
+        self.lstm_type = lstm_type
+        self.embed = Embed(vocab_size, hidden_size)
+        if u_ranks is not None and lstm_type != "vm_group":
+            u_ranks = u_ranks[-1]
+        if lstm_type == "vmgroup":
+            rnns = [MyVMLSTMGroup(hidden_size, hidden_size, w_rank=w_rank, u_ranks=u_ranks) for _ in range(layer_num)]
+        elif lstm_type != "vmlmf":
+            rnns = [LSTM(hidden_size, hidden_size) if lstm_type == "custom" else nn.LSTM(hidden_size, hidden_size)
+                    for _ in range(layer_num)]
+        else:
+            rnns = [MyVMLSTM(hidden_size, hidden_size, w_rank=w_rank, u_ranks=u_ranks) for _ in range(layer_num)]
+        self.rnns = nn.ModuleList(rnns)
+        self.fc = Linear(hidden_size, vocab_size)
+        self.dropout = nn.Dropout(p=dropout)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for param in self.parameters():
+            nn.init.uniform_(param, -self.winit, self.winit)
+
+    def state_init(self, batch_size):
+        dev = next(self.parameters()).device
+        flat = self.lstm_type in ["custom", "vmlmf", "vmgroup", "hmd"]
+        shape = (lambda layer: (batch_size, layer.hidden_size)) if flat else \
+            (lambda layer: (1, batch_size, layer.hidden_size))
+        return [(torch.zeros(*shape(layer), device=dev), torch.zeros(*shape(layer), device=dev)) for layer in self.rnns]
+
+    def detach(self, states):
+        return [(h.detach(), c.detach()) for (h, c) in states]
+
+    def forward(self, x, states):
+        x = self.embed(x)
+        x = self.dropout(x)
+        for i, rnn in enumerate(self.rnns):
+            x, states[i] = rnn(x, states[i])
+            x = self.dropout(x)
+        scores = self.fc(x)
+        return scores, states
