@@ -215,38 +215,6 @@ __device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
   if (g.pergate) return vg_gate(p.bg, k)[n];
   return p.b_x[vg_xchunk(g, k) * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
 }
-// hoisted diagonal-removal vectors (vmlmf.py:102-106 recomputes them every timestep).
-// All loads are issued before the first FMA (fixed trip count 32 = the rank limit, predicated): a
-// run-time-bounded loop would serialise 2 dependent global loads per rank (~1 us each) in pack_kernel.
-__device__ inline float ref_eh(const VGeo& g, const RefP& p, int n, int k) {
-  if (g.novm) return 0.f;
-  float acc = 0.f;
-  for (int r0 = 0; r0 < g.ru0; r0 += 32) {   // ranks in blocks of 32: loads of a block are issued together
-    float u[32], v[32];
-#pragma unroll
-    for (int r = 0; r < 32; ++r) {
-      u[r] = r0 + r < g.ru0 ? ref_uc(g, p, n, r0 + r) : 0.f;
-      v[r] = r0 + r < g.ru0 ? ref_vc(g, p, n, k, r0 + r) : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
-  }
-  return p.dia_h[n] - acc;
-}
-__device__ inline float ref_ex(const VGeo& g, const RefP& p, int n, int k) {
-  if (n >= g.I || g.novm) return 0.f;
-  float u[32], v[32];
-#pragma unroll
-  for (int r = 0; r < 32; ++r) {
-    u[r] = r < g.rw ? p.u_x[(size_t)n * g.rw + r] : 0.f;
-    v[r] = r < g.rw ? p.v_x[((size_t)k * g.H + n) * g.rw + r] : 0.f;
-  }
-  float acc = 0.f;
-#pragma unroll
-  for (int r = 0; r < 32; ++r) acc = fmaf(u[r], v[r], acc);
-  return p.dia_x[n] - acc;
-}
-
 // thread slot -> unit
 __device__ __forceinline__ bool vg_slot_unit(const VGeo& g, int slot, int& n) {
   const int grp = slot / (64 * g.W);

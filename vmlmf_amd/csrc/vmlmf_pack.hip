@@ -11,140 +11,181 @@
 // Image element (j, slot) is register j of the thread in slot `slot`.  Rotated images serve the DPP
 // reductions: in pass p, step kk, lane i of a 16-lane row multiplies the value it RECEIVES from lane
 // src = i + sgn*kk (mod 16) with the weight that couples that source unit to rank p*16 + i.
-__global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, float* __restrict__ out) {
+//
+// Two kinds of workgroup share the launch.  "Copy" workgroups ([0, ncopy)) produce the elements that are one
+// (re-indexed) parameter each.  "Dot" workgroups produce the elements that are a rank-long dot product (the hoisted
+// diagonal-removal vectors ex / eh and the dense x-side matrix W_x): 32 lanes per element, one rank per lane, a
+// shuffle reduction -- one memory latency per element and a few hundred bytes of code.  (Written as one thread per
+// element with the 32 loads unrolled, this kernel was 107 KB of code, more than the instruction cache holds.)
+struct PackDots {
+  int nEH, nEXI, nEXT, nWXD;   // element counts of the four dot regions (0 when absent)
+};
+
+__device__ __forceinline__ float half_wave_sum(float v) {
+#pragma unroll
+  for (int o = 16; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ex(n,k) = dia_x[n] - sum_r ux(n,r) vx(n,k,r), one rank per lane of a 32-lane group (vmlmf.py:102-106 hoisted)
+__device__ __forceinline__ float dot_ex(const VGeo& g, const RefP& p, int n, int k, int l32) {
+  float acc = 0.f;
+  for (int r = l32; r < g.rw; r += 32) acc = fmaf(ref_ux(g, p, n, r), ref_vx(g, p, n, k, r), acc);
+  return p.dia_x[n] - half_wave_sum(acc);
+}
+
+__global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, PackDots D, int ncopy, float* __restrict__ out) {
+  const int NT = g.NT;
+  if ((int)blockIdx.x >= ncopy) {   // ---- dot elements: 8 per workgroup ----
+    const int l32 = threadIdx.x & 31;
+    int d = ((int)blockIdx.x - ncopy) * 8 + (threadIdx.x >> 5);
+    float v = 0.f;
+    long long dst = -1;
+    if (d < D.nEH) {            // EH[k][slot] = dia_h[n] - sum_r uc(n,r) vc(n,k,r)   (block 0 of the rank space)
+      const int k = d / NT, slot = d - k * NT;
+      int n;
+      dst = L.EH + d;
+      if (vg_slot_unit(g, slot, n) && !g.novm) {
+        float acc = 0.f;
+        for (int r = l32; r < g.ru0; r += 32) acc = fmaf(ref_uc(g, p, n, r), ref_vc(g, p, n, k, r), acc);
+        v = p.dia_h[n] - half_wave_sum(acc);
+      }
+    } else if ((d -= D.nEH) < D.nEXI) {   // EXI[k][slot]
+      const int k = d / NT, slot = d - k * NT;
+      int n;
+      dst = L.EXI + d;
+      if (vg_slot_unit(g, slot, n) && n < g.I && !g.novm) v = dot_ex(g, p, n, k, l32);
+    } else if ((d -= D.nEXI) < D.nEXT) {  // EXT[k][n]
+      const int k = d / g.H, n = d - k * g.H;
+      dst = L.EXT + d;
+      if (n < g.I && !g.novm) v = dot_ex(g, p, n, k, l32);
+    } else if ((d -= D.nEXT) < D.nWXD) {  // WXD[(m*4+k)][slot] = W_x: x[m] -> pre-activation k of the unit in `slot`
+      const int j = d / NT, slot = d - j * NT, m = j >> 2, kk = j & 3;
+      int nn;
+      dst = L.WXD + d;
+      if (vg_slot_unit(g, slot, nn)) {
+        if (nn == m && !g.novm) {
+          v = p.dia_x[nn];      // diag(d_x) + (U V^T with its diagonal removed): the diagonal is d_x itself
+        } else {
+          float acc = 0.f;
+          for (int r = l32; r < g.rw; r += 32) acc = fmaf(ref_ux(g, p, m, r), ref_vx(g, p, nn, kk, r), acc);
+          v = half_wave_sum(acc);
+        }
+      }
+    }
+    if (dst >= 0 && l32 == 0) out[dst] = v;
+    return;
+  }
+  // ---- copy elements ----
   const int lane = threadIdx.x & 63;
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
-  const int NT = g.NT;
-  const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < L.total; e += stride) {
+  const int total = (int)L.total, stride = ncopy * 256;
+  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
     float v = 0.f;
     if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
-      const long long le = e - L.VE;
-      if (le < 4LL * g.KH * NT) {
-        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KH, rr = j % g.KH;
+      const int le = e - (int)L.VE;
+      if (le < 4 * g.KH * NT) {
+        const int j = le / NT, slot = le - j * NT, k = j / g.KH, rr = j - k * g.KH;
         int n;
         if (vg_slot_unit(g, slot, n)) v = ref_vc(g, p, n, k, rr);
       }
     } else if (e < L.VR) {  // UR[(p*16+kk)][slot] = uc(n(src), p*16+i)
-      const long long le = e - L.UR;
-      if (le < 1LL * g.KQ * NT) {
-        const int j = (int)(le / NT), slot = (int)(le % NT), pp = j / 16, kk = j % 16, i = slot & 15;
+      const int le = e - (int)L.UR;
+      if (le < g.KQ * NT) {
+        const int j = le / NT, slot = le - j * NT, pp = j >> 4, kk = j & 15, i = slot & 15;
         const int src = (slot & ~15) | ((i + sgn * kk) & 15);
         int n;
         if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_uc(g, p, n, pp * 16 + i);
       }
     } else if (e < L.UE) {  // VR[(k*KQ + p*16+kk)][slot] = vc(n(src), k, p*16+i)
-      const long long le = e - L.VR;
-      if (le < 4LL * g.KQ * NT) {
-        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KQ, jj = j % g.KQ;
-        const int pp = jj / 16, kk = jj % 16, i = slot & 15;
+      const int le = e - (int)L.VR;
+      if (le < 4 * g.KQ * NT) {
+        const int j = le / NT, slot = le - j * NT, k = j / g.KQ, jj = j - k * g.KQ;
+        const int pp = jj >> 4, kk = jj & 15, i = slot & 15;
         const int src = (slot & ~15) | ((i + sgn * kk) & 15);
         int n;
         if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KH) v = ref_vc(g, p, n, k, pp * 16 + i);
       }
     } else if (e < L.EH) {  // UE[rr][slot] = uc(n, rr)
-      const long long le = e - L.UE;
-      if (le < 1LL * g.KH * NT) {
-        const int rr = (int)(le / NT), slot = (int)(le % NT);
+      const int le = e - (int)L.UE;
+      if (le < g.KH * NT) {
+        const int rr = le / NT, slot = le - rr * NT;
         int n;
         if (vg_slot_unit(g, slot, n)) v = ref_uc(g, p, n, rr);
       }
-    } else if (e < L.VRX) {  // EH[k][slot]
-      const long long le = e - L.EH;
-      if (le < 4LL * NT) {
-        const int k = (int)(le / NT), slot = (int)(le % NT);
-        int n;
-        if (vg_slot_unit(g, slot, n)) v = ref_eh(g, p, n, k);
-      }
+    } else if (e < L.VRX) {  // EH: dot workgroups; the alignment gap behind it is zeroed here
+      if (e - (int)L.EH < D.nEH) continue;
     } else if (e < L.UXO) {  // VRX[(k*KQX + p*16+kk)][slot] = vx(n(src), k, p*16+i)
-      const long long le = e - L.VRX;
-      if (le < 4LL * g.KQX * NT) {
-        const int j = (int)(le / NT), slot = (int)(le % NT), k = j / g.KQX, jj = j % g.KQX;
-        const int pp = jj / 16, kk = jj % 16, i = slot & 15;
+      const int le = e - (int)L.VRX;
+      if (le < 4 * g.KQX * NT) {
+        const int j = le / NT, slot = le - j * NT, k = j / g.KQX, jj = j - k * g.KQX;
+        const int pp = jj >> 4, kk = jj & 15, i = slot & 15;
         const int src = (slot & ~15) | ((i + sgn * kk) & 15);
         int n;
         if (vg_slot_unit(g, src, n) && pp * 16 + i < g.KX) v = ref_vx(g, p, n, k, pp * 16 + i);
       }
     } else if (e < L.EXI) {  // UXO[r][slot] = ux(n, r) for x-units
-      const long long le = e - L.UXO;
-      if (le < 1LL * g.KX * NT) {
-        const int r = (int)(le / NT), slot = (int)(le % NT);
+      const int le = e - (int)L.UXO;
+      if (le < g.KX * NT) {
+        const int r = le / NT, slot = le - r * NT;
         int n;
         if (vg_slot_unit(g, slot, n) && n < g.I) v = ref_ux(g, p, n, r);
       }
-    } else if (e < L.UXP) {  // EXI[k][slot]
-      const long long le = e - L.EXI;
-      if (le < 4LL * NT) {
-        const int k = (int)(le / NT), slot = (int)(le % NT);
-        int n;
-        if (vg_slot_unit(g, slot, n)) v = ref_ex(g, p, n, k);
-      }
+    } else if (e < L.UXP) {  // EXI: dot workgroups
+      if (e - (int)L.EXI < D.nEXI) continue;
     } else if (e < L.VXT) {  // UXP[m][r]  row-major, rank padded
-      const long long le = e - L.UXP;
-      if (le < 1LL * g.I * g.KX) v = ref_ux(g, p, (int)(le / g.KX), (int)(le % g.KX));
-    } else if (e < L.EXT) {  // VXT[(k*KX+r)][n]
-      const long long le = e - L.VXT;
-      if (le < 4LL * g.KX * g.H) {
-        const int j = (int)(le / g.H), n = (int)(le % g.H);
-        v = ref_vx(g, p, n, j / g.KX, j % g.KX);
+      const int le = e - (int)L.UXP;
+      if (le < g.I * g.KX) {
+        const int m = le / g.KX;
+        v = ref_ux(g, p, m, le - m * g.KX);
       }
-    } else if (e < L.BBT) {  // EXT[k][n]
-      const long long le = e - L.EXT;
-      if (le < 4LL * g.H) v = ref_ex(g, p, (int)(le % g.H), (int)(le / g.H));
+    } else if (e < L.EXT) {  // VXT[(k*KX+r)][n]
+      const int le = e - (int)L.VXT;
+      if (le < 4 * g.KX * g.H) {
+        const int j = le / g.H, n = le - j * g.H, k = j / g.KX;
+        v = ref_vx(g, p, n, k, j - k * g.KX);
+      }
+    } else if (e < L.BBT) {  // EXT: dot workgroups
+      if (e - (int)L.EXT < D.nEXT) continue;
     } else if (e < L.UD) {  // BBT[k][n]
-      const long long le = e - L.BBT;
-      if (le < 4LL * g.H) v = ref_bb(g, p, (int)(le % g.H), (int)(le / g.H));
+      const int le = e - (int)L.BBT;
+      if (le < 4 * g.H) {
+        const int k = le / g.H;
+        v = ref_bb(g, p, le - k * g.H, k);
+      }
     } else {  // step-wise path: group structure written out densely
       const int GK = g.G * g.KH, N4 = 4 * NT;
       int n = -1, k = 0, rr = 0, j = 0, mode = 0;   // mode 1: U element (n, j, rr)   2: V element (n, k, j, rr)   3: Vx
       if (e < L.VD) {           // UD[n][j*KH+rr]
-        const long long le = e - L.UD;
-        if (le < (long long)g.H * GK) { n = (int)(le / GK); const int c = (int)(le % GK); j = c / g.KH; rr = c % g.KH; mode = 1; }
+        const int le = e - (int)L.UD;
+        if (le < g.H * GK) { n = le / GK; const int c = le - n * GK; j = c / g.KH; rr = c - j * g.KH; mode = 1; }
       } else if (e < L.UDT) {   // VD[j*KH+rr][slot*4+k]
-        const long long le = e - L.VD;
-        if (le < (long long)GK * N4) {
-          const int c = (int)(le / N4), i = (int)(le % N4);
-          j = c / g.KH; rr = c % g.KH; k = i & 3;
+        const int le = e - (int)L.VD;
+        if (le < GK * N4) {
+          const int c = le / N4, i = le - c * N4;
+          j = c / g.KH; rr = c - j * g.KH; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
         }
       } else if (e < L.VDT) {   // UDT[j*KH+rr][n]
-        const long long le = e - L.UDT;
-        if (le < (long long)GK * g.H) { const int c = (int)(le / g.H); n = (int)(le % g.H); j = c / g.KH; rr = c % g.KH; mode = 1; }
+        const int le = e - (int)L.UDT;
+        if (le < GK * g.H) { const int c = le / g.H; n = le - c * g.H; j = c / g.KH; rr = c - j * g.KH; mode = 1; }
       } else if (e < L.VXTT) {  // VDT[slot*4+k][j*KH+rr]
-        const long long le = e - L.VDT;
-        if (le < (long long)N4 * GK) {
-          const int i = (int)(le / GK), c = (int)(le % GK);
-          j = c / g.KH; rr = c % g.KH; k = i & 3;
+        const int le = e - (int)L.VDT;
+        if (le < N4 * GK) {
+          const int i = le / GK, c = le - i * GK;
+          j = c / g.KH; rr = c - j * g.KH; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
         }
       } else if (e < L.TKT) {   // VXTT[slot*4+k][r]
-        const long long le = e - L.VXTT;
-        if (le < (long long)N4 * g.KX) {
-          const int i = (int)(le / g.KX);
-          rr = (int)(le % g.KX); k = i & 3;
+        const int le = e - (int)L.VXTT;
+        if (le < N4 * g.KX) {
+          const int i = le / g.KX;
+          rr = le - i * g.KX; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
         }
-      } else if (e >= L.WXD) {  // WXD[(m*4+k)][slot] = W_x: x[m] -> pre-activation k of the unit in `slot`
-        const long long le = e - L.WXD;
-        if (le < 4LL * g.I * NT) {
-          const int j = (int)(le / NT), slot = (int)(le % NT), m = j >> 2, kk = j & 3;
-          int nn;
-          if (vg_slot_unit(g, slot, nn)) {
-            if (nn == m && !g.novm) {
-              v = p.dia_x[nn];      // diag(d_x) + (U V^T with its diagonal removed): the diagonal is d_x itself
-            } else {
-              float u[32], w[32];
-#pragma unroll
-              for (int r = 0; r < 32; ++r) {
-                u[r] = ref_ux(g, p, m, r);
-                w[r] = ref_vx(g, p, nn, kk, r);
-              }
-#pragma unroll
-              for (int r = 0; r < 32; ++r) v = fmaf(u[r], w[r], v);
-            }
-          }
-        }
+      } else if (e >= L.WXD) {  // WXD: dot workgroups
+        if (e - (int)L.WXD < D.nWXD) continue;
       }                         // else TKT: the split-K tickets start at zero
       if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s
         const int sblk = (g.G == 2 && rr >= g.off1) ? 1 : 0;
@@ -162,8 +203,16 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, floa
 }
 
 int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s) {
-  const int blocks = (int)((L.total + 255) / 256);
-  hipLaunchKernelGGL(pack_kernel, dim3(blocks < 2048 ? blocks : 2048), dim3(256), 0, s, g, p, L, pack);
+  if (L.total >= (1LL << 31)) return -3;
+  PackDots D;
+  D.nEH = 4 * g.NT;
+  D.nEXI = (int)(L.UXP - L.EXI) > 0 ? 4 * g.NT : 0;
+  D.nEXT = 4 * g.H;
+  D.nWXD = (L.total - L.WXD) > 0 ? 4 * g.I * g.NT : 0;
+  int ncopy = (int)((L.total + 255) / 256);
+  if (ncopy > 2048) ncopy = 2048;
+  const int ndot = (D.nEH + D.nEXI + D.nEXT + D.nWXD + 7) / 8;
+  hipLaunchKernelGGL(pack_kernel, dim3(ncopy + ndot), dim3(256), 0, s, g, p, L, D, ncopy, pack);
   return (int)hipGetLastError();
 }
 
