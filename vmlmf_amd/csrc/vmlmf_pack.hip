@@ -219,9 +219,10 @@ int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipSt
 // ---------------------------------------------------------------------------------------------------
 // xproj: the non-recurrent half of the gate pre-activations for every (t,b) row
 // ---------------------------------------------------------------------------------------------------
-constexpr int XR = 8;  // rows per workgroup (measured at the headline shape: 4 -> 19.1 us, 8 -> 15.5, 16 -> 16.7, 32 slower still)
-
-template <int KX>
+// XR: rows per workgroup.  A thread reloads its slots' V_x rows (4 KX floats per slot) once per workgroup, so the
+// L2 traffic for them is rows / XR times the matrix: 8 is best at the headline shape (8192 rows, measured: 4 -> 19.1 us,
+// 8 -> 15.5, 16 -> 16.7, 32 slower still: too few workgroups), 16 for the long LM shapes (8960 rows x 768 slots).
+template <int KX, int XR>
 __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restrict__ x,
                                                     const float* __restrict__ uxp,
                                                     const float* __restrict__ vxt,
@@ -247,24 +248,48 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
     xs[idx] = v;
   }
   __syncthreads();
-  for (int idx = tid; idx < XR * KX; idx += 256) {
-    const int r = idx / KX, j = idx - r * KX, rp = row0 + r;
-    float acc = 0.f;
-    // the U_x loads of 8 consecutive inputs are issued together (a one-load-per-iteration loop is a chain of I
-    // L2 latencies: 22 us per launch at I = 256); the summation order stays sequential in m
-    int m = 0;
-    for (; m + 8 <= I; m += 8) {
-      float u[8];
+  // qx = x U_x for the XR rows.  Thread (j, c) owns rank j and the c-th of NC input chunks: a U_x element is loaded
+  // once per workgroup and serves all XR rows, and a thread's loads are I / NC long (8 in flight at a time) -- one
+  // thread per (row, rank) walking all of I was a chain of I / 8 L2 latencies (57 us of the 138 at I = 650).
+  // Chunk partials meet in LDS and are summed in chunk order.
+  {
+    constexpr int NC = 256 / KX;
+    float* part = qs + XR * KX;   // [NC][XR][KX]
+    const int j = tid % KX, c = tid / KX;
+    if (c < NC) {
+      const int per = (I + NC - 1) / NC, m0 = c * per, m1 = m0 + per < I ? m0 + per : I;
+      float acc[XR];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) u[i] = uxp[(m + i) * KX + j];
+      for (int r = 0; r < XR; ++r) acc[r] = 0.f;
+      int m = m0;
+      for (; m + 8 <= m1; m += 8) {
+        float u[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) acc = fmaf(xs[r * I + m + i], u[i], acc);
+        for (int i = 0; i < 8; ++i) u[i] = uxp[(m + i) * KX + j];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+          for (int r = 0; r < XR; ++r) acc[r] = fmaf(xs[r * I + m + i], u[i], acc[r]);
+      }
+      for (; m < m1; ++m) {
+        const float u = uxp[m * KX + j];
+#pragma unroll
+        for (int r = 0; r < XR; ++r) acc[r] = fmaf(xs[r * I + m], u, acc[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < XR; ++r) part[(c * XR + r) * KX + j] = acc[r];
     }
-    for (; m < I; ++m) acc = fmaf(xs[r * I + m], uxp[m * KX + j], acc);
-    qs[idx] = acc;
-    if (qx != nullptr && rp < TBp) {
-      const int t = rp / g.Bp, b = rp - t * g.Bp;
-      if (b < g.B) qx[(size_t)(t * g.B + b) * KX + j] = acc;
+    __syncthreads();
+    for (int idx = tid; idx < XR * KX; idx += 256) {
+      const int r = idx / KX, rp = row0 + r;
+      float acc = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) acc += part[cc * XR * KX + idx];
+      qs[idx] = acc;
+      if (qx != nullptr && rp < TBp) {
+        const int t = rp / g.Bp, b = rp - t * g.Bp;
+        if (b < g.B) qx[(size_t)(t * g.B + b) * KX + (idx - r * KX)] = acc;
+      }
     }
   }
   __syncthreads();
@@ -310,12 +335,22 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
                  hipStream_t s) {
   const int TBp = g.T * g.Bp;
-  const dim3 grid((TBp + XR - 1) / XR), block(256);
-  const size_t lds = sizeof(float) * (size_t)(XR * g.I + XR * g.KX);
+  const int xr = 8;   // 16 (template variant kept) measured no faster at 8960 rows: the V_x reloads are not the bound
+  const dim3 grid((TBp + xr - 1) / xr), block(256);
+  const size_t lds = sizeof(float) * ((size_t)xr * g.I + (size_t)xr * g.KX + (size_t)(256 / g.KX) * xr * g.KX);
   const float *uxp = pack + L.UXP, *vxt = pack + L.VXT, *ext = pack + L.EXT, *bbt = pack + L.BBT;
-#define VX_CASE(K)                                                                                     \
-  case K:                                                                                              \
-    hipLaunchKernelGGL(xproj_kernel<K>, grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);        \
+#define VX_CASE(K)                                                                                          \
+  case K:                                                                                                   \
+    if (xr == 16) {                                                                                         \
+      if (lds > 48 * 1024) {                                                                                \
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(xproj_kernel<K, 16>),        \
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     \
+        if (e != hipSuccess) return (int)e;                                                                 \
+      }                                                                                                     \
+      hipLaunchKernelGGL((xproj_kernel<K, 16>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);     \
+    } else {                                                                                                \
+      hipLaunchKernelGGL((xproj_kernel<K, 8>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);      \
+    }                                                                                                       \
     break;
   switch (g.KX) {
     VX_CASE(8)
