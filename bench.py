@@ -161,11 +161,15 @@ def main():
     import vmlmf_amd
     criterion = torch.nn.functional.cross_entropy if args.torch_loss else vmlmf_amd.cross_entropy
 
+    # d(loss)/d(loss) = 1, allocated once: loss.backward() alone makes autograd fill a fresh ones_like(loss) every step
+    # (one more 4 us launch between the loss and its backward); same gradient either way
+    one = torch.ones((), device=dev)
+
     def fwd_bwd():
         net.zero_grad(set_to_none=True)
         out = net(x)
         loss = criterion(out, tgt)
-        loss.backward()
+        loss.backward(one)
         return loss
 
     def step():

@@ -129,6 +129,7 @@ CASES = [
     (O.V2, 4, 3, 10, 48, 4, [24, 20], False, True),  # group ranks pad to 24 + 24 = 48
     (O.V3, 6, 4, 70, 70, 9, [33], True, True),       # rank 33 -> padded 40
     (O.V4, 7, 3, 44, 44, 5, [20, 36], True, True),   # flat layout, padded 24 + 40 = 64
+    (O.V1, 512, 16, 20, 330, 32, [40], False, False),  # 8192 rows, K = 1536: the 16 x 32 skinny tiles of dqx = dpre VxT
     # the cells without vm: per-gate factor tensors (V5), both sides chunked (f,i,n,o) (V6)
     (O.V5, 5, 6, 9, 70, 5, [7], False, True),
     (O.V5, 3, 4, 40, 200, 24, [32], False, False),   # wide input: x-projection kernel, no x-fold

@@ -24,6 +24,9 @@ class GraphedTrainStep:
         self.x = example_input.clone()
         self.t = example_target.clone()
         dev = self.x.device
+        # root gradient of the scalar loss, kept across replays (a bare loss.backward() fills a new ones_like(loss)
+        # inside every step: one more launch on the critical path)
+        self._one = torch.ones((), device=dev)
         if warmup < 1:
             raise ValueError("at least one warm-up step: optimizer state must exist before the capture")
         if dev.type != "cuda":
@@ -44,7 +47,7 @@ class GraphedTrainStep:
     def _body(self):
         self.model.zero_grad(set_to_none=True)
         loss = self.criterion(self.model(self.x), self.t)
-        loss.backward()
+        loss.backward(self._one if loss.dim() == 0 and loss.dtype == self._one.dtype else None)
         self.optimizer.step()
         return loss.detach()
 
