@@ -161,9 +161,10 @@ def main():
     import vmlmf_amd
     criterion = torch.nn.functional.cross_entropy if args.torch_loss else vmlmf_amd.cross_entropy
 
-    # d(loss)/d(loss) = 1, allocated once: loss.backward() alone makes autograd fill a fresh ones_like(loss) every step
-    # (one more 4 us launch between the loss and its backward); same gradient either way
-    one = torch.ones((), device=dev)
+    # d(loss)/d(loss) = 1 as the package's constant tensor: loss.backward() alone makes autograd fill a fresh
+    # ones_like(loss) every step (a 4 us launch between the loss and its backward), and the fused criterion returns the
+    # gradient its forward kernel already wrote when it is handed this tensor; same values either way
+    one = vmlmf_amd.unit_gradient(dev)
 
     def fwd_bwd():
         net.zero_grad(set_to_none=True)

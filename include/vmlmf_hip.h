@@ -129,9 +129,11 @@ int vmlmf_head_backward(int B, int H, int C, const float *h, long long ldh, cons
  * log-sum-exps lse (B) and the number of counted rows nvalid (1); backward turns them and the incoming
  * gradient of the loss (device scalar) into dlogits (B,C).  One workgroup in forward: meant for classifier
  * sized problems (the Python wrapper dispatches B*C <= 65536 here and leaves larger ones to the library op).
+ * dlogits_unit (B,C), optional: forward also writes the gradient for dloss = 1 there, so a caller that knows its
+ * incoming gradient is one (loss.backward() of the training loop) needs no backward launch.
  */
 int vmlmf_ce_forward(int B, int C, const float *logits, const int64_t *target, int64_t ignore_index, float *loss,
-                     float *lse, float *nvalid, void *stream);
+                     float *lse, float *nvalid, float *dlogits_unit, void *stream);
 int vmlmf_ce_backward(int B, int C, const float *logits, const int64_t *target, int64_t ignore_index,
                       const float *lse, const float *nvalid, const float *dloss, float *dlogits, void *stream);
 

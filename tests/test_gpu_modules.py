@@ -370,3 +370,30 @@ def test_lm_network_two_minibatches_vs_reference():
     for k, v in d["final"].items():
         assert_out(sd[k].cpu().numpy(), v, "final." + k, atol=2e-5, rtol=1e-3)
     assert_out(torch.stack([s[0].detach() for s in states]).cpu().numpy(), d["hT"], "hT")
+
+
+def test_cross_entropy_unit_gradient_shortcut_equals_the_general_backward():
+    """loss.backward(unit_gradient(dev)) returns the gradient the forward kernel wrote; loss.backward() and an explicit
+    other scale take the backward kernel.  All three must agree (the first two bit for bit)."""
+    import vmlmf_amd
+    torch.manual_seed(5)
+    z0 = torch.randn(64, 18, device=DEV)
+    t = torch.randint(0, 18, (64,), device=DEV)
+    t[3] = -100
+    grads = []
+    for mode in ("unit", "implicit", "scaled"):
+        z = z0.clone().requires_grad_(True)
+        loss = vmlmf_amd.cross_entropy(z, t)
+        if mode == "unit":
+            loss.backward(vmlmf_amd.unit_gradient(DEV))
+        elif mode == "implicit":
+            loss.backward()
+        else:
+            loss.backward(torch.tensor(2.5, device=DEV))
+        grads.append(z.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert torch.allclose(grads[2], 2.5 * grads[0], rtol=1e-6, atol=0)
+    zr = z0.clone().requires_grad_(True)
+    torch.nn.functional.cross_entropy(zr, t).backward()
+    assert torch.allclose(grads[0], zr.grad, rtol=1e-5, atol=1e-7)
+    assert vmlmf_amd.unit_gradient(DEV) is vmlmf_amd.unit_gradient("cuda") and float(vmlmf_amd.unit_gradient(DEV)) == 1.0

@@ -62,7 +62,7 @@ SYMBOLS = {
                                 _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp]),
     "vmlmf_head_forward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),
     "vmlmf_head_backward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "vmlmf_ce_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp]),
+    "vmlmf_ce_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_ce_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_nll_forward": (_i, [_i, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),
     "vmlmf_nll_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),

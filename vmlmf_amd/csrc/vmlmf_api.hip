@@ -441,12 +441,13 @@ int vmlmf_head_backward(int B, int H, int C, const float* h, long long ldh, cons
 }
 
 int vmlmf_ce_forward(int B, int C, const float* logits, const int64_t* target, int64_t ignore_index, float* loss,
-                     float* lse, float* nvalid, void* stream) {
+                     float* lse, float* nvalid, float* dlogits_unit, void* stream) {
   if (B < 1 || C < 1) return fail(VMLMF_E_BADARG, "ce: B and C must be >= 1");
   if (!logits || !target || !loss || !lse || !nvalid) return fail(VMLMF_E_BADARG, "ce: null pointer");
   hipStream_t s = (hipStream_t)stream;
   Scope sc(10, s);
-  hipError_t e = launch_ce_fwd(B, C, logits, (const long long*)target, (long long)ignore_index, loss, lse, nvalid, s);
+  hipError_t e = launch_ce_fwd(B, C, logits, (const long long*)target, (long long)ignore_index, loss, lse, nvalid,
+                               dlogits_unit, s);
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 

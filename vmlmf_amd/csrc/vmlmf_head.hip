@@ -162,26 +162,54 @@ hipError_t launch_head_bwd(int B, int H, int C, const float* h, long long ldh, c
 // ---------------------------------------------------------------------------------------------------
 namespace {
 
-// row statistics: lse[b] = log sum_c exp(z[b][c]);  loss = -(1/N) sum_valid (z[b][t_b] - lse[b])
+// row statistics: lse[b] = log sum_c exp(z[b][c]);  loss = -(1/N) sum_valid (z[b][t_b] - lse[b]).
+// Four lanes share a row (classes c = q, q + 4, ...: the loads of a row are independent and issued together, the row
+// maximum and sum meet through two quad shuffles), 64 rows per pass of the single workgroup.  CQ = classes per lane
+// held in registers (rows up to 4 CQ wide); wider rows re-read z (L1-resident) instead.
+template <int CQ>
 __global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* __restrict__ z,
                                                      const long long* __restrict__ tgt, long long ignore_index,
                                                      float* __restrict__ loss, float* __restrict__ lse,
-                                                     float* __restrict__ nvalid) {
+                                                     float* __restrict__ nvalid, float* __restrict__ dz_unit) {
   __shared__ float ssum[256];
   __shared__ float scnt[256];
+  const int q = threadIdx.x & 3;
   float part = 0.f, cnt = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) {
-    const float* zb = z + (size_t)b * C;
+  for (int b0 = 0; b0 < B; b0 += 64) {
+    const int b = b0 + (threadIdx.x >> 2);
+    const bool rok = b < B;
+    const float* zb = z + (size_t)(rok ? b : 0) * C;
+    float v[CQ > 0 ? CQ : 1];
     float m = -INFINITY;
-    for (int c = 0; c < C; ++c) m = fmaxf(m, zb[c]);
+    if (CQ > 0) {
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) {
+        const int c = q + 4 * i;
+        v[i] = (rok && c < C) ? zb[c] : -INFINITY;
+        m = fmaxf(m, v[i]);
+      }
+    } else {
+      for (int c = q; c < C; c += 4) m = fmaxf(m, rok ? zb[c] : -INFINITY);
+    }
+    m = fmaxf(m, __shfl_xor(m, 1, 64));
+    m = fmaxf(m, __shfl_xor(m, 2, 64));
     float s = 0.f;
-    for (int c = 0; c < C; ++c) s += expf(zb[c] - m);
+    if (CQ > 0) {
+#pragma unroll
+      for (int i = 0; i < CQ; ++i) s += expf(v[i] - m);   // exp(-inf) = 0 for the padding
+    } else {
+      for (int c = q; c < C; c += 4) s += rok ? expf(zb[c] - m) : 0.f;
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
     const float l = m + logf(s);
-    lse[b] = l;
-    const long long t = tgt[b];
-    if (t != ignore_index) {
-      part += l - zb[t];
-      cnt += 1.f;
+    if (rok && q == 0) {
+      lse[b] = l;
+      const long long t = tgt[b];
+      if (t != ignore_index) {
+        part += l - zb[t];
+        cnt += 1.f;
+      }
     }
   }
   ssum[threadIdx.x] = part;
@@ -197,6 +225,17 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* 
   if (threadIdx.x == 0) {
     *nvalid = scnt[0];
     *loss = ssum[0] / scnt[0];   // 0/0 = NaN when every target is ignored, as PyTorch returns
+  }
+  // the gradient for d(loss) = 1, while the rows are still in cache: a backward whose incoming gradient is known to be
+  // one needs no launch of its own (ce_bwd_kernel's arithmetic, same operation order)
+  if (dz_unit != nullptr) {
+    const float scale = 1.f / scnt[0];
+    for (int e = threadIdx.x; e < B * C; e += 256) {
+      const int b = e / C, c = e - b * C;
+      const long long t = tgt[b];
+      const float p = expf(z[e] - lse[b]);   // lse[b] was written by this workgroup before the barriers above
+      dz_unit[e] = t == ignore_index ? 0.f : scale * (p - (c == (int)t ? 1.f : 0.f));
+    }
   }
 }
 
@@ -218,8 +257,11 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int B, int C, const float* 
 }  // namespace
 
 hipError_t launch_ce_fwd(int B, int C, const float* z, const long long* tgt, long long ignore_index, float* loss,
-                         float* lse, float* nvalid, hipStream_t s) {
-  hipLaunchKernelGGL(ce_fwd_kernel, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid);
+                         float* lse, float* nvalid, float* dz_unit, hipStream_t s) {
+  if (C <= 32)
+    hipLaunchKernelGGL(ce_fwd_kernel<8>, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
+  else
+    hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
   return hipGetLastError();
 }
 

@@ -66,7 +66,7 @@ hipError_t launch_head_bwd(int B, int H, int C, const float* h, long long ldh, c
                            float* dh, float* dW, float* db, hipStream_t s);
 
 hipError_t launch_ce_fwd(int B, int C, const float* z, const long long* tgt, long long ignore_index, float* loss,
-                         float* lse, float* nvalid, hipStream_t s);
+                         float* lse, float* nvalid, float* dz_unit, hipStream_t s);
 hipError_t launch_ce_bwd(int B, int C, const float* z, const long long* tgt, long long ignore_index,
                          const float* lse, const float* nvalid, const float* dloss, float* dz, hipStream_t s);
 

@@ -234,8 +234,27 @@ def head_linear(h, weight, bias):
     return torch.nn.functional.linear(h, weight, bias)
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """The constant 1.0 as a 0-d fp32 tensor on `device`, one object per device, never written.  `loss.backward()` makes
+    autograd fill a fresh ones_like(loss) in every step; `loss.backward(vmlmf_amd.unit_gradient(loss.device))` is the
+    same gradient without that launch, and the fused criteria recognise this very tensor as "scale 1" and return
+    the gradient their forward kernel already wrote instead of launching a backward kernel."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    t = _UNIT.get(device)
+    if t is None:
+        t = torch.ones((), device=device, dtype=torch.float32)
+        _UNIT[device] = t
+    return t
+
+
 class CrossEntropyFn(torch.autograd.Function):
-    """Mean cross-entropy of (B, C) logits against int64 targets, forward and backward in one launch each."""
+    """Mean cross-entropy of (B, C) logits against int64 targets, forward and backward in one launch each (and no
+    backward launch at all when the incoming gradient is unit_gradient(device))."""
 
     @staticmethod
     def forward(ctx, logits, target, ignore_index):
@@ -245,18 +264,22 @@ class CrossEntropyFn(torch.autograd.Function):
         B, C = logits.shape
         dev = logits.device
         stats = torch.empty(B + 2, device=dev, dtype=torch.float32)     # loss | nvalid | lse[B]
+        dz_unit = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
         stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         with torch.cuda.device(dev):
             _lib.check(_lib.lib().vmlmf_ce_forward(B, C, _ptr(logits), _ptr(target), int(ignore_index),
                                                    stats.data_ptr(), stats.data_ptr() + 8, stats.data_ptr() + 4,
-                                                   stream))
-        ctx.save_for_backward(logits, target, stats)
+                                                   _ptr(dz_unit), stream))
+        ctx.save_for_backward(logits, target, stats, *([dz_unit] if dz_unit is not None else []))
         ctx.ignore_index = int(ignore_index)
         return stats[0]
 
     @staticmethod
     def backward(ctx, dloss):
-        logits, target, stats = ctx.saved_tensors
+        logits, target, stats = ctx.saved_tensors[:3]
+        unit = _UNIT.get(logits.device)
+        if unit is not None and dloss.data_ptr() == unit.data_ptr() and len(ctx.saved_tensors) == 4:
+            return ctx.saved_tensors[3], None, None     # d(loss) is the package's constant one: forward wrote this
         B, C = logits.shape
         dloss = dloss.contiguous()
         dz = torch.empty_like(logits)

@@ -15,6 +15,8 @@ import gc
 
 import torch
 
+from .functional import unit_gradient
+
 
 class GraphedTrainStep:
     def __init__(self, model, criterion, optimizer, example_input, example_target, warmup=3):
@@ -26,7 +28,7 @@ class GraphedTrainStep:
         dev = self.x.device
         # root gradient of the scalar loss, kept across replays (a bare loss.backward() fills a new ones_like(loss)
         # inside every step: one more launch on the critical path)
-        self._one = torch.ones((), device=dev)
+        self._one = unit_gradient(dev)
         if warmup < 1:
             raise ValueError("at least one warm-up step: optimizer state must exist before the capture")
         if dev.type != "cuda":
