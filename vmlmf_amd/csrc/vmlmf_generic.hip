@@ -7,9 +7,9 @@
 //     P_t   = Q_t Vd                (B x G*KH)(G*KH x 4*slots) gemm_tile_kernel<1> (fp32 MFMA 32x32x2), whose epilogue is
 //     gates, c_t, h_t               elementwise                the forward gate math (gates_fwd_one)
 // and in reverse
-//     dpre_t from the tape          elementwise                gates_bwd_kernel
 //     dQ_t  = dpre_t VdT            (B x 4*slots)(4*slots x G*KH)   gemm_skinny_kernel
-//     dH_{t-1} = dQ_t UdT           (B x G*KH)(G*KH x H)            gemm_tile_kernel<0>
+//     dH_{t-1} = dQ_t UdT           (B x G*KH)(G*KH x H)            gemm_rows16_kernel<2>, whose epilogue is
+//     dpre_{t-1} from the tape      elementwise                     the gate derivatives (gates_bwd_kernel for step T-1)
 // Ud/Vd are the group structure written out densely (zeros where a unit does not feed / read a rank-space
 // vector); they are produced by pack_kernel.  The non-recurrent kernels (xproj, wgrad_mfma, reduce, finish)
 // are shared with the persistent path; dqx / dx use the same GEMM kernel over all T*B rows.
@@ -172,7 +172,8 @@ struct GemmArgs {
 };
 
 // EPI 1: C = P_t is not stored; each (row, slot) of the tile goes straight through the forward gate math.
-// EPI 2: C = dH_rec is not stored; each (row, unit) of the tile continues into the gate derivatives of step e.b.t.
+// (The backward counterpart lives in gemm_rows16_kernel: on 64 x 64 tiles dH_rec has 44 of them and they carried all
+// of the element-wise work, 19.5 us against 8.9 + 5.2 unfused.)
 template <int EPI>
 __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a, EpiArgs e) {
   extern __shared__ float4 gsm4[];
@@ -261,23 +262,6 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a, EpiArgs e) {
         for (int i = 0; i < 4; ++i) {
           const int row = (tid >> 4) + 16 * i, b = m0 + row;
           if (b < a.M) gates_fwd_finish(e.g, e.f, b, slot, in[i], *reinterpret_cast<const float4*>(&Ct[row][4 * sl]));
-        }
-      }
-    } else {          // thread -> unit n0 + tid % 64 of rows tid/64 + 4 i
-      const int cn = tid & 63, n = n0 + cn;
-      if (n < a.N) {
-        const int slot = vg_slot(e.g, n), NT = e.g.NT;
-        const float4 eh = make_float4(e.b.EH[0 * NT + slot], e.b.EH[1 * NT + slot], e.b.EH[2 * NT + slot], e.b.EH[3 * NT + slot]);
-        BwdIn in[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int b = m0 + (tid >> 6) + 4 * i;
-          if (b < a.M) in[i] = gates_bwd_load(e.g, e.b, b, slot, true, n);
-        }
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int row = (tid >> 6) + 4 * i, b = m0 + row;
-          if (b < a.M) gates_bwd_finish(e.g, e.b, b, slot, true, in[i], Ct[row][cn], eh);
         }
       }
     }
@@ -447,6 +431,66 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
   }
 }
 
+// C[M x N] = A[M x K] B[K x N] for a short K (the rank space, K = G*KH <= 128) and a wide N, in 16 x 64 tiles: the four
+// waves of a workgroup own a 16 x 16 sub-tile each, read their operands straight into MFMA layout (as the skinny
+// kernel does) and never meet.  dH_rec = dQ_t UdT (256 x 650, K = 128) is 176 workgroups this way instead of 44 tiles
+// of 64 x 64, and the accumulator layout (lane = column, four consecutive rows) is already one (row, unit) element
+// per register: with EPI == 2 the gate derivatives of the previous timestep continue from the registers
+// (gates_bwd_finish), four elements per lane, all their loads issued before the first store; C is not stored then.
+// (The forward product P_t = Q_t Vd with its gate epilogue was tried on these tiles too -- a 4 x 4 quad transpose
+// brings a slot's four gates into one lane -- and measured 2 % slower than the 64 x 64 tiles it keeps.)
+template <int EPI>
+__global__ void __launch_bounds__(256) gemm_rows16_kernel(GemmArgs a, EpiArgs e) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int tiles_n = (a.N + 63) / 64, tiles_m = (a.M + 15) / 16;
+  const int lid = xcd_tile_id(blockIdx.x, tiles_m * tiles_n);
+  const int tn = lid / tiles_m, tm = lid - tn * tiles_m;   // an XCD owns a range of B's columns
+  const int m0 = tm * 16, col = tn * 64 + 16 * wave + r;
+  const bool row_ok = m0 + r < a.M, col_ok = col < a.N;
+  const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
+  const float* Bp = a.B + (col_ok ? col : 0);
+  const int acls = sk_align_class(a.A, a.lda);
+  constexpr int CH = 8;   // 16-wide k blocks per batch (K = 128 in one)
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = 0; kb < a.K; kb += 16 * CH) {
+    float av[CH][4], bv[CH][4];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int k = kb + 16 * c + 4 * q;
+      const int n = a.K - k;
+      sk_load4(Ap + k, acls, row_ok ? n : 0, av[c]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[c][j] = (col_ok && j < n) ? Bp[(long long)(k + j) * a.ldb] : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[c][j], acc, 0, 0, 0);
+  }
+  if (!col_ok) return;
+  if (EPI == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = m0 + 4 * q + i;
+      if (row < a.M) a.C[(long long)row * a.ldc + col] = acc[i];
+    }
+  } else {   // column = hidden unit n, rows = batch rows
+    const int n = col, slot = vg_slot(e.g, n), NT = e.g.NT;
+    const float4 eh = make_float4(e.b.EH[0 * NT + slot], e.b.EH[1 * NT + slot], e.b.EH[2 * NT + slot], e.b.EH[3 * NT + slot]);
+    BwdIn in[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = m0 + 4 * q + i;
+      if (b < a.M) in[i] = gates_bwd_load(e.g, e.b, b, slot, true, n);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int b = m0 + 4 * q + i;
+      if (b < a.M) gates_bwd_finish(e.g, e.b, b, slot, true, in[i], acc[i], eh);
+    }
+  }
+}
+
 // split-K scratch of one layer call (GenericBuf::part / ticket): room for GEMM_MAX_SPLIT partial copies of the
 // largest skinny product (B x G*KH) and one ticket per tile of it
 constexpr int GEMM_MAX_SPLIT = VG_GEMM_SPLIT;
@@ -462,7 +506,8 @@ static const int g_fuse_mode = []() {
   return e == nullptr ? 1 : atoi(e);
 }();
 static const bool g_fuse = g_fuse_mode != 0;       // forward: gate math as the epilogue of P_t = Q_t Vd
-static const bool g_fuse_bwd = g_fuse_mode == 2;   // backward: measured slower (44 tiles carry all of the element-wise work)
+static const bool g_fuse_bwd = g_fuse_mode != 3 && g_fuse_mode != 0;   // backward: gate derivatives as the epilogue of dH_rec
+                                                                       // (3: 64 x 64 tiles and a gates kernel, for A/B runs)
 
 // Bt / ldbt: the same factor stored transposed (N x K), or nullptr
 static int gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
@@ -471,19 +516,26 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
   GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K, part, ticket};
   static bool raised = false;
   if (!raised) {   // 69 KB of dynamic LDS
-    for (const void* f : {reinterpret_cast<const void*>(gemm_tile_kernel<0>), reinterpret_cast<const void*>(gemm_tile_kernel<1>),
-                          reinterpret_cast<const void*>(gemm_tile_kernel<2>)}) {
+    for (const void* f : {reinterpret_cast<const void*>(gemm_tile_kernel<0>), reinterpret_cast<const void*>(gemm_tile_kernel<1>)}) {
       const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GEMM_LDS);
       if (e != hipSuccess) return (int)e;
     }
     raised = true;
   }
-  if (epi != 0) {   // fused element-wise continuation: one workgroup per tile, whole K (<= a few stages)
+  if (epi == 2 || epi == 3) {   // 16 x 64 tiles, operands straight into MFMA layout; 2: gate derivatives as the epilogue
+    const int t16 = ((M + 15) / 16) * ((N + 63) / 64);
+    if (epi == 2) {
+      hipLaunchKernelGGL(gemm_rows16_kernel<2>, dim3(t16), dim3(256), 0, s, a, *ea);
+    } else {
+      EpiArgs none;
+      memset(&none, 0, sizeof(none));
+      hipLaunchKernelGGL(gemm_rows16_kernel<0>, dim3(t16), dim3(256), 0, s, a, none);
+    }
+    return (int)hipGetLastError();
+  }
+  if (epi == 1) {   // fused forward gate math: one workgroup per 64 x 64 tile, whole K (<= a few stages)
     const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
-    if (epi == 1)
-      hipLaunchKernelGGL(gemm_tile_kernel<1>, dim3(tiles, 1), dim3(256), GEMM_LDS, s, a, *ea);
-    else
-      hipLaunchKernelGGL(gemm_tile_kernel<2>, dim3(tiles, 1), dim3(256), GEMM_LDS, s, a, *ea);
+    hipLaunchKernelGGL(gemm_tile_kernel<1>, dim3(tiles, 1), dim3(256), GEMM_LDS, s, a, *ea);
     return (int)hipGetLastError();
   }
   if (N <= 128 && K >= 256 && g_skinny) {   // skinny output, long K: 16 x 16 tiles, K split inside the workgroup
@@ -683,7 +735,9 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
       if ((rc = gemm(dQt, GK, w.UdT, H, nullptr, 0, B, H, GK, nullptr, 0, nullptr, 0, s, nullptr, 0, 2, &ea)) != 0) return rc;
       continue;
     }
-    if ((rc = gemm(dQt, GK, w.UdT, H, w.dHrec, H, B, H, GK, w.part, w.part_cap, w.ticket, w.ticket_cap, s)) != 0) return rc;
+    if ((rc = gemm(dQt, GK, w.UdT, H, w.dHrec, H, B, H, GK, w.part, w.part_cap, w.ticket, w.ticket_cap, s, nullptr, 0,
+                   g_fuse_mode == 3 ? 0 : 3, nullptr)) != 0)
+      return rc;
   }
   hipLaunchKernelGGL(carry_kernel, egrid, eblock, 0, s, g, 1, (const float*)nullptr, (const float*)nullptr, w.dHrec,
                      w.ehterm, w.dcar, w.dh0, w.dc0);
