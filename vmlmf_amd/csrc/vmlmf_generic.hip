@@ -16,6 +16,7 @@
 // Same arithmetic, same tape layout ([t][B][slot]), so the parity tests cover both paths with one oracle.
 #include "vmlmf_launch.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <string.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -169,6 +170,13 @@ struct GemmArgs {
   int M, N, K;
   float* part;   // [gridDim.y][tiles][64 * 64] partial tiles in accumulator order (split K only)
   int* ticket;   // one per tile, zero on entry and on exit
+  // K split over gridDim.y workgroups WITHOUT a reduction (gemm_skinny_kernel): workgroup z writes its partial C to
+  // C + z * zstride; the consumer adds the copies while it loads them (gemm_rows16_kernel: na copies of A, astride
+  // apart), and the launch boundary between the two is all the synchronisation there is
+  long long zstride;
+  int na;
+  long long astride;
+  float* Asum;   // gemm_rows16_kernel: where the column-tile-0 workgroups leave A summed over its copies (or nullptr)
 };
 
 // EPI 1: C = P_t is not stored; each (row, slot) of the tile goes straight through the forward gate math.
@@ -326,29 +334,10 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs a, EpiArgs e) {
 // registers -- no LDS staging, one memory latency -- and the partial tiles meet in LDS, summed in wave order.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// four consecutive floats p[0..3] of a row, `n` of them inside the slice; cls = widest load the row alignment allows
-__device__ __forceinline__ void sk_load4(const float* p, int cls, int n, float (&v)[4]) {
-  if (n >= 4 && cls == 4) {
-    const float4 t = ld4(p);
-    v[0] = t.x, v[1] = t.y, v[2] = t.z, v[3] = t.w;
-  } else if (n >= 4 && cls == 2) {
-    const float2 t0 = *reinterpret_cast<const float2*>(p), t1 = *reinterpret_cast<const float2*>(p + 2);
-    v[0] = t0.x, v[1] = t0.y, v[2] = t1.x, v[3] = t1.y;
-  } else {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = j < n ? p[j] : 0.f;
-  }
-}
-__host__ __device__ inline int sk_align_class(const float* base, long long ld) {
-  const uintptr_t b = reinterpret_cast<uintptr_t>(base);
-  if (ld % 4 == 0 && (b & 15) == 0) return 4;
-  if (ld % 2 == 0 && (b & 7) == 0) return 2;
-  return 1;
-}
-
 // BT: `B` points at B^T (N x K row-major, ldb its row stride): both operands are then read along k, 16 bytes per lane
 // and load (the step-wise path keeps every factor in both orientations); otherwise B is K x N and a lane fetches its
-// column element row by row (four 64-byte segments per load instruction: 3x slower at K = 3072).
+// column element row by row (four 64-byte segments per load instruction).  Reading both along k measured slower
+// (rows 12 KB apart); the BT instantiations stay for A/B runs (VMLMF_SKINNY=4).
 // NSUB: 16-column sub-tiles per workgroup (2: a 16 x 32 tile whose two MFMA chains share the A operand -- for tall
 // products such as dqx = dpre VxT (8960 x 32, K = 3072), where A is the 110 MB operand and should be read once).
 template <int NWV, bool BT, int SK_CH, int NSUB>
@@ -365,9 +354,11 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
     tm = lid / tiles_n, tn = lid - tm * tiles_n;
   }
   const int m0 = tm * 16, n0 = tn * TN;
-  const int nblk = (a.K + 15) / 16, per = (nblk + NWV - 1) / NWV;
-  const int kb0 = wave * per * 16;
+  const int nz = gridDim.y, parts = NWV * nz;   // K slices: one per (workgroup z, wave)
+  const int nblk = (a.K + 15) / 16, per = (nblk + parts - 1) / parts;
+  const int kb0 = ((int)blockIdx.y * NWV + wave) * per * 16;
   const int kb1 = kb0 + per * 16 < a.K ? kb0 + per * 16 : a.K;
+  float* const Cz = a.C + (long long)blockIdx.y * a.zstride;
   const bool row_ok = m0 + r < a.M;
   bool col_ok[NSUB];
   const float* Bp[NSUB];
@@ -378,35 +369,69 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
     Bp[u] = BT ? a.B + (long long)c * a.ldb : a.B + c;
   }
   const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
-  const int acls = sk_align_class(a.A, a.lda), bcls = sk_align_class(a.B, a.ldb);
   f32x4v acc[NSUB];
 #pragma unroll
   for (int u = 0; u < NSUB; ++u) acc[u] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  for (int kb = kb0; kb < kb1; kb += 16 * SK_CH) {
-    float av[SK_CH][4], bv[NSUB][SK_CH][4];
+  // Operand fetches are branch-free and in two phases: every load of a batch goes out from a clamped (always valid)
+  // address, and masking happens where the values are consumed -- with the loads under `if`, or masked right where they
+  // are issued, the compiler put a vmcnt(0) wait in front of most of them.  AV: 16-byte loads of whole quads of A (rows
+  // 16-byte aligned, K a multiple of four: a quad is then entirely inside or outside the slice), else element loads.
+  const bool avec_ok = a.lda % 4 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 15) == 0 && a.K % 4 == 0;
+  const bool bvec_ok = BT && a.ldb % 4 == 0 && (reinterpret_cast<uintptr_t>(a.B) & 15) == 0 && a.K % 4 == 0;
+  auto run = [&](auto av_c, auto bv_c) {
+    constexpr int AV = decltype(av_c)::value;
+    constexpr bool BV = decltype(bv_c)::value;
+    for (int kb = kb0; kb < kb1; kb += 16 * SK_CH) {
+      float av[SK_CH][4], bv[NSUB][SK_CH][4];
 #pragma unroll
-    for (int c = 0; c < SK_CH; ++c) {
-      const int k = kb + 16 * c + 4 * q;
-      const int n = kb1 - k;   // elements of this quad inside the slice (<= 0: none)
-      sk_load4(Ap + k, acls, row_ok ? n : 0, av[c]);
-#pragma unroll
-      for (int u = 0; u < NSUB; ++u) {
-        if (BT) {
-          sk_load4(Bp[u] + k, bcls, col_ok[u] ? n : 0, bv[u][c]);
+      for (int c = 0; c < SK_CH; ++c) {
+        const int k = kb + 16 * c + 4 * q;
+        if (AV == 4) {
+          const float4 t = ld4(Ap + (k < kb1 ? k : 0));
+          av[c][0] = t.x, av[c][1] = t.y, av[c][2] = t.z, av[c][3] = t.w;
+        } else if (AV == 2) {   // rows 8-byte aligned, K even (H = 650): pairs are entirely inside or outside
+          const float2 t0 = *reinterpret_cast<const float2*>(Ap + (k < kb1 ? k : 0));
+          const float2 t1 = *reinterpret_cast<const float2*>(Ap + (k + 2 < kb1 ? k + 2 : 0));
+          av[c][0] = t0.x, av[c][1] = t0.y, av[c][2] = t1.x, av[c][3] = t1.y;
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) bv[u][c][j] = (col_ok[u] && j < n) ? Bp[u][(long long)(k + j) * a.ldb] : 0.f;
+          for (int j = 0; j < 4; ++j) av[c][j] = Ap[k + j < kb1 ? k + j : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) {
+          if (BT && BV) {
+            const float4 t = ld4(Bp[u] + (k < kb1 ? k : 0));
+            bv[u][c][0] = t.x, bv[u][c][1] = t.y, bv[u][c][2] = t.z, bv[u][c][3] = t.w;
+          } else if (BT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][c][j] = Bp[u][k + j < kb1 ? k + j : 0];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[u][c][j] = Bp[u][(long long)(k + j < kb1 ? k + j : 0) * a.ldb];
+          }
         }
       }
+#pragma unroll
+      for (int c = 0; c < SK_CH; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const bool in = kb + 16 * c + 4 * q + j < kb1;
+          const float av_m = (in && row_ok) ? av[c][j] : 0.f;
+#pragma unroll
+          for (int u = 0; u < NSUB; ++u)
+            acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av_m, (in && col_ok[u]) ? bv[u][c][j] : 0.f, acc[u], 0, 0, 0);
+        }
     }
-#pragma unroll
-    for (int c = 0; c < SK_CH; ++c)
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int u = 0; u < NSUB; ++u)
-          acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[u][c][j], acc[u], 0, 0, 0);
-  }
+  };
+  const bool apair_ok = a.lda % 2 == 0 && (reinterpret_cast<uintptr_t>(a.A) & 7) == 0 && a.K % 2 == 0;
+  if (avec_ok && bvec_ok)
+    run(std::integral_constant<int, 4>{}, std::true_type{});
+  else if (avec_ok)
+    run(std::integral_constant<int, 4>{}, std::false_type{});
+  else if (apair_ok)
+    run(std::integral_constant<int, 2>{}, std::false_type{});
+  else
+    run(std::integral_constant<int, 1>{}, std::false_type{});
   if (wave > 0) {
 #pragma unroll
     for (int u = 0; u < NSUB; ++u) red[u][wave - 1][lane] = make_float4(acc[u][0], acc[u][1], acc[u][2], acc[u][3]);
@@ -424,7 +449,7 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = m0 + 4 * q + i;
-          if (row < a.M) a.C[(long long)row * a.ldc + n0 + 16 * u + r] = acc[u][i];
+          if (row < a.M) Cz[(long long)row * a.ldc + n0 + 16 * u + r] = acc[u][i];
         }
       }
     }
@@ -439,7 +464,7 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
 // (gates_bwd_finish), four elements per lane, all their loads issued before the first store; C is not stored then.
 // (The forward product P_t = Q_t Vd with its gate epilogue was tried on these tiles too -- a 4 x 4 quad transpose
 // brings a slot's four gates into one lane -- and measured 2 % slower than the 64 x 64 tiles it keeps.)
-template <int EPI>
+template <int EPI, int NA>
 __global__ void __launch_bounds__(256) gemm_rows16_kernel(GemmArgs a, EpiArgs e) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   const int tiles_n = (a.N + 63) / 64, tiles_m = (a.M + 15) / 16;
@@ -449,23 +474,48 @@ __global__ void __launch_bounds__(256) gemm_rows16_kernel(GemmArgs a, EpiArgs e)
   const bool row_ok = m0 + r < a.M, col_ok = col < a.N;
   const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
   const float* Bp = a.B + (col_ok ? col : 0);
-  const int acls = sk_align_class(a.A, a.lda);
   constexpr int CH = 8;   // 16-wide k blocks per batch (K = 128 in one)
+  const bool keep_sum = NA > 1 && a.Asum != nullptr && tn == 0 && wave == 0 && row_ok;
   f32x4v acc = {0.f, 0.f, 0.f, 0.f};
   for (int kb = 0; kb < a.K; kb += 16 * CH) {
-    float av[CH][4], bv[CH][4];
+    // every load of the batch is issued before anything consumes one: the NA copies of A (a K-split producer leaves
+    // its partial sums side by side, see GemmArgs) and the B rows
+    float av[NA][CH][4], bv[CH][4];
+    // branch-free: K is a multiple of four here (the padded rank space) and the rows are 16-byte aligned (checked by the
+    // launcher), so a quad of k is entirely inside or outside; outside quads load from k = 0 and are masked afterwards
+    float4 a4[NA][CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int k = kb + 16 * c + 4 * q;
-      const int n = a.K - k;
-      sk_load4(Ap + k, acls, row_ok ? n : 0, av[c]);
+      const int kk = k < a.K ? k : 0;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bv[c][j] = (col_ok && j < n) ? Bp[(long long)(k + j) * a.ldb] : 0.f;
+      for (int z = 0; z < NA; ++z) a4[z][c] = ld4(Ap + z * a.astride + kk);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bv[c][j] = Bp[(long long)(kk + j) * a.ldb];
     }
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int c = 0; c < CH; ++c) {
+      const bool in = kb + 16 * c + 4 * q < a.K;
+      float4 t = a4[0][c];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c][j], bv[c][j], acc, 0, 0, 0);
+      for (int z = 1; z < NA; ++z) t = f4add(t, a4[z][c]);   // copy order
+      av[0][c][0] = (in && row_ok) ? t.x : 0.f, av[0][c][1] = (in && row_ok) ? t.y : 0.f;
+      av[0][c][2] = (in && row_ok) ? t.z : 0.f, av[0][c][3] = (in && row_ok) ? t.w : 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float b = (in && col_ok) ? bv[c][j] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0][c][j], b, acc, 0, 0, 0);
+      }
+    }
+    if (keep_sum) {   // the summed A tile, for whoever needs it after this launch (dQ_t for the weight gradients)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        const int k = kb + 16 * c + 4 * q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (k + j < a.K) a.Asum[(long long)(m0 + r) * a.lda + k + j] = av[0][c][j];
+      }
+    }
   }
   if (!col_ok) return;
   if (EPI == 0) {
@@ -491,6 +541,29 @@ __global__ void __launch_bounds__(256) gemm_rows16_kernel(GemmArgs a, EpiArgs e)
   }
 }
 
+// The backward pair of a timestep on the step-wise path:
+//   launch_dq_split   dQ partials = dpre_t VdT with K split over ZS workgroups per tile (no reduction, see GemmArgs)
+//   launch_dhrec      dH_rec = (sum of the partials) UdT on 16 x 64 tiles; leaves the summed dQ_t in dQsum for the weight
+//                     gradients; epi 2 continues into the gate derivatives of the previous step
+constexpr int DQ_ZS = 2;
+
+static int launch_dq_split(const float* dpre_t, long long lda, const float* VdT, int GK, float* part, int B, int K,
+                           hipStream_t s) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = dpre_t, a.lda = lda, a.B = VdT, a.ldb = GK, a.C = part, a.ldc = GK, a.M = B, a.N = GK, a.K = K;
+  a.zstride = (long long)B * GK;
+  const int t16 = ((B + 15) / 16) * ((GK + 15) / 16);
+  if (K / DQ_ZS >= 1536)
+    hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
+  else
+    hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 8, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
+  return (int)hipGetLastError();
+}
+
+static int launch_dhrec(const float* part, int GK, const float* UdT, int H, float* dHrec, float* dQsum, int B,
+                        const EpiArgs* ea, hipStream_t s);
+
 // split-K scratch of one layer call (GenericBuf::part / ticket): room for GEMM_MAX_SPLIT partial copies of the
 // largest skinny product (B x G*KH) and one ticket per tile of it
 constexpr int GEMM_MAX_SPLIT = VG_GEMM_SPLIT;
@@ -500,6 +573,11 @@ static const int g_skinny_mode = []() {
   return e == nullptr ? 1 : atoi(e);
 }();
 static const bool g_skinny = g_skinny_mode != 0;
+// VMLMF_DQ_SPLIT=0: dQ_t as one product per tile (A/B measurements)
+static const bool g_dq_split = []() {
+  const char* e = getenv("VMLMF_DQ_SPLIT");
+  return (e == nullptr || e[0] != '0') && g_skinny_mode == 1;
+}();
 // VMLMF_FUSE_GATES=0: element-wise halves of a step as kernels of their own (A/B measurements)
 static const int g_fuse_mode = []() {
   const char* e = getenv("VMLMF_FUSE_GATES");
@@ -508,6 +586,24 @@ static const int g_fuse_mode = []() {
 static const bool g_fuse = g_fuse_mode != 0;       // forward: gate math as the epilogue of P_t = Q_t Vd
 static const bool g_fuse_bwd = g_fuse_mode != 3 && g_fuse_mode != 0;   // backward: gate derivatives as the epilogue of dH_rec
                                                                        // (3: 64 x 64 tiles and a gates kernel, for A/B runs)
+
+static int launch_dhrec(const float* part, int GK, const float* UdT, int H, float* dHrec, float* dQsum, int B,
+                        const EpiArgs* ea, hipStream_t s) {
+  GemmArgs a;
+  memset(&a, 0, sizeof(a));
+  a.A = part, a.lda = GK, a.B = UdT, a.ldb = H, a.C = dHrec, a.ldc = H, a.M = B, a.N = H, a.K = GK;
+  a.na = DQ_ZS, a.astride = (long long)B * GK, a.Asum = dQsum;
+  const int t16 = ((B + 15) / 16) * ((H + 63) / 64);
+  static_assert(DQ_ZS == 2, "gemm_rows16_kernel is instantiated for two partial copies");
+  if (ea != nullptr) {
+    hipLaunchKernelGGL((gemm_rows16_kernel<2, 2>), dim3(t16), dim3(256), 0, s, a, *ea);
+  } else {
+    EpiArgs none;
+    memset(&none, 0, sizeof(none));
+    hipLaunchKernelGGL((gemm_rows16_kernel<0, 2>), dim3(t16), dim3(256), 0, s, a, none);
+  }
+  return (int)hipGetLastError();
+}
 
 // Bt / ldbt: the same factor stored transposed (N x K), or nullptr
 static int gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
@@ -525,11 +621,11 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
   if (epi == 2 || epi == 3) {   // 16 x 64 tiles, operands straight into MFMA layout; 2: gate derivatives as the epilogue
     const int t16 = ((M + 15) / 16) * ((N + 63) / 64);
     if (epi == 2) {
-      hipLaunchKernelGGL(gemm_rows16_kernel<2>, dim3(t16), dim3(256), 0, s, a, *ea);
+      hipLaunchKernelGGL((gemm_rows16_kernel<2, 1>), dim3(t16), dim3(256), 0, s, a, *ea);
     } else {
       EpiArgs none;
       memset(&none, 0, sizeof(none));
-      hipLaunchKernelGGL(gemm_rows16_kernel<0>, dim3(t16), dim3(256), 0, s, a, none);
+      hipLaunchKernelGGL((gemm_rows16_kernel<0, 1>), dim3(t16), dim3(256), 0, s, a, none);
     }
     return (int)hipGetLastError();
   }
@@ -552,7 +648,7 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
       else
         hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 1>), dim3(t16), dim3(512), 0, s, a);
     } else {
-      hipLaunchKernelGGL((gemm_skinny_kernel<4, false, 12, 1>), dim3(t16), dim3(256), 0, s, a);
+      hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 8, 1>), dim3(t16), dim3(512), 0, s, a);
     }
     return (int)hipGetLastError();
   }
@@ -727,6 +823,15 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
       if ((rc = (int)hipGetLastError()) != 0) return rc;
     }
     float* dQt = w.dQs + (size_t)t * B * GK;
+    if (g_dq_split && (long long)DQ_ZS * B * GK <= w.part_cap) {
+      // dQ_t in DQ_ZS partial copies (K = 4 * slots split over workgroups, no reduction); the dH_rec product adds them
+      // as it loads them and leaves their sum in dQs[t] for the weight gradients
+      if ((rc = launch_dq_split(w.dpre + (size_t)t * sstride * 4, (long long)NT * 4, w.VdT, GK, w.part, B, NT * 4, s)) != 0)
+        return rc;
+      a.t = t - 1;   // the step whose gate derivatives the epilogue computes
+      if ((rc = launch_dhrec(w.part, GK, w.UdT, H, w.dHrec, dQt, B, (g_fuse_bwd && t > 0) ? &ea : nullptr, s)) != 0) return rc;
+      continue;
+    }
     if ((rc = gemm(w.dpre + (size_t)t * sstride * 4, (long long)NT * 4, w.VdT, GK, dQt, GK, B, GK, NT * 4, w.part,
                    w.part_cap, w.ticket, w.ticket_cap, s, w.Vd, (long long)NT * 4)) != 0)
       return rc;
