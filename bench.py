@@ -289,6 +289,21 @@ def main():
     lib.vmlmf_profile_enable(0)
     kern = {lib.vmlmf_kernel_name(k).decode(): round(usec[k] / max(cnt[k], 1), 2) for k in range(_lib.NKERNELS)}
 
+    # the gradient all-reduce on its own ("all-reduce time isolated"): the same in-place RCCL group call
+    # the timed steps make, on the gradients of the last step, between barriers
+    allreduce_ms = None
+    if collective:
+        for _ in range(5):
+            reducer.reduce()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(50):
+            reducer.reduce()
+        barrier()
+        tar = torch.tensor([(time.perf_counter() - t1) / 50 * 1e3], device=dev, dtype=torch.float64)
+        dist.all_reduce(tar, op=dist.ReduceOp.MAX)
+        allreduce_ms = float(tar.item())
+
     # optimizer, outside the metric (train.py:47,65): the stock one and the package's single-launch one, and the
     # whole training step (forward + loss + backward + optimizer) replayed from one hipGraph
     def time_opt(opt):
@@ -371,6 +386,8 @@ def main():
                          "note": "fp32: MFMA peak == vector peak on gfx950; the kernel is a 2T-long dependent "
                                  "chain on 64 of 256 CUs (one batch row per CU), see DESIGN.md"},
             "kernels_us": kern,
+            "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
+            "allreduce_bytes": 4 * reducer.numel() if collective else 0,
             "adam_ms": round(adam_ms, 4),
             "fused_adam_ms": round(fused_adam_ms, 4),
             "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
