@@ -26,13 +26,23 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(int H, int C, const float
   float acc[HEAD_CMAX / 4];
 #pragma unroll
   for (int j = 0; j < HEAD_CMAX / 4; ++j) acc[j] = 0.f;
-  for (int n = lane; n < H; n += 64) {
-    const float hv = hb[n];
+  // Loads go out from clamped (always valid) indices and are masked where they are consumed, four feature strides
+  // per pass: under `c < C ? W[..] : 0` hipcc waits for each load before issuing the next (vmcnt(0) after every
+  // one), which made this kernel a chain of memory latencies.
+  for (int n0 = lane; n0 < H; n0 += 256) {
+    float hv[4], wv[4][HEAD_CMAX / 4];
 #pragma unroll
-    for (int j = 0; j < HEAD_CMAX / 4; ++j) {
-      const int c = w + 4 * j;
-      const float wv = c < C ? W[(size_t)c * H + n] : 0.f;
-      acc[j] = fmaf(hv, wv, acc[j]);
+    for (int u = 0; u < 4; ++u) {
+      const int n = n0 + 64 * u < H ? n0 + 64 * u : lane;
+      hv[u] = hb[n];
+#pragma unroll
+      for (int j = 0; j < HEAD_CMAX / 4; ++j) wv[u][j] = W[(size_t)(w + 4 * j < C ? w + 4 * j : 0) * H + n];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float hm = n0 + 64 * u < H ? hv[u] : 0.f;
+#pragma unroll
+      for (int j = 0; j < HEAD_CMAX / 4; ++j) acc[j] = fmaf(hm, w + 4 * j < C ? wv[u][j] : 0.f, acc[j]);
     }
   }
 #pragma unroll
@@ -65,7 +75,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int C, cons
     for (int n = threadIdx.x; n < H; n += 256) {
       float wv[HEAD_CMAX];   // every weight load of the column is issued before the first FMA: one latency
 #pragma unroll
-      for (int c = 0; c < HEAD_CMAX; ++c) wv[c] = c < C ? W[(size_t)c * H + n] : 0.f;
+      for (int c = 0; c < HEAD_CMAX; ++c) wv[c] = W[(size_t)(c < C ? c : 0) * H + n];   // sdl masks the classes past C
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < HEAD_CMAX; ++c) acc = fmaf(sdl[0][c], wv[c], acc);   // sdl is zero past C
@@ -83,16 +93,26 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(int B, int H, int C, cons
     for (int j = 0; j < HEAD_CMAX / 4; ++j) acc[j] = 0.f;
     for (int b0 = 0; b0 < B; b0 += 64) {
       if (b0 > 0) __syncthreads();
+      // 24 independent loads per thread, all issued (clamped indices) before the first LDS write; masked on the way
+      // into LDS.  Written as `cond ? load : 0` straight into LDS they went out one at a time.
+      float th[16], td[8];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {                 // 16 independent coalesced loads per thread
+      for (int i = 0; i < 16; ++i) {
         const int b = b0 + i * 4 + w;
-        sh[i * 4 + w][lane] = (ok && b < B) ? h[(size_t)b * ldh + n] : 0.f;
+        th[i] = h[(size_t)(b < B ? b : 0) * ldh + (ok ? n : 0)];
       }
 #pragma unroll
       for (int i = 0; i < 8; ++i) {                  // 64 x 32 dl tile: thread -> (row, class slot)
         const int e = i * 256 + threadIdx.x, r = e >> 5, slot = e & 31, c = (slot >> 3) + 4 * (slot & 7);
         const int b = b0 + r;
-        sdl[r][slot] = (b < B && c < C) ? dl[(size_t)b * C + c] : 0.f;
+        td[i] = dl[(size_t)(b < B ? b : 0) * C + (c < C ? c : 0)];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sh[i * 4 + w][lane] = (ok && b0 + i * 4 + w < B) ? th[i] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int e = i * 256 + threadIdx.x, r = e >> 5, slot = e & 31, c = (slot >> 3) + 4 * (slot & 7);
+        sdl[r][slot] = (b0 + r < B && c < C) ? td[i] : 0.f;
       }
       __syncthreads();
 #pragma unroll 4
