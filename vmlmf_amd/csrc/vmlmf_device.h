@@ -168,13 +168,20 @@ __device__ __forceinline__ int vg_xchunk(const VGeo& g, int k) { return g.xperm 
 template <class T>
 __device__ __forceinline__ T* vg_gate(T* const (&a)[4], int k) { return k == 0 ? a[0] : k == 1 ? a[1] : k == 2 ? a[2] : a[3]; }
 
+// The x-side accessors are branch-free (clamped index, masked value): finish_kernel calls them in short loops, and a load
+// under a condition is not issued before the previous one has returned (hipcc puts a vmcnt(0) in front of it).
 __device__ inline float ref_ux(const VGeo& g, const RefP& p, int m, int r) {
-  return r < g.rw ? p.u_x[(size_t)m * g.rw + r] : 0.f;
+  const bool in = r < g.rw;
+  const float v = p.u_x[(size_t)m * g.rw + (in ? r : 0)];
+  return in ? v : 0.f;
 }
 __device__ inline float ref_vx(const VGeo& g, const RefP& p, int n, int k, int r) {
-  if (r >= g.rw) return 0.f;
-  if (g.pergate) return vg_gate(p.wg, k)[(size_t)r * g.H + n];
-  return p.v_x[((size_t)vg_xchunk(g, k) * g.H + n) * g.rw + r];
+  const bool in = r < g.rw;
+  const int rr = in ? r : 0;
+  const float* base = g.pergate ? vg_gate(p.wg, k) : p.v_x;
+  const size_t off = g.pergate ? (size_t)rr * g.H + n : ((size_t)vg_xchunk(g, k) * g.H + n) * g.rw + rr;
+  const float v = base[off];
+  return in ? v : 0.f;
 }
 // unit n's contribution weight to rank rr of the concatenated rank space
 __device__ inline float ref_uc(const VGeo& g, const RefP& p, int n, int rr) {
