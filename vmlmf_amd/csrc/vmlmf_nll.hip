@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int V, const float* __res
 #pragma unroll
     for (int i = 0; i < NLL_Q; ++i) {
       const int q = tid + 256 * i;
-      v[i] = q < nq ? reinterpret_cast<const float4*>(z)[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      const float4 t = reinterpret_cast<const float4*>(z)[q < nq ? q : 0];
+      v[i] = q < nq ? t : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
     }
 #pragma unroll
     for (int i = 0; i < NLL_Q; ++i) m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(int V, float scale, const 
     for (int q0 = 0; q0 < nq; q0 += 256 * 4) {   // four 16-byte loads in flight per thread
       float4 v[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < 4; ++i) {   // clamped index, no condition: a load under `if` waits for the one before it
         const int q = q0 + tid + 256 * i;
-        if (q < nq) v[i] = reinterpret_cast<const float4*>(z)[q];
+        v[i] = reinterpret_cast<const float4*>(z)[q < nq ? q : 0];
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
