@@ -130,3 +130,40 @@ def query(desc):
     s = Sizes()
     check(lib().vmlmf_query(ctypes.byref(desc), ctypes.byref(s)))
     return s
+
+
+# ---- cheap host-side access to torch's current HIP stream / device ------------------------------------------------
+# torch.cuda.current_stream(dev).cuda_stream and `with torch.cuda.device(dev)` cost ~7 us and ~5 us of Python per use;
+# a layer's forward + backward makes six library calls, and eager mode is host-bound at the headline shape.  The raw
+# accessors below are what those wrappers call underneath; if a torch build lacks them the public API is used.
+def raw_stream(dev):
+    """ctypes handle of torch's current stream on `dev` (a torch.device with an index)."""
+    import torch
+    try:
+        return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(dev.index))
+    except (AttributeError, TypeError):
+        return ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class on_device:
+    """`with on_device(dev):` -- make `dev` the current HIP device for the library call, switching only when it is not
+    already (the common case costs one integer compare)."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, dev):
+        self.idx = dev.index
+        self.prev = -1
+
+    def __enter__(self):
+        import torch
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            torch.cuda.set_device(self.idx)
+            self.prev = cur
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            import torch
+            torch.cuda.set_device(self.prev)
+        return False

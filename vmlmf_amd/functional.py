@@ -71,7 +71,7 @@ def _desc_for(cfg, B, T, I, H, training):
 def _workspace(dev, nbytes):
     if torch.cuda.is_current_stream_capturing():
         return torch.empty(nbytes, device=dev, dtype=torch.uint8)      # graph-private pool
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    key = (dev.index, _lib.raw_stream(dev).value)
     buf = _WORKSPACE.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(nbytes, device=dev, dtype=torch.uint8)
@@ -116,8 +116,8 @@ class VmlmfSeqFn(torch.autograd.Function):
         h0c = None if h0 is None else h0.contiguous()
         c0c = None if c0 is None else c0.contiguous()
         ps = _params_struct(params, g, variant)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_seq_forward(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
                 _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream))
@@ -159,8 +159,8 @@ class VmlmfSeqFn(torch.autograd.Function):
         ws = _workspace(dev, sizes.workspace_bytes)
         ps = _params_struct(params, g, variant)
         gs = _params_struct(grads, g, variant)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_seq_backward(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
                 _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
@@ -196,8 +196,8 @@ class HeadLinearFn(torch.autograd.Function):
         B, H = h.shape
         C = weight.shape[0]
         out = torch.empty((B, C), device=h.device, dtype=torch.float32)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
-        with torch.cuda.device(h.device):
+        stream = _lib.raw_stream(h.device)
+        with _lib.on_device(h.device):
             _lib.check(_lib.lib().vmlmf_head_forward(B, H, C, _ptr(h), h.stride(0), _ptr(weight), _ptr(bias_c),
                                                      _ptr(out), stream))
         ctx.save_for_backward(h, weight)
@@ -218,8 +218,8 @@ class HeadLinearFn(torch.autograd.Function):
         flat = torch.empty(C * H + C, device=h.device, dtype=torch.float32) if (need_w or need_b) else None
         dW = flat[:C * H].view(C, H) if need_w else None
         db = flat[C * H:] if need_b else None
-        stream = ctypes.c_void_p(torch.cuda.current_stream(h.device).cuda_stream)
-        with torch.cuda.device(h.device):
+        stream = _lib.raw_stream(h.device)
+        with _lib.on_device(h.device):
             _lib.check(_lib.lib().vmlmf_head_backward(B, H, C, _ptr(h), h.stride(0), _ptr(weight), _ptr(dl),
                                                       _ptr(dh), _ptr(dW), _ptr(db), stream))
         return dh, dW, db
@@ -265,8 +265,8 @@ class CrossEntropyFn(torch.autograd.Function):
         dev = logits.device
         stats = torch.empty(B + 2, device=dev, dtype=torch.float32)     # loss | nvalid | lse[B]
         dz_unit = torch.empty_like(logits) if ctx.needs_input_grad[0] else None
-        stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        with torch.cuda.device(dev):
+        stream = _lib.raw_stream(dev)
+        with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_ce_forward(B, C, _ptr(logits), _ptr(target), int(ignore_index),
                                                    stats.data_ptr(), stats.data_ptr() + 8, stats.data_ptr() + 4,
                                                    _ptr(dz_unit), stream))
@@ -283,8 +283,8 @@ class CrossEntropyFn(torch.autograd.Function):
         B, C = logits.shape
         dloss = dloss.contiguous()
         dz = torch.empty_like(logits)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
-        with torch.cuda.device(logits.device):
+        stream = _lib.raw_stream(logits.device)
+        with _lib.on_device(logits.device):
             _lib.check(_lib.lib().vmlmf_ce_backward(B, C, _ptr(logits), _ptr(target), ctx.ignore_index,
                                                     stats.data_ptr() + 8, stats.data_ptr() + 4, _ptr(dloss),
                                                     _ptr(dz), stream))
@@ -326,9 +326,9 @@ class NllLossFn(torch.autograd.Function):
         R, V = scores.shape
         scale = float(batch_size) / float(R)
         stats = torch.empty(1 + 2 * R, device=scores.device, dtype=torch.float32)   # loss | lse | rowloss
-        stream = ctypes.c_void_p(torch.cuda.current_stream(scores.device).cuda_stream)
+        stream = _lib.raw_stream(scores.device)
         base = stats.data_ptr()
-        with torch.cuda.device(scores.device):
+        with _lib.on_device(scores.device):
             _lib.check(_lib.lib().vmlmf_nll_forward(R, V, _ptr(scores), _ptr(yrow), scale, base, base + 4,
                                                     base + 4 * (1 + R), stream))
         ctx.save_for_backward(scores, yrow, stats)
@@ -343,8 +343,8 @@ class NllLossFn(torch.autograd.Function):
         R, V = scores.shape
         dloss = dloss.contiguous()
         dz = torch.empty_like(scores)
-        stream = ctypes.c_void_p(torch.cuda.current_stream(scores.device).cuda_stream)
-        with torch.cuda.device(scores.device):
+        stream = _lib.raw_stream(scores.device)
+        with _lib.on_device(scores.device):
             _lib.check(_lib.lib().vmlmf_nll_backward(R, V, _ptr(scores), _ptr(yrow), ctx.scale, stats.data_ptr() + 4,
                                                      _ptr(dloss), _ptr(dz), stream))
         return dz, None, None

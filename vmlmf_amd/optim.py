@@ -89,9 +89,9 @@ class Adam(torch.optim.Optimizer):
                 _check(p, g)
                 pairs.append((p, g))
             dev = live[0].device
-            stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            stream = _lib.raw_stream(dev)
             b1, b2 = group["betas"]
-            with torch.cuda.device(dev):
+            with _lib.on_device(dev):
                 lists = _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live])
                 for tl in lists:
                     _lib.check(lib.vmlmf_adam_step(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(),
@@ -128,8 +128,8 @@ def clip_sgd_step(parameters, lr, max_norm):
     scratch = _Scratch.get(dev)
     norm = torch.empty((), device=dev)
     tl = _tensor_lists([(p, p.grad) for p in live], [0] * len(live))[0]
-    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    with torch.cuda.device(dev):
+    stream = _lib.raw_stream(dev)
+    with _lib.on_device(dev):
         _lib.check(_lib.lib().vmlmf_sgd_clip_step(ctypes.byref(tl), float(lr), float(max_norm), norm.data_ptr(),
                                                   scratch.data_ptr(), stream))
     return norm
