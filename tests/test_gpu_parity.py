@@ -240,3 +240,35 @@ def test_dy_is_never_read_past_its_end():
     y[:, -1].sum().backward()
     torch.cuda.synchronize()
     assert all(torch.isfinite(p.grad).all() for p in rnn.parameters())
+
+
+@pytest.mark.parametrize("env", [{"VMLMF_SKINNY": "0"}, {"VMLMF_FUSE_GATES": "0"}, {"VMLMF_DQ_SPLIT": "0"},
+                                 {"VMLMF_FUSE_GATES": "3"}, {"VMLMF_SKINNY": "4"}, {"VMLMF_XWAVE": "0"}],
+                         ids=lambda e: "_".join(f"{k[6:]}{v}" for k, v in e.items()))
+def test_measurement_switches_compute_the_same_thing(env):
+    """The A/B switches of the native code (read once when the library loads) select alternative kernels for the same
+    arithmetic: each is run in a fresh interpreter on a step-wise-path shape and on the headline cell, against the oracle."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path[:0] = [%r, %r, %r]\n"
+        "import numpy as np, vmlmf_oracle as O\n"
+        "from hip_util import run_hip, run_literal, compare_all\n"
+        "for variant, B, T, I, H, rw, ru, tm in [(O.V4, 7, 3, 44, 44, 5, [20, 36], True), (O.V1, 5, 4, 12, 40, 6, [40], False),\n"
+        "                                          (O.V1, 6, 5, 9, 70, 4, [8], False)]:\n"
+        "    rng = np.random.Generator(np.random.PCG64(5))\n"
+        "    P = O.make_params(variant, I, H, rw, ru if variant == O.V4 else ru[0], seed=7)\n"
+        "    shp = (T, B, I) if tm else (B, T, I)\n"
+        "    x = rng.standard_normal(shp).astype(np.float32)\n"
+        "    h0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32)\n"
+        "    c0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32)\n"
+        "    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)\n"
+        "    dhT = rng.standard_normal((B, H)).astype(np.float32)\n"
+        "    dcT = rng.standard_normal((B, H)).astype(np.float32)\n"
+        "    compare_all(run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm),\n"
+        "                run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm), 'switch')\n"
+        "print('ok')\n") % (os.path.dirname(here), os.path.join(os.path.dirname(here), "oracle"), here)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
