@@ -66,6 +66,10 @@ const bool g_xwave = []() {
   return e == nullptr || e[0] != '0';
 }();
 
+// wgrad chunking (A/B measurements): VMLMF_WCHUNKS = target number of row chunks, VMLMF_WMIN = fewest rows per chunk
+const int g_wchunks = []() { const char* e = getenv("VMLMF_WCHUNKS"); return e ? atoi(e) : 64; }();
+const int g_wmin = []() { const char* e = getenv("VMLMF_WMIN"); return e ? atoi(e) : 64; }();   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
+
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (d == nullptr) return fail(VMLMF_E_BADARG, "null descriptor");
@@ -148,8 +152,8 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (rc < 8) rc = 8;
   g.RC = rc;
   g.nblk = (TB + rc - 1) / rc;
-  int rc2 = (TB + 63) / 64;
-  if (rc2 < 32) rc2 = 32;
+  int rc2 = (TB + g_wchunks - 1) / g_wchunks;
+  if (rc2 < g_wmin) rc2 = g_wmin;
   g.RC2 = rc2;
   g.nchunk = (TB + rc2 - 1) / rc2;
   g.foldx = (!g.generic && g.I <= g.KX) ? 1 : 0;
