@@ -4,6 +4,7 @@
 //   reduce_kernel  deterministic sum of the wgrad workgroups' partial accumulators
 //   finish_kernel  canonical gradients -> reference-layout gradients (folds d(ex), d(eh) into dia/U/V)
 #include "vmlmf_launch.h"
+#include <stdlib.h>
 
 // ---------------------------------------------------------------------------------------------------
 // pack
@@ -335,7 +336,10 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
                  hipStream_t s) {
   const int TBp = g.T * g.Bp;
-  const int xr = 8;   // 16 (template variant kept) measured no faster at 8960 rows: the V_x reloads are not the bound
+  // rows per workgroup: 4 for short sequences of rows (config C, 3072 rows: 0.2390 ms per step against 0.2426 with 8 and
+  // 0.2565 with 16), 8 otherwise (8192 rows: 15.5 us against 19.1 with 4); VMLMF_XR = 4 / 8 / 16 overrides (A/B runs)
+  static const int xr_env = []() { const char* e = getenv("VMLMF_XR"); return e ? atoi(e) : 0; }();
+  const int xr = xr_env == 16 ? 16 : (xr_env == 8 ? 8 : (xr_env == 4 ? 4 : (TBp <= 4096 ? 4 : 8)));
   const dim3 grid((TBp + xr - 1) / xr), block(256);
   const size_t lds = sizeof(float) * ((size_t)xr * g.I + (size_t)xr * g.KX + (size_t)(256 / g.KX) * xr * g.KX);
   const float *uxp = pack + L.UXP, *vxt = pack + L.VXT, *ext = pack + L.EXT, *bbt = pack + L.BBT;
@@ -348,6 +352,8 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
         if (e != hipSuccess) return (int)e;                                                                 \
       }                                                                                                     \
       hipLaunchKernelGGL((xproj_kernel<K, 16>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);     \
+    } else if (xr == 4) {                                                                                   \
+      hipLaunchKernelGGL((xproj_kernel<K, 4>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);      \
     } else {                                                                                                \
       hipLaunchKernelGGL((xproj_kernel<K, 8>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);      \
     }                                                                                                       \
