@@ -68,6 +68,7 @@ const bool g_xwave = []() {
 
 // wgrad chunking (A/B measurements): VMLMF_WCHUNKS = target number of row chunks, VMLMF_WMIN = fewest rows per chunk
 const int g_wchunks = []() { const char* e = getenv("VMLMF_WCHUNKS"); return e ? atoi(e) : 64; }();
+const int g_rc = []() { const char* e = getenv("VMLMF_RC"); return e ? atoi(e) : 0; }();   // dqx_dx rows per workgroup (A/B)
 const int g_wmin = []() { const char* e = getenv("VMLMF_WMIN"); return e ? atoi(e) : 64; }();   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
 
 // ---- geometry ----
@@ -150,6 +151,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // 128 chunks gain 2 us there and lose them again in reduce_cg_kernel, 32 chunks cost 10 us)
   int rc = ((TB + 1023) / 1024 + 7) / 8 * 8;
   if (rc < 8) rc = 8;
+  if (g_rc > 0) rc = g_rc;
   g.RC = rc;
   g.nblk = (TB + rc - 1) / rc;
   int rc2 = (TB + g_wchunks - 1) / g_wchunks;
