@@ -397,3 +397,16 @@ def test_cross_entropy_unit_gradient_shortcut_equals_the_general_backward():
     torch.nn.functional.cross_entropy(zr, t).backward()
     assert torch.allclose(grads[0], zr.grad, rtol=1e-5, atol=1e-7)
     assert vmlmf_amd.unit_gradient(DEV) is vmlmf_amd.unit_gradient("cuda") and float(vmlmf_amd.unit_gradient(DEV)) == 1.0
+
+
+def test_unit_gradient_shortcut_survives_a_retained_graph():
+    """Leaf logits + retain_graph: the second backward must add the same gradient again, not a doubled one."""
+    import vmlmf_amd
+    torch.manual_seed(6)
+    z = torch.randn(16, 7, device=DEV, requires_grad=True)
+    t = torch.randint(0, 7, (16,), device=DEV)
+    loss = vmlmf_amd.cross_entropy(z, t)
+    loss.backward(vmlmf_amd.unit_gradient(DEV), retain_graph=True)
+    g1 = z.grad.clone()
+    loss.backward(vmlmf_amd.unit_gradient(DEV))
+    assert torch.allclose(z.grad, 2 * g1, rtol=1e-6, atol=0)

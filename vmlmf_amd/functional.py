@@ -279,7 +279,9 @@ class CrossEntropyFn(torch.autograd.Function):
         logits, target, stats = ctx.saved_tensors[:3]
         unit = _UNIT.get(logits.device)
         if unit is not None and dloss.data_ptr() == unit.data_ptr() and len(ctx.saved_tensors) == 4:
-            return ctx.saved_tensors[3], None, None     # d(loss) is the package's constant one: forward wrote this
+            # d(loss) is the package's constant one: forward wrote this.  Handed out as a view so that autograd never adopts the
+            # saved buffer itself as a leaf's .grad (it clones views), which a second backward through a retained graph would see
+            return ctx.saved_tensors[3].view_as(logits), None, None
         B, C = logits.shape
         dloss = dloss.contiguous()
         dz = torch.empty_like(logits)
