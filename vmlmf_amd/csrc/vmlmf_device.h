@@ -71,6 +71,11 @@ __device__ __forceinline__ float bcast_lane(float x, int l) {
 }
 
 // Sum over the four 16-lane rows of a wave: every lane i ends with v[i] + v[i+16] + v[i+32] + v[i+48].
+// sum over each pair of 16-lane rows (rows 0+1 and rows 2+3), every lane of the pair gets it
+__device__ __forceinline__ float rowsum2(float v) {
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 __device__ __forceinline__ float rowsum4(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
