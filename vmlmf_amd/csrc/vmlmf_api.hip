@@ -162,7 +162,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.NA = 5 * g.KX + 5 * g.KH + 12;
   {
     const long long GK = (long long)g.G * g.KH;
-    const long long nb1 = (g.KX + GK + 31) / 32 * 32, nb2 = (GK + 31) / 32 * 32, nb3 = (g.KX + 31) / 32 * 32;
+    const long long nb1 = (vg_nb1(g) + 31) / 32 * 32, nb2 = (GK + 31) / 32 * 32, nb3 = (g.KX + 31) / 32 * 32;
     g.PCH = (long long)g.NT * 4 * nb1 + (long long)((g.H + 31) / 32) * 32 * nb2 +
             (long long)((g.I + 31) / 32) * 32 * nb3 + 3LL * g.NT * 4;
   }

@@ -89,6 +89,12 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   return p;
 }
 
+// Columns of B in the dV product (wgrad mode 1): qx and the rank-space vectors a (slot, gate) column can pair with.  In
+// the flat layout a slot's gates read both vectors; otherwise (V1-V3, V5, V6) a unit only ever reads the vector of its
+// own group, and the slots of a task (8 consecutive ones) lie in one group, so the other vector's columns would only
+// be computed to be thrown away by reduce_cg_kernel (they were: 80 instead of 48 columns for the group cell).
+VG_HD int vg_nb1(const VGeo& g) { return g.KX + (g.flat ? g.G * g.KH : g.KH); }
+
 // wgrad accumulator indices (per thread slot)
 VG_HD int va_vx(const VGeo& g, int k, int r) { return k * g.KX + r; }
 VG_HD int va_vc(const VGeo& g, int k, int rr) { return 4 * g.KX + k * g.KH + rr; }

@@ -131,7 +131,8 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
   const int row0 = crow0 + half * plen < crow1 ? crow0 + half * plen : crow1;
   const int row1 = row0 + plen < crow1 && half != NS - 1 ? row0 + plen : crow1;
   const int li = lane & 31, lk = lane >> 5;
-  const int NB = MODE == 1 ? KX + GK : (MODE == 2 ? GK : KX);     // B columns
+  const int NB = MODE == 1 ? vg_nb1(g) : (MODE == 2 ? GK : KX);   // B columns
+  const int qoff = (MODE == 1 && !g.flat) ? ((mt * 8) / (64 * g.W)) * g.KH : 0;   // mode 1: this task's group's vector
   constexpr int nbt = NBT;
   const int col = mt * 32 + li;                                     // A column of this lane
   int n1 = 0;
@@ -161,7 +162,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
         bsrc[j] = a.x + (cc < g.I ? cc : 0);
         bstr[j] = 0;
       } else {
-        bsrc[j] = cc < KX ? a.qx + cc : a.Qs + (cc - KX);
+        bsrc[j] = cc < KX ? a.qx + cc : a.Qs + qoff + (cc - KX);
         bstr[j] = cc < KX ? KX : GK;
       }
     } else if (MODE == 2) {
@@ -263,7 +264,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
     }
   }
   // partial layout per chunk: C1 [NT*4][NB1p] | C2 [M2p][NB2p] | C3 [M3p][NB3p] | E [3][NT*4]
-  const int NB1p = (KX + GK + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
+  const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
   const size_t o2 = (size_t)NT * 4 * NB1p, o3 = o2 + (size_t)MT2 * 32 * NB2p, oe = o3 + (size_t)MT3 * 32 * NB3p;
   float* P = a.P + (size_t)chunk * g.PCH;
   float* C = MODE == 1 ? P : (MODE == 2 ? P + o2 : P + o3);
@@ -331,19 +332,20 @@ __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __r
 
   const int KX = g.KX, KH = g.KH, GK = g.G * KH, NT = g.NT;
   const int MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
-  const int NB1p = (KX + GK + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
+  const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
   const long long o2 = (long long)NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p,
                   oe = o3 + (long long)MT3 * 32 * NB3p;
   if (e < o2) {                       // C1[(slot,k)][j]
     const int i = (int)(e / NB1p), j = (int)(e - (long long)i * NB1p), slot = i >> 2, k = i & 3;
     if (j < KX) {
       cgrad[(size_t)va_vx(g, k, j) * NT + slot] = total;
-    } else if (j < KX + GK) {
-      int n;
-      const bool valid = vg_slot_unit(g, slot, n);
-      const int q = (j - KX) / KH, rr = (j - KX) - q * KH;
-      const int qsel = g.flat ? (k >= 2 ? 1 : 0) : (valid ? n / g.Hg : 0);
-      if (q == qsel) cgrad[(size_t)va_vc(g, k, rr) * NT + slot] = total;
+    } else if (j < vg_nb1(g)) {
+      if (g.flat) {   // both vectors' columns are there; gates i, f pair with vector 0, gates o, n with vector 1
+        const int q = (j - KX) / KH, rr = (j - KX) - q * KH;
+        if (q == (k >= 2 ? 1 : 0)) cgrad[(size_t)va_vc(g, k, rr) * NT + slot] = total;
+      } else {        // only the columns of the slot's own group were computed
+        cgrad[(size_t)va_vc(g, k, j - KX) * NT + slot] = total;
+      }
     }
   } else if (e < o3) {                // C2[n][dest*KH + rr]
     const long long e2 = e - o2;
@@ -392,13 +394,15 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
   a.P = w.wpart;
   const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
-  const int GK = g.G * g.KH, n1 = (g.KX + GK + 31) / 32, n2 = (GK + 31) / 32;
+  const int GK = g.G * g.KH, n1 = (vg_nb1(g) + 31) / 32, n2 = (GK + 31) / 32;
   const dim3 grid((tasks + 3) / 4, g.nchunk);
   // two waves per task while the hand-over buffer stays small (four measured slower at the headline shape:
   // 0.1990 vs 0.1966 ms per step)
-  if (n1 <= 2) {
-    const size_t lds = sizeof(float) * 4 * (16 * (size_t)n1 + 3) * 64;
-    if (n1 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 2>), grid, dim3(512), lds, s, g, a);
+  if (n1 <= 2 && n2 <= 2) {
+    const int nm = n1 > n2 ? n1 : n2;
+    const size_t lds = sizeof(float) * 4 * (16 * (size_t)nm + 3) * 64;
+    if (n1 == 1 && n2 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 2>), grid, dim3(512), lds, s, g, a);
+    else if (n1 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2, 2>), grid, dim3(512), lds, s, g, a);
     else if (n2 == 1) hipLaunchKernelGGL((wgrad_mfma_kernel<2, 1, 2>), grid, dim3(512), lds, s, g, a);
     else hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, 2>), grid, dim3(512), lds, s, g, a);
     return (int)hipGetLastError();
@@ -406,10 +410,14 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   const dim3 block(256);
 #define WG_CASE(A, Bv) \
   if (n1 == A && n2 == Bv) hipLaunchKernelGGL((wgrad_mfma_kernel<A, Bv, 1>), grid, block, 0, s, g, a)
-  // n1 = tiles of KX + G*KH (<= 160 columns), n2 = tiles of G*KH (<= 128 columns), n2 <= n1
-  WG_CASE(3, 1);
+  // n1 = tiles of KX + (own vector: KH, flat layout: G*KH) (<= 160 columns), n2 = tiles of G*KH (<= 128 columns); with two
+  // groups n2 can exceed n1
+  WG_CASE(2, 3);
+  else WG_CASE(2, 4);
+  else WG_CASE(3, 1);
   else WG_CASE(3, 2);
   else WG_CASE(3, 3);
+  else WG_CASE(3, 4);
   else WG_CASE(4, 2);
   else WG_CASE(4, 3);
   else WG_CASE(4, 4);
