@@ -55,6 +55,9 @@ def test_query_headline_geometry():
     assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kx, s.kh) == (1, 192, 64, 16, 16)
     s = _lib.query(_lib.make_desc(_lib.V6_GROUP_NOVM, 64, 128, 9, 180, 16, [16, 16], g=2))
     assert (s.threads_per_wg, s.kh) == (256, 32)
+    # ... and, unlike them, accept more inputs than hidden units (as the reference does for these two cells)
+    s = _lib.query(_lib.make_desc(_lib.V5_LMF_CELL, 4, 3, 10, 8, 3, [3]))
+    assert s.workspace_bytes > 0
 
 
 @pytest.mark.parametrize("desc,code", [
@@ -62,7 +65,6 @@ def test_query_headline_geometry():
     (dict(variant=_lib.V3_LM, B=4, T=3, I=6, H=8, w_rank=3, u_ranks=[3]), _lib.E_SHAPE),          # vmlmf_lm.py:243
     (dict(variant=_lib.V2_GROUP_CELL, B=4, T=3, I=4, H=9, w_rank=3, u_ranks=[2, 2], g=2), _lib.E_SHAPE),
     (dict(variant=7, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
-    (dict(variant=_lib.V5_LMF_CELL, B=4, T=3, I=10, H=8, w_rank=3, u_ranks=[3]), _lib.E_UNSUPPORTED),  # valid in the reference
     (dict(variant=_lib.V6_GROUP_NOVM, B=4, T=3, I=4, H=9, w_rank=3, u_ranks=[2, 2], g=2), _lib.E_SHAPE),
     (dict(variant=_lib.V1_CELL, B=0, T=3, I=4, H=8, w_rank=3, u_ranks=[3]), _lib.E_BADARG),
     (dict(variant=_lib.V1_CELL, B=4, T=3, I=4, H=8, w_rank=3, u_ranks=[0]), _lib.E_BADARG),

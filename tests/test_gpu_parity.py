@@ -91,14 +91,13 @@ def test_config_a_comparison_cells_full_size_vs_reference_golden(name):
         assert_grad(got["G"][k], v, "G." + k)
 
 
-def test_comparison_cell_wider_input_than_hidden_is_refused_loudly():
-    """The reference's cells without vm accept input_size > hidden_size (golden cell_v5_iwide pins the oracle there);
-    the HIP kernels do not cover it yet and say so instead of computing something else."""
-    from vmlmf_amd._lib import VmlmfError, E_UNSUPPORTED
+def test_comparison_cell_with_more_inputs_than_units_vs_reference_golden():
+    """The reference's cells without vm accept input_size > hidden_size (no vm_x to pad); such a layer runs the step-wise
+    path, whose x side is indexed by input rather than by unit slot."""
     d = load_golden("cell_v5_iwide")
-    with pytest.raises(VmlmfError) as e:
-        run_hip(O.V5, d["P"], d["x"][:, None], d["h0"], d["c0"])
-    assert e.value.code == E_UNSUPPORTED
+    got = run_hip(O.V5, d["P"], d["x"][:, None], d["h0"], d["c0"], None, d["dh"], d["dc"])
+    ref = {"hT": d["h1"], "cT": d["c1"], "dx": d["dx"][:, None], "dh0": d["dh0"], "dc0": d["dc0"], "G": d["G"]}
+    compare_all(got, ref, "cell_v5_iwide")
 
 
 CASES = [
@@ -138,6 +137,8 @@ CASES = [
     (O.V6, 4, 5, 10, 136, 8, [16, 8], False, True),
     (O.V6, 300, 2, 5, 24, 3, [4, 4], False, False),
     (O.V6, 3, 3, 20, 48, 4, [24, 20], False, True),  # step-wise path
+    (O.V5, 5, 4, 77, 40, 8, [6], False, True),       # more inputs than units (valid without vm): step-wise path
+    (O.V6, 4, 3, 100, 24, 5, [4, 4], True, False),   # ... group cell, time-major, three input tiles
 ]
 
 

@@ -99,8 +99,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   // the reference fails on these shapes too (vmlmf.py:94 / vmlmf_lm.py:243)
   if (!lm && !g.novm && g.I > g.H)
     return fail(VMLMF_E_SHAPE, "input_size > hidden_size: the reference cell raises (vmlmf.py:94,103)");
-  if (g.novm && g.I > g.H)
-    return fail(VMLMF_E_UNSUPPORTED, "input_size > hidden_size is not covered by the HIP kernels (cells without vm)");
+
   if (lm && g.I != g.H) return fail(VMLMF_E_SHAPE, "LM layers need input_size == hidden_size (vmlmf_lm.py:243)");
   g.ru0 = d->u_ranks[0];
   g.ru1 = g.G == 2 ? d->u_ranks[1] : 0;
@@ -135,7 +134,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   if (g.G * g.KH > 128) return fail(VMLMF_E_UNSUPPORTED, "padded hidden rank (summed over groups) > 128 is not covered");
   // register-resident persistent kernels need <= 32 ranks per unit and <= 512 thread slots; larger layers
   // (e.g. H = 650, ranks [32,32]) run the step-wise path of vmlmf_generic.hip
-  g.generic = (g.KH > 32 || g.NT > 512) ? 1 : 0;
+  // (the cells without vm accept input_size > hidden_size; the persistent kernels keep x-side quantities in the slots of the
+  // first I units, so such a layer takes the step-wise path, whose x side is indexed by input)
+  g.generic = (g.KH > 32 || g.NT > 512 || g.I > g.H) ? 1 : 0;
   // One batch row per workgroup, whatever the batch: with more rows than CUs the workgroups queue up, which
   // measured at least as fast as two rows per workgroup at every size (H = 180, T = 128: B = 512 0.49 vs 0.55 ms,
   // 768 0.71 vs 0.78, 1024 0.98 vs 0.96, 2048 1.84 vs 2.00); the kernels keep their R template parameter.
@@ -209,7 +210,7 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
   L.b_dqx = o, o += align64(TB * g.KX);
   L.b_wpart = o, o += align64((long long)g.nchunk * g.PCH);
-  L.b_cgrad = o, o += align64((long long)g.NA * g.NT);
+  L.b_cgrad = o, o += align64((long long)g.NA * g.NT + (g.I > g.H ? (long long)g.I * g.KX : 0));   // + dU_x by input when I > H
   L.b_trash = o, o += 64;
   {
     const long long gen = g.generic ? 1 : 0, BN = (long long)g.B * g.NT;

@@ -733,8 +733,11 @@ __global__ void __launch_bounds__(256) dx_kernel(VGeo g, const float* __restrict
       const float4 v = ld4(uxp + (size_t)m * KX + 4 * q);
       u[4 * q] = v.x, u[4 * q + 1] = v.y, u[4 * q + 2] = v.z, u[4 * q + 3] = v.w;
     }
-    const float e0 = ext[0 * g.H + m], e1 = ext[1 * g.H + m], e2 = ext[2 * g.H + m], e3 = ext[3 * g.H + m];
-    const int slot = vg_slot(g, m);
+    // inputs beyond the last unit (cells without vm only) have no x .* ex term and no slot
+    const int mh = m < g.H ? m : 0;
+    const float em = m < g.H ? 1.f : 0.f;
+    const float e0 = em * ext[0 * g.H + mh], e1 = em * ext[1 * g.H + mh], e2 = em * ext[2 * g.H + mh], e3 = em * ext[3 * g.H + mh];
+    const int slot = vg_slot(g, mh);
     float4 d[DXR];
 #pragma unroll
     for (int r = 0; r < DXR; ++r) {

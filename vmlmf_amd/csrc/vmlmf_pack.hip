@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   if (e < n_ux) {  // du_x[m][r]
     if (g.foldx) return;
     const int m = (int)(e / rw), r = (int)(e % rw);
-    float v = CG(va_ux(g, r), m);
+    float v = I > H ? cg[(size_t)g.NA * NT + (size_t)m * g.KX + r] : CG(va_ux(g, r), m);   // (I > H: reduce_cg_kernel's own block)
     if (!g.novm)
       for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
     o.u_x[e] = v;

@@ -359,7 +359,10 @@ __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __r
   } else if (e < oe) {                // C3[m][r]
     const long long e3 = e - o3;
     const int m = (int)(e3 / NB3p), r = (int)(e3 - (long long)m * NB3p);
-    if (!g.foldx && m < g.I && r < KX) cgrad[(size_t)va_ux(g, r) * NT + vg_slot(g, m)] = total;
+    // dU_x lives in the slot of unit m; with more inputs than units (cells without vm only) in a block of its own behind the
+    // per-slot accumulators
+    if (!g.foldx && m < g.I && r < KX)
+      cgrad[g.I > g.H ? (size_t)g.NA * NT + (size_t)m * KX + r : (size_t)va_ux(g, r) * NT + vg_slot(g, m)] = total;
   } else {                            // E[which][(slot,k)]
     const long long e4 = e - oe;
     const int which = (int)(e4 / (NT * 4)), i = (int)(e4 - (long long)which * NT * 4), slot = i >> 2, k = i & 3;
