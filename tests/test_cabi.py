@@ -91,3 +91,15 @@ def test_forward_refuses_null_buffers_without_touching_the_gpu():
     rc = lib.vmlmf_seq_forward(ctypes.byref(d5), ctypes.byref(p), None, None, None, None, None, None, None, None,
                                0, None)
     assert rc == _lib.E_BADARG and b"null pointer in params" in lib.vmlmf_last_error()
+
+
+def test_driver_build_entry_point_runs():
+    """__graft_entry__.build() is what the driver calls on the CPU box: make (a no-op when the library is current),
+    import, ABI check."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.build()
