@@ -66,7 +66,7 @@ def usable_cores():
     return max(1, n)
 
 
-def cpu_baseline(budget_s=25.0):
+def cpu_baseline(budget_s=30.0):
     """Reference CPU path (port): oracle.literal_* (op-for-op PyTorch-CPU restatement of the reference cell
     and time loop, autograd backward) on the host cores, same shapes, same step definition.  The workload is
     dispatch-bound (~75 tiny ATen ops per timestep), so more threads are not faster: it is timed with 1
@@ -92,14 +92,15 @@ def cpu_baseline(budget_s=25.0):
     results = {}
     for nt in sorted({1, min(cores, 16)}):
         torch.set_num_threads(nt)
-        one()                                   # warm-up
+        for _ in range(3):                      # 3 warm-up + >= 5 timed steps, median
+            one()
         times, t_start = [], time.perf_counter()
-        while len(times) < 5 and (time.perf_counter() - t_start) < budget_s / 2:
+        while len(times) < 5 or (len(times) < 9 and (time.perf_counter() - t_start) < budget_s / 4):
             times.append(one())
         results[nt] = float(np.median(times))
     best = min(results, key=results.get)
     return {"value": T / results[best], "unit": "RNN timesteps/s", "cores": best, "kind": "port",
-            "sample": f"full steps of the bench workload (B={B_PER_GPU} T={T} I={I} H={H} r={RU}), 1 warm-up + up to 5 "
+            "sample": f"full steps of the bench workload (B={B_PER_GPU} T={T} I={I} H={H} r={RU}), 3 warm-up + 5-9 "
                       f"timed per thread count, median; s/step by threads: "
                       + ", ".join(f"{k}: {v:.3f}" for k, v in results.items())
                       + f"; host has {cores} usable cores",

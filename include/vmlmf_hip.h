@@ -125,7 +125,8 @@ int vmlmf_head_backward(int B, int H, int C, const float *h, long long ldh, cons
 /*
  * Cross-entropy of the classifier logits, mean over the rows whose target != ignore_index: the criterion of
  * the reference's training loop (nn.CrossEntropyLoss on Net's output, V/src/train_test/train.py:58-65) — SURVEY
- * §8f "next" row.  logits (B,C) dense fp32, target (B) int64.  Forward writes the scalar loss, the row
+ * §8f "next" row.  logits (B,C) dense fp32, target (B) int64 in [0, C) or == ignore_index (any other value: the loss
+ * becomes NaN, nothing is read out of bounds).  Forward writes the scalar loss, the row
  * log-sum-exps lse (B) and the number of counted rows nvalid (1); backward turns them and the incoming
  * gradient of the loss (device scalar) into dlogits (B,C).  One workgroup in forward: meant for classifier
  * sized problems (the Python wrapper dispatches B*C <= 65536 here and leaves larger ones to the library op).
@@ -139,7 +140,8 @@ int vmlmf_ce_backward(int B, int C, const float *logits, const int64_t *target, 
 
 /*
  * Softmax negative log-likelihood of the language-model loop (nll_loss, V/src/train_test/lm_test.py:140-153) —
- * SURVEY §8f rank 3.  scores (R,V) dense fp32 with R = T*B rows, y (R) int64 targets in row order.
+ * SURVEY §8f rank 3.  scores (R,V) dense fp32 with R = T*B rows, y (R) int64 targets in [0, V) in row order (a target
+ * outside that range makes the loss NaN; the reference's indexing raises).
  *   loss = scale * sum_r (logsumexp(scores[r]) - scores[r][y[r]])        (the reference: scale = batch_size / R)
  * Forward writes loss (1), lse (R) and rowloss (R) and reads scores once; backward writes
  * dscores = dloss * scale * (softmax(scores) - onehot(y)) from scores, lse and the device scalar dloss.

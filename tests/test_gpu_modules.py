@@ -247,11 +247,16 @@ def test_graphed_train_step_matches_the_eager_loop():
     step = vmlmf_amd.GraphedTrainStep(a, vmlmf_amd.cross_entropy, vmlmf_amd.optim.Adam(a.parameters(), lr=2e-3),
                                       xs[0], ts[0], warmup=2)
     opt = vmlmf_amd.optim.Adam(b.parameters(), lr=2e-3)
-    for _ in range(2):                      # the warm-up steps of the graphed loop, eagerly
-        b.zero_grad(set_to_none=True)
-        vmlmf_amd.cross_entropy(b(xs[0]), ts[0]).backward()
-        opt.step()
-    for x, t in zip(xs, ts):
+    # constructing the graphed step must leave model and optimizer untouched (its warm-up runs on a snapshot): the
+    # eager twin does NO extra steps, the first call is step 1 of the loop (train.py:58-65)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+    xs.append(torch.randn(5, 12, 9, generator=g).cuda())      # the last, shorter DataLoader batch: eager fallback
+    ts.append(torch.randint(0, 18, (5,), generator=g).cuda())
+    for it, (x, t) in enumerate(zip(xs, ts)):
+        if it == 2:                         # a scheduler changes the learning rate: the replay must follow it
+            for o in (step.optimizer, opt):
+                o.param_groups[0]["lr"] = 5e-4
         la = step(x, t).clone()
         b.zero_grad(set_to_none=True)
         lb = vmlmf_amd.cross_entropy(b(x), t)
@@ -260,6 +265,43 @@ def test_graphed_train_step_matches_the_eager_loop():
         assert abs(float(la) - float(lb)) <= 1e-6 * max(1.0, abs(float(lb)))
     for pa, pb in zip(a.parameters(), b.parameters()):
         assert torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+    assert float(step.optimizer.state[next(a.rnn.parameters())]["step"]) == float(len(xs))
+
+
+def test_fused_adam_resumes_from_a_checkpoint_like_torch_adam():
+    """save -> load_state_dict -> step: moments and step counts must survive, also when the checkpoint was
+    written by torch.optim.Adam itself."""
+    import vmlmf_amd
+    g = torch.Generator().manual_seed(2)
+    shapes = [(9, 16), (180,), (18, 180)]
+    mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    o1, o2 = vmlmf_amd.optim.Adam(mine, lr=2e-3), torch.optim.Adam(ref, lr=2e-3)
+
+    def feed():
+        for a, b in zip(mine, ref):
+            gr = torch.randn(*a.shape, generator=g).cuda()
+            a.grad, b.grad = gr.clone(), gr.clone()
+
+    for _ in range(3):
+        feed()
+        o1.step(), o2.step()
+    sd_mine, sd_ref = o1.state_dict(), o2.state_dict()
+    fresh = vmlmf_amd.optim.Adam(mine, lr=2e-3)             # resume on a fresh optimizer
+    fresh.load_state_dict(sd_mine)
+    o1.load_state_dict(sd_ref)                              # and on one that has stepped, from the stock optimizer's file
+    mine2 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    third = vmlmf_amd.optim.Adam(mine2, lr=2e-3)
+    third.load_state_dict(sd_ref)
+    for _ in range(2):
+        feed()
+        for a, c in zip(mine, mine2):
+            c.grad = a.grad.clone()
+        fresh.step(), o2.step(), third.step()
+    for a, b, c in zip(mine, ref, mine2):
+        assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+        assert float((c - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+    assert float(fresh.state[mine[0]]["step"]) == 5.0 and float(third.state[mine2[0]]["step"]) == 5.0
 
 
 @pytest.mark.parametrize("name", ["seq_v5_wide", "seq_v6_demo"])
@@ -408,5 +450,27 @@ def test_unit_gradient_shortcut_survives_a_retained_graph():
     loss = vmlmf_amd.cross_entropy(z, t)
     loss.backward(vmlmf_amd.unit_gradient(DEV), retain_graph=True)
     g1 = z.grad.clone()
-    loss.backward(vmlmf_amd.unit_gradient(DEV))
+    loss.backward(vmlmf_amd.unit_gradient(DEV), retain_graph=True)
     assert torch.allclose(z.grad, 2 * g1, rtol=1e-6, atol=0)
+    # in-place work on the leaf's gradient must not reach the buffer the graph keeps
+    z.grad.zero_()
+    torch.nn.utils.clip_grad_norm_([z], 1e-3)
+    loss.backward(vmlmf_amd.unit_gradient(DEV))
+    assert torch.allclose(z.grad, g1, rtol=1e-6, atol=0)
+
+
+def test_out_of_range_targets_poison_the_loss_without_reading_out_of_bounds():
+    """A class index outside [0, C) that is not ignore_index: PyTorch asserts on the device; the fused criteria return NaN."""
+    import vmlmf_amd
+    z = torch.randn(8, 5, device=DEV)
+    t = torch.tensor([0, 1, 2, 3, 4, 0, 1, 2], device=DEV)
+    assert torch.isfinite(vmlmf_amd.cross_entropy(z, t))
+    for bad in (5, -3, 1 << 40):
+        t2 = t.clone()
+        t2[4] = bad
+        assert torch.isnan(vmlmf_amd.cross_entropy(z, t2))
+    s = torch.randn(6, 1000, device=DEV)
+    y = torch.randint(0, 1000, (3, 2), device=DEV)
+    assert torch.isfinite(vmlmf_amd.nll_loss(s, y))
+    y[1, 1] = 1000
+    assert torch.isnan(vmlmf_amd.nll_loss(s, y))

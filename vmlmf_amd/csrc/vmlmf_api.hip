@@ -67,9 +67,16 @@ const bool g_xwave = []() {
 }();
 
 // wgrad chunking (A/B measurements): VMLMF_WCHUNKS = target number of row chunks, VMLMF_WMIN = fewest rows per chunk
-const int g_wchunks = []() { const char* e = getenv("VMLMF_WCHUNKS"); return e ? atoi(e) : 64; }();
-const int g_rc = []() { const char* e = getenv("VMLMF_RC"); return e ? atoi(e) : 0; }();   // dqx_dx rows per workgroup (A/B)
-const int g_wmin = []() { const char* e = getenv("VMLMF_WMIN"); return e ? atoi(e) : 64; }();   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
+// (non-numeric or non-positive values fall back to the defaults: a zero here would divide by zero in make_geo)
+int env_pos(const char* name, int dflt) {
+  const char* e = getenv(name);
+  if (e == nullptr) return dflt;
+  const int v = atoi(e);
+  return v >= 1 ? v : dflt;
+}
+const int g_wchunks = env_pos("VMLMF_WCHUNKS", 64);
+const int g_rc = env_pos("VMLMF_RC", 0);   // dqx_dx rows per workgroup (A/B); 0 = derived from the row count
+const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out) {

@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* 
       lse[b] = l;
       const long long t = tgt[b];
       if (t != ignore_index) {
-        part += l - zb[t];
+        // a class index outside [0, C) (PyTorch: device-side assert) poisons the loss instead of reading out of bounds
+        const bool inr = t >= 0 && t < C;
+        part += inr ? l - zb[inr ? t : 0] : NAN;
         cnt += 1.f;
       }
     }

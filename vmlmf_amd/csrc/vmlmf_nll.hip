@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256) void nll_rows_kernel(int V, const float* __res
   if (tid == 0) {
     const float l = m + __logf(s);
     lse[row] = l;
-    rowloss[row] = l - z[y[row]];
+    const long long t = y[row];   // outside [0, V): NaN loss, no out-of-bounds read (the reference's indexing asserts)
+    const bool inr = t >= 0 && t < V;
+    rowloss[row] = inr ? l - z[inr ? t : 0] : NAN;
   }
 }
 

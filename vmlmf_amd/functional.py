@@ -272,6 +272,7 @@ class CrossEntropyFn(torch.autograd.Function):
                                                    _ptr(dz_unit), stream))
         ctx.save_for_backward(logits, target, stats, *([dz_unit] if dz_unit is not None else []))
         ctx.ignore_index = int(ignore_index)
+        ctx.leaf_logits = logits.grad_fn is None
         return stats[0]
 
     @staticmethod
@@ -279,9 +280,12 @@ class CrossEntropyFn(torch.autograd.Function):
         logits, target, stats = ctx.saved_tensors[:3]
         unit = _UNIT.get(logits.device)
         if unit is not None and dloss.data_ptr() == unit.data_ptr() and len(ctx.saved_tensors) == 4:
-            # d(loss) is the package's constant one: forward wrote this.  Handed out as a view so that autograd never adopts the
-            # saved buffer itself as a leaf's .grad (it clones views), which a second backward through a retained graph would see
-            return ctx.saved_tensors[3].view_as(logits), None, None
+            # d(loss) is the package's constant one: forward wrote this.  Logits produced by another node (the classifier
+            # head) just pass it on.  When the logits are a LEAF, AccumulateGrad adopts what it is handed as .grad (views
+            # included), and in-place work on that gradient (zero_grad(set_to_none=False), clip_grad_norm_, a further
+            # backward through a retained graph) would then write into the saved buffer: such callers get a copy.
+            dz = ctx.saved_tensors[3]
+            return (dz.clone() if ctx.leaf_logits else dz), None, None
         B, C = logits.shape
         dloss = dloss.contiguous()
         dz = torch.empty_like(logits)

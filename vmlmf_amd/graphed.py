@@ -8,6 +8,11 @@ host synchronisation, device-side step counters).
     step = GraphedTrainStep(model, vmlmf_amd.cross_entropy, vmlmf_amd.optim.Adam(model.parameters(), lr), x0, t0)
     for data, target in loader:
         loss = step(data.to(dev), target.to(dev))        # 0-d device tensor, valid until the next call
+
+Constructing it leaves the model and the optimizer as they were (the warm-up steps the capture needs run on a
+snapshot that is restored).  A batch whose shape differs from the example's (the last, shorter DataLoader batch) runs
+the same body eagerly.  Scalars the kernels take by value are frozen in a capture (the learning rate of
+vmlmf_amd.optim.Adam): when a group's lr / betas / eps / weight_decay has changed since the capture, the step is captured again.
 """
 from __future__ import annotations
 
@@ -20,8 +25,9 @@ from .functional import unit_gradient
 
 class GraphedTrainStep:
     def __init__(self, model, criterion, optimizer, example_input, example_target, warmup=3):
-        """The `warmup` steps are real training steps on the example batch (they create the optimizer state and
-        settle the allocator); the capture itself executes nothing."""
+        """The `warmup` steps (allocator warm-up, creation of the optimizer state) run on the example batch; parameters
+        and optimizer state are put back to their values from before afterwards, so the first call is step 1 of the
+        reference loop (train.py:58-65).  The capture itself executes nothing."""
         self.model, self.criterion, self.optimizer = model, criterion, optimizer
         self.x = example_input.clone()
         self.t = example_target.clone()
@@ -33,6 +39,13 @@ class GraphedTrainStep:
             raise ValueError("at least one warm-up step: optimizer state must exist before the capture")
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
+        params = [p for group in optimizer.param_groups for p in group["params"]]
+        seen = {id(p) for p in params}
+        params += [p for p in model.parameters() if id(p) not in seen]
+        with torch.no_grad():
+            p_before = [p.detach().clone() for p in params]
+            s_before = {(id(p), k): (v.detach().clone() if torch.is_tensor(v) else v)
+                        for p, st in optimizer.state.items() for k, v in st.items()}
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -40,20 +53,45 @@ class GraphedTrainStep:
                 self._body()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
-        gc.collect()                         # no autograd graph of the warm-up may outlive this point
+        # undo the warm-up IN PLACE (the state tensors must keep their addresses: the capture records them): state
+        # that did not exist before goes back to zero, which is what a fresh optimizer starts from
+        with torch.no_grad():
+            for p, v in zip(params, p_before):
+                p.copy_(v)
+            for p, st in optimizer.state.items():
+                for k, v in st.items():
+                    old = s_before.get((id(p), k))
+                    if torch.is_tensor(v):
+                        v.copy_(old) if torch.is_tensor(old) else v.zero_()
+                    elif old is not None:
+                        st[k] = old
+        torch.cuda.synchronize(dev)
+        self._capture()
+
+    def _hyper(self):
+        return tuple((float(g["lr"]), tuple(g.get("betas", ())), g.get("eps"), g.get("weight_decay"))
+                     for g in self.optimizer.param_groups)
+
+    def _capture(self):
+        gc.collect()                         # no autograd graph of earlier steps may outlive this point
         self.graph = torch.cuda.CUDAGraph()
-        model.zero_grad(set_to_none=True)
+        self.model.zero_grad(set_to_none=True)
+        self._captured_hyper = self._hyper()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
 
-    def _body(self):
+    def _body(self, x=None, t=None):
         self.model.zero_grad(set_to_none=True)
-        loss = self.criterion(self.model(self.x), self.t)
+        loss = self.criterion(self.model(self.x if x is None else x), self.t if t is None else t)
         loss.backward(self._one if loss.dim() == 0 and loss.dtype == self._one.dtype else None)
         self.optimizer.step()
         return loss.detach()
 
     def __call__(self, x, target):
+        if x.shape != self.x.shape or target.shape != self.t.shape:
+            return self._body(x, target)     # e.g. the last, shorter batch of a DataLoader: same step, eager launches
+        if self._hyper() != self._captured_hyper:
+            self._capture()                  # a scheduler changed lr (by-value kernel argument): capture it again
         self.x.copy_(x, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self.graph.replay()

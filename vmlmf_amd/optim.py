@@ -67,9 +67,25 @@ class Adam(torch.optim.Optimizer):
             self._flat[gi] = gs
             for p in ps:
                 o = offs[p]
-                self.state[p] = dict(step=gs["steps"][sidx[p]], exp_avg=gs["m"][o:o + p.numel()].view_as(p),
-                                     exp_avg_sq=gs["v"][o:o + p.numel()].view_as(p))
+                new = dict(step=gs["steps"][sidx[p]], exp_avg=gs["m"][o:o + p.numel()].view_as(p),
+                           exp_avg_sq=gs["v"][o:o + p.numel()].view_as(p))
+                # state that exists already (load_state_dict of a checkpoint, also one written by torch.optim.Adam)
+                # moves into the flat buffers the kernel reads
+                old = self.state.get(p)
+                if old:
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if k in old:
+                            new[k].copy_(old[k].to(device=dev, dtype=torch.float32).view_as(p))
+                    if "step" in old:
+                        new["step"].fill_(float(old["step"]))
+                self.state[p] = new
         return gs
+
+    def load_state_dict(self, state_dict):
+        """As torch.optim.Optimizer.load_state_dict; the flat buffers are rebuilt from the loaded moments and step
+        counts at the next step()."""
+        super().load_state_dict(state_dict)
+        self._flat = {}
 
     @torch.no_grad()
     def step(self, closure=None):
