@@ -9,9 +9,14 @@ reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step
 value = (N ranks x T timesteps per step) / step time: weak scaling, per-GPU batch fixed at 64
 (N = 8 is BASELINE config D: global batch 512).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--global-batch G]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+
+`--gpus N` (N > 1) without a torchrun environment starts the N ranks itself: the parent process - before it makes
+any GPU call - runs the torchrun line above as a child, relays rank 0's JSON line and exits with the child's code.
+`--global-batch G` is the strong-scaling mode (BASELINE configs[3]: G = 512 split contiguously, 512/N rows per GPU);
+`value` then counts 64-row batches: (G / 64) x T / step time, the same unit as the weak mode's N x T / step time.
 
 Rank 0 prints ONE JSON line.  Extra objects: "roofline" (dominant kernel, HIP events on the launch stream,
 inside the timed region) and, at N = 1, "cpu_baseline" (the oracle's op-for-op PyTorch-CPU port of the
@@ -47,11 +52,52 @@ def numpy_params(seed):
     return {k: (0.1 * rng.standard_normal(s)).astype(np.float32) for k, s in shapes.items()}
 
 
-def synthetic_batch(rank):
+def synthetic_batch(rank, rows=None, global_rows=None):
+    """Weak mode: `rows` rows from the rank's own seed.  Strong mode (global_rows): the rank's contiguous shard of ONE
+    global minibatch (seed 1234), so N ranks together compute exactly the single-GPU step on that minibatch."""
+    rows = B_PER_GPU if rows is None else rows
+    if global_rows is not None:
+        rng = np.random.Generator(np.random.PCG64(1234))
+        x = rng.standard_normal((global_rows, T, I)).astype(np.float32)
+        tgt = rng.integers(0, CLASSES, size=(global_rows,)).astype(np.int64)
+        return x[rank * rows:(rank + 1) * rows], tgt[rank * rows:(rank + 1) * rows]
     rng = np.random.Generator(np.random.PCG64(1234 + rank))
-    x = rng.standard_normal((B_PER_GPU, T, I)).astype(np.float32)
-    tgt = rng.integers(0, CLASSES, size=(B_PER_GPU,)).astype(np.int64)
+    x = rng.standard_normal((rows, T, I)).astype(np.float32)
+    tgt = rng.integers(0, CLASSES, size=(rows,)).astype(np.int64)
     return x, tgt
+
+
+def spawn_ranks(n, argv):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: one fresh process per GPU through
+    torchrun.  Nothing in this process has touched the GPU (torch.cuda.device_count() does not initialise it); the
+    children's stderr passes through, rank 0's JSON line is relayed, a failing child fails the run."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"[bench] --gpus {n} asked for, {have} visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:
+        if out.startswith("{") and '"metric"' in out:
+            line = out
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("[bench] the ranks finished without a result line", file=sys.stderr)
+        rc = 1
+    if rc == 0:
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return rc
 
 
 def usable_cores():
@@ -117,7 +163,13 @@ def main():
     ap.add_argument("--graph-collective", action="store_true", help="capture the gradient all-reduce inside the hipGraph too")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
     ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
+    ap.add_argument("--global-batch", type=int, default=0,
+                    help="strong scaling: this many rows in total, split contiguously over the ranks (configs[3]: 512)")
+    ap.add_argument("--transport", choices=("cabi", "torch"), default="cabi",
+                    help="gradient all-reduce through the C ABI (vmlmf_flat_allreduce_group, RCCL) or torch.distributed")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     # Only the JSON line may reach stdout: libraries print there too (RCCL's version banner at N > 1), so fd 1 is
     # pointed at stderr for the rest of the process and the result goes out through a private copy of stdout.
     sys.stdout.flush()
@@ -127,6 +179,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
+    strong = args.global_batch > 0
+    if strong and args.global_batch % world != 0:
+        raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
+    rows_gpu = args.global_batch // world if strong else B_PER_GPU      # batch rows of this rank
+    batches_per_step = (args.global_batch / B_PER_GPU) if strong else world   # 64-row batches one step processes
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -150,10 +209,10 @@ def main():
             getattr(net.rnn.rnncells[0], k).copy_(torch.tensor(v))
     net = net.to(dev)
     broadcast_parameters(net)
-    x_np, tgt_np = synthetic_batch(rank)
+    x_np, tgt_np = synthetic_batch(rank, rows_gpu, args.global_batch if strong else None)
     x = torch.tensor(x_np, device=dev)
     tgt = torch.tensor(tgt_np, device=dev)
-    reducer = FlatGradAllReduce(net.parameters(), op="avg")
+    reducer = FlatGradAllReduce(net.parameters(), op="avg", transport=args.transport if collective else "torch")
     reducer.always = args.force_collective
     lib = _lib.lib()
 
@@ -345,7 +404,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
-    value = world * T * args.steps / dt
+    value = batches_per_step * T * args.steps / dt
 
     if rank == 0:
         dom = max(rec, key=rec.get)                      # dominant kernel by measured time
@@ -358,24 +417,29 @@ def main():
             traffic_note = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x FETCH correction)"
         except (OSError, KeyError, ValueError):
             pass
-        rows = B_PER_GPU * T                             # sample-timesteps one launch processes
+        rows = rows_gpu * T                              # sample-timesteps one launch processes
         flops = rows * F_H * (1 if dom == "rec_fwd_kernel" else 1)   # 10 H ru per sample-step either way
         achieved = flops / (rec[dom] * 1e-6) / 1e12
         out = {
             "metric": "RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "RNN timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: UCI-HAR shape, Net(MyLSTM[MyVMLMFCell]) 1 layer, "
-                                   "B=64/GPU T=128 I=9 H=180 w_rank=16 u_rank=16, CE loss, fwd+bwd"
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("BASELINE configs[3]: UCI-HAR shape, global batch %d split contiguously over the ranks, "
+                                    % args.global_batch if strong else "BASELINE configs[1]: UCI-HAR shape, ")
+                                   + f"Net(MyLSTM[MyVMLMFCell]) 1 layer, B={rows_gpu}/GPU T=128 I=9 H=180 w_rank=16 "
+                                     "u_rank=16, CE loss, fwd+bwd"
                                    + (", in-place RCCL all-reduce (AVG) of the flat gradient buffers" if collective else ""),
-                       "global_batch": B_PER_GPU * world, "seq_len": T, "parallelism": f"dp{world}",
+                       "global_batch": rows_gpu * world, "batch_per_gpu": rows_gpu, "seq_len": T,
+                       "parallelism": f"dp{world}", "scaling": "strong" if strong else "weak",
+                       "value_counts": "64-row batches x T timesteps per second",
+                       "allreduce_transport": reducer.transport_used() if collective else None,
                        "launch": launch_mode,
                        "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
-            "step_flops": rows * F_STEP,
-            "step_tflops": round(rows * F_STEP / (ms_per_step * 1e-3) / 1e12, 3),
+            "step_flops": rows * F_STEP * world,
+            "step_tflops": round(rows * F_STEP * world / (ms_per_step * 1e-3) / 1e12, 3),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3),
                          "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
@@ -394,7 +458,7 @@ def main():
             "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
             "loss": round(float(loss.item()), 6),
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not strong and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 2
+#define VMLMF_ABI_VERSION 3
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -33,6 +33,7 @@ extern "C" {
 #define VMLMF_E_SHAPE (-2)       /* shape the reference itself rejects (I > H, I != H for LM, H % g) */
 #define VMLMF_E_UNSUPPORTED (-3) /* valid for the reference, not yet covered by the HIP kernels       */
 #define VMLMF_E_WORKSPACE (-4)   /* workspace / reserve smaller than vmlmf_query() asked for          */
+#define VMLMF_E_COMM (-5)        /* RCCL reported an error (text in vmlmf_last_error())                */
 
 /* One layer's problem description.  x is (T,B,I) when time_major else (B,T,I); y likewise with H. */
 typedef struct vmlmf_desc {
@@ -178,6 +179,29 @@ int vmlmf_adam_step(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp
                     float beta1, float beta2, float eps, float weight_decay, void *stream);
 int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_norm, float *norm, float *scratch,
                         void *stream);
+
+/*
+ * Data-parallel gradient exchange (no reference line: the reference has no distributed
+ * code).  Batch rows are independent through the whole forward and backward, so the ONLY exchange of a training step is the
+ * sum over ranks of the parameter gradients; the kernels above already write a layer's gradients into one flat
+ * allocation, which is all-reduced IN PLACE on `stream` (RCCL over xGMI; HAR Net: 121 KiB, latency-bound, hence one
+ * group call for all buffers of a step and no bucketing).
+ *   op: VMLMF_AVG reproduces a mean loss over the global batch (HAR cross-entropy, train.py:63), VMLMF_SUM the LM loss
+ *       (mean token NLL x local batch, lm_test.py:147-153).
+ *   comm: an RCCL communicator as void*: either one the caller owns (ncclComm_t) or one made here -
+ *       rank 0 calls vmlmf_comm_unique_id(), ships the 128 bytes to the other ranks by any means (the Python
+ *       binding uses torch.distributed's store), every rank calls vmlmf_comm_init() with its HIP device current.
+ * RCCL is bound at run time from the copy the process already holds (PyTorch-ROCm's) or the ROCm install;
+ * VMLMF_E_UNSUPPORTED when there is none, VMLMF_E_COMM for RCCL's own errors.
+ */
+#define VMLMF_SUM 0
+#define VMLMF_AVG 1
+#define VMLMF_COMM_ID_BYTES 128
+int vmlmf_comm_unique_id(void *id128);
+int vmlmf_comm_init(void **comm, int world, int rank, const void *id128);
+int vmlmf_comm_destroy(void *comm);
+int vmlmf_flat_allreduce(void *buf, size_t n, int op, void *comm, void *stream);
+int vmlmf_flat_allreduce_group(int nbuf, void *const *bufs, const size_t *counts, int op, void *comm, void *stream);
 
 /*
  * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel

@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in declared_functions():
         assert hasattr(handle, name), f"missing export {name}"
     lib = _lib.lib()
-    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 2
+    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 3
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
         "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",
@@ -103,3 +103,16 @@ def test_driver_build_entry_point_runs():
         sys.path.insert(0, root)
     entry = importlib.import_module("__graft_entry__")
     entry.build()
+
+
+def test_comm_entry_points_validate_arguments_without_a_gpu():
+    """The RCCL entry points are bound at run time: bad arguments are refused before RCCL is touched, and a missing RCCL
+    is VMLMF_E_UNSUPPORTED with a reason, never a crash (no collective is run here)."""
+    lib = _lib.lib()
+    rc = lib.vmlmf_flat_allreduce(None, 0, _lib.SUM, None, None)
+    assert rc in (_lib.E_BADARG, _lib.E_UNSUPPORTED) and lib.vmlmf_last_error()
+    rc = lib.vmlmf_flat_allreduce(None, 0, 7, ctypes.c_void_p(1), None)
+    assert rc in (_lib.E_BADARG, _lib.E_UNSUPPORTED)
+    h = ctypes.c_void_p()
+    rc = lib.vmlmf_comm_init(ctypes.byref(h), 2, 5, (ctypes.c_ubyte * 128)())
+    assert rc in (_lib.E_BADARG, _lib.E_UNSUPPORTED) and not h

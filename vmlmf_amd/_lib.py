@@ -17,8 +17,10 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 2
-E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE = -1, -2, -3, -4
+ABI_VERSION = 3
+E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
+SUM, AVG = 0, 1
+COMM_ID_BYTES = 128
 
 _fp = ctypes.POINTER(ctypes.c_float)
 
@@ -69,6 +71,11 @@ SYMBOLS = {
     "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
+    "vmlmf_comm_unique_id": (_i, [_vp]),
+    "vmlmf_comm_init": (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
+    "vmlmf_comm_destroy": (_i, [_vp]),
+    "vmlmf_flat_allreduce": (_i, [_vp, _sz, _i, _vp, _vp]),
+    "vmlmf_flat_allreduce_group": (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _i, _vp, _vp]),
     "vmlmf_profile_enable": (_i, [_i]),
     "vmlmf_profile_read": (_i, [_fp, ctypes.POINTER(ctypes.c_int32), _i]),
     "vmlmf_kernel_name": (ctypes.c_char_p, [_i]),

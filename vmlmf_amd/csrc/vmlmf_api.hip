@@ -265,6 +265,9 @@ int hip_fail(int rc, const char* what) {
 
 }  // namespace
 
+// error text for the other translation units of the C ABI (vmlmf_comm.cpp)
+int vmlmf_set_error(int code, const std::string& msg) { return fail(code, msg); }
+
 extern "C" {
 
 int vmlmf_abi_version(void) { return VMLMF_ABI_VERSION; }

@@ -13,17 +13,61 @@ Reduction op must reproduce single-process semantics:
 """
 from __future__ import annotations
 
+import ctypes
+
 import torch
 import torch.distributed as dist
+
+from . import _lib
+
+
+class CabiComm:
+    """An RCCL communicator made and used through the C ABI (include/vmlmf_hip.h: vmlmf_comm_*, vmlmf_flat_allreduce_group):
+    what a non-PyTorch host would bind.  torch.distributed only carries the 128-byte id from rank 0 to the others.
+    The calling process must have its HIP device current (torch.cuda.set_device)."""
+
+    def __init__(self, device, group=None):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        if rank == 0:
+            _lib.check(self.lib.vmlmf_comm_unique_id(ident))
+        t = torch.tensor(list(ident), dtype=torch.uint8, device=self.device)
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
+        self.handle = ctypes.c_void_p()
+        with _lib.on_device(self.device):
+            _lib.check(self.lib.vmlmf_comm_init(ctypes.byref(self.handle), world, rank, ident))
+
+    def all_reduce(self, tensors, op):
+        """In place, every tensor of the list under one RCCL group call, on torch's current stream."""
+        n = len(tensors)
+        bufs = (ctypes.c_void_p * n)(*[t.data_ptr() for t in tensors])
+        counts = (ctypes.c_size_t * n)(*[t.numel() for t in tensors])
+        with _lib.on_device(self.device):
+            _lib.check(self.lib.vmlmf_flat_allreduce_group(n, bufs, counts, _lib.AVG if op == "avg" else _lib.SUM,
+                                                            self.handle, _lib.raw_stream(self.device)))
+
+    def close(self):
+        if self.handle:
+            self.lib.vmlmf_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
 
 
 class FlatGradAllReduce:
     """Owns a flat buffer covering the gradients of `params` (only those that can receive one)."""
 
-    def __init__(self, params, op="avg", group=None):
-        assert op in ("avg", "sum")
+    def __init__(self, params, op="avg", group=None, transport="torch"):
+        """transport: "torch" = torch.distributed collectives (RCCL under backend "nccl", gloo in the CPU tests);
+        "cabi" = the package's own RCCL entry points behind the C ABI (HIP tensors, backend "nccl" only; when the
+        communicator cannot be made on EVERY rank, all ranks fall back to "torch" together)."""
+        assert op in ("avg", "sum") and transport in ("torch", "cabi")
         self.op = op
         self.group = group
+        self.transport = transport
+        self._comm = None           # CabiComm, made at the first reduce()
+        self._comm_tried = False
         self.params = [p for p in params if p.requires_grad]
         self.always = False   # run the collectives even in a group of one (bench self-test of the RCCL path)
         self.flat = None   # staging buffer for gradients that do not already share a flat allocation
@@ -54,9 +98,35 @@ class FlatGradAllReduce:
                 out.append((None, gs))
         return out
 
+    def transport_used(self):
+        return "cabi:vmlmf_flat_allreduce_group(rccl)" if self._comm is not None else f"torch.distributed:{dist.get_backend(self.group) if dist.is_initialized() else 'none'}"
+
+    def _cabi(self, device, backend):
+        """The C-ABI communicator, or None (wrong backend / CPU tensors / creation failed somewhere)."""
+        if self.transport != "cabi" or backend != "nccl" or device.type != "cuda":
+            return None
+        if not self._comm_tried:
+            self._comm_tried = True
+            comm, ok = None, 1
+            try:
+                comm = CabiComm(device, self.group)
+            except Exception:       # noqa: BLE001 - any failure means "use torch.distributed", decided collectively
+                ok = 0
+            flag = torch.tensor([ok], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+            if int(flag.item()) == 1:
+                self._comm = comm
+            elif comm is not None:
+                comm.close()
+        return self._comm
+
     def _all_reduce(self, tensors, op, backend):
         """One collective launch for all `tensors`: on RCCL several all-reduces issued under the coalescing manager
         become one group call (the exchange is latency-bound: two launches would cost twice one)."""
+        comm = self._cabi(tensors[0].device, backend)
+        if comm is not None:
+            comm.all_reduce(tensors, "avg" if op == dist.ReduceOp.AVG else "sum")
+            return
         if len(tensors) > 1 and backend == "nccl" and hasattr(dist, "_coalescing_manager"):
             try:
                 with dist._coalescing_manager(group=self.group, device=tensors[0].device, async_ops=False):
