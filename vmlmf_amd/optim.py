@@ -85,7 +85,12 @@ class Adam(torch.optim.Optimizer):
         """As torch.optim.Optimizer.load_state_dict; the flat buffers are rebuilt from the loaded moments and step
         counts at the next step()."""
         super().load_state_dict(state_dict)
+        # converted NOW, not at the next step(): torch hands the checkpoint's own tensors through when device and dtype
+        # already match, so a lazily read state would follow whatever the checkpoint's owner does to them meanwhile
         self._flat = {}
+        for gi, group in enumerate(self.param_groups):
+            if any(self.state.get(p) for p in group["params"]):
+                self._group_state(gi, group)
 
     @torch.no_grad()
     def step(self, closure=None):
