@@ -84,6 +84,17 @@ const char *vmlmf_build_info(void);
 /* Text of the last error raised on this host thread (never NULL). */
 const char *vmlmf_last_error(void);
 
+/*
+ * Kernel-selection switches (A/B measurements and tests; process-wide, take effect at the next call, and a descriptor
+ * must see the same setting in vmlmf_query, forward and backward).  Keys:
+ *   "rb"            -1 automatic (default), 0 never, 1 always where instantiated: the row-block recurrent kernels
+ *                   (16 batch rows per workgroup, both products of a step on v_mfma_f32_16x16x4_f32) instead of the
+ *                   one-row-per-CU VALU kernels / the step-wise path
+ *   "rb_min_batch"  batch size from which automatic mode picks them for layers the VALU kernels also cover (default 1024)
+ *   "rb_cluster"    workgroups a 16-row block's hidden units are split over for layers beyond one CU (0 = automatic)
+ */
+int vmlmf_tune(const char *key, int value);
+
 /* Validate `d` and report buffer sizes + launch geometry.  Host only, no GPU call. */
 int vmlmf_query(const vmlmf_desc *d, vmlmf_sizes *out);
 

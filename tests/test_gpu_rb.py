@@ -1,0 +1,150 @@
+"""GPU parity of the row-block MFMA recurrent kernels (vmlmf_rb.hip): forced on through vmlmf_tune("rb", 1) and compared
+with the fp64 literal oracle and the reference's golden vectors at the same tolerances as the VALU kernels
+(tests/hip_util.py); the cluster form (a 16-row block's units split over S workgroups) runs on the H = 650 PTB shapes."""
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_oracle as O
+from conftest import load_golden
+from hip_util import run_hip, run_literal, compare_all, assert_out, assert_grad, ranks_of
+from vmlmf_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def force_row_block_kernels():
+    _lib.tune("rb", 1)
+    yield
+    _lib.tune("rb", -1)
+    _lib.tune("rb_cluster", 0)
+
+
+def uses_rb(variant, B, T, I, H, rw, ru, tm=False):
+    g = 2 if variant in (O.V2, O.V4, O.V6) else 1
+    s = _lib.query(_lib.make_desc(variant, B, T, I, H, rw, ru, g=g, time_major=tm))
+    return s.rows_per_wg == 16, s.workgroups
+
+
+RB_CASES = [
+    # variant, B, T, I, H, rw, ru, time_major, with_state
+    (O.V1, 3, 5, 4, 16, 2, [3], False, False),        # one tile, rank 3 -> 2 contraction steps
+    (O.V1, 7, 9, 16, 64, 8, [8], False, True),        # 4 tiles, one per wave
+    (O.V1, 5, 4, 9, 65, 5, [11], True, True),         # ragged last tile, time-major
+    (O.V1, 17, 6, 9, 180, 16, [16], False, True),     # UCI layer, two row blocks (the second one ragged)
+    (O.V1, 2, 3, 30, 200, 16, [24], False, False),    # rank 24: 6 contraction steps, 2 M-tiles
+    (O.V1, 3, 4, 12, 130, 32, [32], False, True),     # rank 32
+    (O.V1, 33, 3, 77, 256, 24, [24], False, False),   # OPP layer (config C), 4 tiles per wave
+    (O.V1, 300, 3, 6, 40, 4, [4], False, False),      # 19 row blocks
+    (O.V2, 4, 5, 6, 20, 3, [2, 5], False, False),     # group cell, ranks pad to 8 + 8
+    (O.V2, 3, 4, 10, 136, 8, [16, 8], False, True),   # ranks 16 + 8 -> 24: no instantiation, falls back (still must be right)
+    (O.V2, 20, 6, 9, 180, 16, [16, 16], False, True), # UCI group cell
+    (O.V3, 6, 5, 24, 24, 4, [6], True, True),
+    (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),      # flat layout, batch != 40
+    (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
+    (O.V5, 5, 6, 9, 70, 5, [7], False, True),         # cells without vm
+    (O.V6, 4, 5, 10, 100, 8, [8, 8], False, True),
+    # clusters: layers beyond the register-resident kernels
+    (O.V1, 18, 3, 20, 600, 8, [8], False, True),      # 640 thread slots: 38 tiles over 4 workgroups
+    (O.V3, 5, 4, 650, 650, 32, [32], True, True),     # PTB plain layer
+    (O.V4, 21, 3, 650, 650, 32, [32, 32], True, True),  # PTB group layer (config E), two row blocks
+]
+EXPECT_RB = {i for i in range(len(RB_CASES))} - {9}
+
+
+@pytest.mark.parametrize("idx", range(len(RB_CASES)), ids=lambda i: "v%d_B%d_T%d_I%d_H%d_r%d_%s" % (
+    RB_CASES[i][:6] + ("x".join(map(str, RB_CASES[i][6])),)))
+def test_row_block_kernels_vs_oracle(idx):
+    variant, B, T, I, H, rw, ru, tm, with_state = RB_CASES[idx]
+    on, wgs = uses_rb(variant, B, T, I, H, rw, ru, tm)
+    assert on == (idx in EXPECT_RB), f"row-block selection changed: {on} ({wgs} workgroups)"
+    rng = np.random.Generator(np.random.PCG64(2000 + B + 7 * T + 13 * H))
+    P = O.make_params(variant, I, H, rw, ru if variant in (O.V2, O.V4, O.V6) else ru[0], seed=H + rw)
+    shp = (T, B, I) if tm else (B, T, I)
+    x = rng.standard_normal(shp).astype(np.float32)
+    h0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    c0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    dcT = rng.standard_normal((B, H)).astype(np.float32)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)
+    compare_all(got, ref, "rb")
+
+
+def test_config_a_full_size_vs_reference_golden_on_row_blocks():
+    d = load_golden("cfgA_v1_uci")
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    assert uses_rb(O.V1, B, T, I, H, rw, [ru])[0]
+    P = O.make_params(O.V1, I, H, rw, ru, seed=int(d["seeds"][0]))
+    x, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][2]))).standard_normal((B, T, H)).astype(np.float32)
+    got = run_hip(O.V1, P, x, None, None, dy, None, None)
+    assert_out(got["y"][:, ::16], d["y_s"], "y")
+    assert_out(got["hT"], d["hT"], "hT")
+    assert_grad(got["dx"], d["dx"], "dx")
+    for k, v in d["G"].items():
+        assert_grad(got["G"][k], v, "G." + k)
+
+
+def _regen_lm_inputs(seed, B, T, H, xscale):
+    r = np.random.Generator(np.random.PCG64(seed))
+    x = (xscale * r.standard_normal((T, B, H))).astype(np.float32)
+    h0 = (0.3 * r.standard_normal((B, H))).astype(np.float32)
+    c0 = (0.3 * r.standard_normal((B, H))).astype(np.float32)
+    dy = r.standard_normal((T, B, H)).astype(np.float32)
+    dhT = r.standard_normal((B, H)).astype(np.float32)
+    dcT = r.standard_normal((B, H)).astype(np.float32)
+    return x, h0, c0, dy, dhT, dcT
+
+
+@pytest.mark.parametrize("name", ["cfgE_v4_b40", "cfgE_v3_b64"])
+def test_config_e_shape_vs_reference_golden_on_clusters(name):
+    """BASELINE config E shape (H = 650, ranks 32 / [32,32], T = 35) against the imported reference's vectors, on the
+    clustered row-block kernels instead of the step-wise path."""
+    d = load_golden(name)
+    meta = [int(v) for v in d["meta"]]
+    variant, B, T, _, H, rw = meta[:6]
+    ru = meta[6:]
+    on, wgs = uses_rb(variant, B, T, H, H, rw, ru, True)
+    assert on and wgs > (B + 15) // 16, "expected a cluster of workgroups per row block"
+    seed, (scale, xscale) = int(d["seed"][0]), (float(d["scale"][0]), float(d["scale"][1]))
+    P = O.make_params(variant, H, H, rw, ru if variant == O.V4 else ru[0], seed=seed + 1, scale=scale)
+    x, h0, c0, dy, dhT, dcT = _regen_lm_inputs(seed, B, T, H, xscale)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=True)
+    assert_out(got["y"][::4, ::4], d["y_s"], "y")
+    assert_out(got["hT"], d["hT"], "hT")
+    assert_out(got["cT"], d["cT"], "cT")
+    assert_grad(got["dx"][::4, ::4], d["dx_s"], "dx")
+    assert_grad(got["dh0"], d["dh0"], "dh0")
+    assert_grad(got["dc0"], d["dc0"], "dc0")
+    for k, v in d["G"].items():
+        assert_grad(got["G"][k], v, "G." + k)
+
+
+def test_config_e_at_batch_256_vs_oracle():
+    """configs[4] at its own batch size (the reference's group layer only runs B = 40): the HIP path against the fp64
+    restatement with v4_scratch_rows = 256, T shortened to keep the CPU side in seconds."""
+    variant, B, T, H, rw, ru = O.V4, 256, 6, 650, 32, [32, 32]
+    assert uses_rb(variant, B, T, H, H, rw, ru, True)[0]
+    P = O.make_params(variant, H, H, rw, ru, seed=11, scale=0.05)
+    x, h0, c0, dy, dhT, dcT = _regen_lm_inputs(5, B, T, H, 0.05)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT, time_major=True)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=True)
+    compare_all(got, ref, "E.B256")
+
+
+def test_row_block_and_valu_kernels_agree_at_large_batch():
+    """B = 1024, T = 16 at the UCI layer: both kernel families against each other (they sum in different orders)."""
+    P = O.make_params(O.V1, 9, 180, 16, 16, seed=3)
+    rng = np.random.Generator(np.random.PCG64(8))
+    x = rng.standard_normal((1024, 16, 9)).astype(np.float32)
+    dy = rng.standard_normal((1024, 16, 180)).astype(np.float32)
+    a = run_hip(O.V1, P, x, None, None, dy)
+    _lib.tune("rb", 0)
+    b = run_hip(O.V1, P, x, None, None, dy)
+    assert_out(a["y"], b["y"], "y")
+    assert_grad(a["dx"], b["dx"], "dx", rel=2e-5)
+    for k in a["G"]:
+        assert_grad(a["G"][k], b["G"][k], "G." + k, rel=5e-5)

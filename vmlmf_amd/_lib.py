@@ -57,6 +57,7 @@ SYMBOLS = {
     "vmlmf_abi_version": (_i, []),
     "vmlmf_build_info": (ctypes.c_char_p, []),
     "vmlmf_last_error": (ctypes.c_char_p, []),
+    "vmlmf_tune": (_i, [ctypes.c_char_p, _i]),
     "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),
     "vmlmf_seq_forward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
@@ -114,6 +115,13 @@ def lib():
             raise RuntimeError("libvmlmf_hip.so ABI version mismatch: rebuild")
         _lib = handle
     return _lib
+
+
+def tune(key, value):
+    """Kernel-selection switches of the library (include/vmlmf_hip.h: vmlmf_tune).  Cached descriptors are dropped."""
+    check(lib().vmlmf_tune(key.encode(), int(value)))
+    from . import functional
+    functional._DESC_CACHE.clear()
 
 
 def check(rc):

@@ -78,8 +78,14 @@ const int g_wchunks = env_pos("VMLMF_WCHUNKS", 64);
 const int g_rc = env_pos("VMLMF_RC", 0);   // dqx_dx rows per workgroup (A/B); 0 = derived from the row count
 const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
 
+// Row-block MFMA kernels (vmlmf_rb.hip): -1 = automatic (large batches, and layers beyond the register-resident VALU kernels),
+// 0 = never, 1 = wherever an instantiation exists.  VMLMF_RB in the environment, or vmlmf_tune("rb", v) at run time.
+int g_rb_mode = []() { const char* e = getenv("VMLMF_RB"); return e ? atoi(e) : -1; }();
+int g_rb_minB = env_pos("VMLMF_RB_MINB", 1024);   // automatic mode: batch rows from which the row-block kernels take over
+int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
+
 // ---- geometry ----
-int make_geo(const vmlmf_desc* d, VGeo* out) {
+int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
   if (d == nullptr) return fail(VMLMF_E_BADARG, "null descriptor");
   VGeo g;
   memset(&g, 0, sizeof(g));
@@ -168,6 +174,23 @@ int make_geo(const vmlmf_desc* d, VGeo* out) {
   g.nchunk = (TB + rc2 - 1) / rc2;
   g.foldx = (!g.generic && g.I <= g.KX) ? 1 : 0;
   g.NA = 5 * g.KX + 5 * g.KH + 12;
+  // row-block MFMA recurrence?
+  {
+    RbGeo q;
+    memset(&q, 0, sizeof(q));
+    g.rb = 0;
+    if (g_rb_mode != 0 && g.I <= g.H) {
+      if (g.generic) {          // factors beyond one CU's registers: a cluster of S workgroups per 16-row block
+        const int cand[] = {g_rb_S, 2, 4, 8};
+        for (int i = (g_rb_S > 0 ? 0 : 1); i < 4 && g.rb == 0; ++i)
+          if (cand[i] > 1 && rb_geometry(g, cand[i], &q)) g.rb = cand[i];
+      } else if ((g_rb_mode == 1 || g.B >= g_rb_minB) && rb_geometry(g, 1, &q)) {
+        g.rb = 1;
+      }
+    }
+    if (g.rb != 0) g.foldx = 0;   // the x-fold belongs to the x-projection wave's layers; here qx always exists
+    if (rbout != nullptr) *rbout = q;
+  }
   {
     const long long GK = (long long)g.G * g.KH;
     const long long nb1 = (vg_nb1(g) + 31) / 32 * 32, nb2 = (GK + 31) / 32 * 32, nb3 = (g.KX + 31) / 32 * 32;
@@ -183,12 +206,12 @@ struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
   long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
   // forward workspace  : PACK (inference only) | gx
-  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_total;
+  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_total;
 };
 
-Layout make_layout(const VGeo& g, const VPack& P) {
+Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   Layout L;
   const long long TB = (long long)g.T * g.B;
   const long long TS = (long long)g.T * g.Bp * g.NT;   // (t, padded row, thread slot)
@@ -204,13 +227,15 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   L.f_gx = o, o += align64(TS * 4);
   L.f_trash = o, o += 64;
   {
-    const long long gen = g.generic ? 1 : 0, BN = (long long)g.B * g.NT;
+    const long long gen = (g.generic && !g.rb) ? 1 : 0, BN = (long long)g.B * g.NT;
     L.f_Qtmp = o, o += align64(gen * g.B * g.G * g.KH);
     L.f_P = o, o += align64(gen * BN * 4);
     L.f_ccar = o, o += align64(gen * BN);
     L.f_zeros = o, o += align64(gen * (long long)g.B * g.H);
     L.f_part = o, o += align64(gen * (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64));
   }
+  L.f_xq = o, o += align64(g.rb ? q.xq_floats : 0);
+  L.f_flag = o, o += align64(g.rb ? q.flag_words : 0);
   L.f_total = o;
   o = 0;
   L.b_dpre = o, o += align64(TS * 4);
@@ -220,12 +245,15 @@ Layout make_layout(const VGeo& g, const VPack& P) {
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT + (g.I > g.H ? (long long)g.I * g.KX : 0));   // + dU_x by input when I > H
   L.b_trash = o, o += 64;
   {
-    const long long gen = g.generic ? 1 : 0, BN = (long long)g.B * g.NT;
+    const long long gen = (g.generic && !g.rb) ? 1 : 0, BN = (long long)g.B * g.NT;
     L.b_dHrec = o, o += align64(gen * (long long)g.B * g.H);
     L.b_ehterm = o, o += align64(gen * BN);
     L.b_dcar = o, o += align64(gen * BN);
-    L.b_part = o, o += align64(gen * (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64));
+    // (the dqx product of large layers keeps its split-K scratch under the row-block kernels too)
+    L.b_part = o, o += align64((g.generic ? 1 : 0) * (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64));
   }
+  L.b_xq = o, o += align64(g.rb ? q.xq_floats : 0);
+  L.b_flag = o, o += align64(g.rb ? q.flag_words : 0);
   L.b_total = o;
   return L;
 }
@@ -279,16 +307,17 @@ const char* vmlmf_last_error(void) { return g_err.c_str(); }
 int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
   if (out == nullptr) return fail(VMLMF_E_BADARG, "null sizes");
   VGeo g;
-  const int rc = make_geo(d, &g);
+  RbGeo q;
+  const int rc = make_geo(d, &g, &q);
   if (rc != 0) return rc;
-  const VPack P = vg_pack_layout(g);
-  const Layout L = make_layout(g, P);
+  const VPack P = vg_pack_layout(g, q.total);
+  const Layout L = make_layout(g, P, q);
   const long long ws = L.f_total > L.b_total ? L.f_total : L.b_total;
   out->workspace_bytes = (size_t)ws * sizeof(float);
   out->reserve_bytes = (size_t)L.r_total * sizeof(float);
-  out->rows_per_wg = g.R;
-  out->threads_per_wg = g.NT;
-  out->workgroups = g.nwg;
+  out->rows_per_wg = g.rb ? 16 : g.R;
+  out->threads_per_wg = g.rb ? 256 : g.NT;
+  out->workgroups = g.rb ? q.nrb * q.S : g.nwg;
   out->kx = g.KX;
   out->kh = g.KH;
   return 0;
@@ -298,13 +327,14 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
                       const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                       size_t workspace_bytes, void* stream) {
   VGeo g;
-  int rc = make_geo(d, &g);
+  RbGeo q;
+  int rc = make_geo(d, &g, &q);
   if (rc != 0) return rc;
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "null x / y / workspace");
   if (g.training && reserve == nullptr) return fail(VMLMF_E_BADARG, "training forward needs a reserve buffer");
-  const VPack P = vg_pack_layout(g);
-  const Layout L = make_layout(g, P);
+  const VPack P = vg_pack_layout(g, q.total);
+  const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.f_total * sizeof(float))
     return fail(VMLMF_E_WORKSPACE, "workspace smaller than vmlmf_query() reported");
   hipStream_t s = (hipStream_t)stream;
@@ -323,6 +353,20 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
     Scope sc(1, s);
     if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : nullptr, s), "xproj")) != 0)
       return rc;
+  }
+  if (g.rb) {
+    {
+      Scope sc(0, s);
+      if ((rc = hip_fail(launch_rb_pack(g, q, rp, pack + P.RB, s), "rb_pack")) != 0) return rc;
+    }
+    RbIo io;
+    memset(&io, 0, sizeof(io));
+    io.gx = gx, io.EH = pack + P.EH, io.h0 = h0, io.c0 = c0, io.img = pack + P.RB, io.y = y, io.hT = hT, io.cT = cT;
+    io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
+    io.Qs = g.training ? rs + L.r_Qs : nullptr;
+    io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag);
+    Scope sc(2, s);
+    return hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd");
   }
   if (g.generic) {
     GenericBuf w;
@@ -362,21 +406,47 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
                        const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
                        const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream) {
   VGeo g;
-  int rc = make_geo(d, &g);
+  RbGeo q;
+  int rc = make_geo(d, &g, &q);
   if (rc != 0) return rc;
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || reserve == nullptr || workspace == nullptr || gr == nullptr)
     return fail(VMLMF_E_BADARG, "null x / y / reserve / workspace / grads");
   if ((rc = check_pointers(g, gr, "grads")) != 0) return rc;
-  const VPack P = vg_pack_layout(g);
-  const Layout L = make_layout(g, P);
+  const VPack P = vg_pack_layout(g, q.total);
+  const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.b_total * sizeof(float))
     return fail(VMLMF_E_WORKSPACE, "workspace smaller than vmlmf_query() reported");
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const float* rs = (const float*)reserve;
   const float* pack = rs + L.r_pack;
-  if (g.generic) {
+  if (g.rb) {
+    RbIo io;
+    memset(&io, 0, sizeof(io));
+    io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
+    io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
+    io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag);
+    {
+      Scope sc(3, s);
+      if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
+    }
+    if (g.generic) {   // large layer: dqx as one skinny product over all rows, then dx
+      GenericBuf w;
+      memset(&w, 0, sizeof(w));
+      w.dpre = ws + L.b_dpre, w.VxT = pack + P.VXTT, w.dqx = ws + L.b_dqx, w.dx = dx, w.UXP = pack + P.UXP, w.EXT = pack + P.EXT;
+      w.part = ws + L.b_part, w.part_cap = (long long)VG_GEMM_SPLIT * ((g.B + 63) / 64 * 64) * ((g.G * g.KH + 63) / 64 * 64);
+      w.ticket = reinterpret_cast<int*>(const_cast<float*>(pack + P.TKT)), w.ticket_cap = VG_GEMM_TICKETS;
+      Scope sc(4, s);
+      if ((rc = hip_fail(generic_dqx_dx(g, w, s), "dqx_dx")) != 0) return rc;
+    } else {
+      WgxArgs wx;
+      wx.dpre = ws + L.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
+      wx.dx = dx, wx.dqx = ws + L.b_dqx;
+      Scope sc(4, s);
+      if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
+    }
+  } else if (g.generic) {
     GenericBuf w;
     memset(&w, 0, sizeof(w));
     w.EH = pack + P.EH, w.gates = const_cast<float*>(rs + L.r_gates), w.cs = const_cast<float*>(rs + L.r_cs);
@@ -426,6 +496,16 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
     Scope sc(7, s);
     if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, s), "finish")) != 0) return rc;
   }
+  return 0;
+}
+
+int vmlmf_tune(const char* key, int value) {
+  if (key == nullptr) return fail(VMLMF_E_BADARG, "tune: null key");
+  const std::string k(key);
+  if (k == "rb") g_rb_mode = value;
+  else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
+  else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
+  else return fail(VMLMF_E_BADARG, "tune: unknown key " + k);
   return 0;
 }
 

@@ -850,6 +850,12 @@ int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s) {
   hipLaunchKernelGGL(carry_kernel, egrid, eblock, 0, s, g, 1, (const float*)nullptr, (const float*)nullptr, w.dHrec,
                      w.ehterm, w.dcar, w.dh0, w.dc0);
   if ((rc = (int)hipGetLastError()) != 0) return rc;
+  return generic_dqx_dx(g, w, s);
+}
+
+int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s) {
+  const int B = g.B, NT = g.NT, T = g.T;
+  int rc;
   // dqx over all rows, then dx
   if ((rc = gemm(w.dpre, (long long)NT * 4, w.VxT, g.KX, w.dqx, g.KX, T * B, g.KX, NT * 4, w.part, w.part_cap, w.ticket,
                  w.ticket_cap, s)) != 0)

@@ -35,6 +35,17 @@ struct VGeo {
                 //    yields G = dpre^T x; finish_kernel derives dV_x = G U_x and dU_x = G^T V_x from it, so neither dqx
                 //    nor the x^T dqx product is needed unless the layer's input wants a gradient
   int generic;  // 1: step-wise path (vmlmf_generic.hip): factors do not fit the register-resident kernels
+  int rb;       // > 0: the recurrence runs on the row-block MFMA kernels (vmlmf_rb.hip), 16 batch rows per workgroup;
+                //      the value is S, the workgroups a row block's hidden units are split over (1 = no cluster)
+};
+
+// Geometry of the row-block kernels (vmlmf_rb.hip).  Valid 16-unit tiles of a group are dealt to "wave slots"
+// (4 compute waves x S workgroups, split evenly over the groups), MT consecutive tiles each.
+struct RbGeo {
+  int S, MT, TPGV, WSG, NMT, nmu, nrb;
+  int mlist[2][5];              // per group: the M-tiles of the padded rank space its units couple to
+  long long UA, VA, VB, UB, total;   // float offsets of the A-operand images inside the RB region of PACK
+  long long xq_floats, flag_words;   // cluster exchange scratch (S > 1)
 };
 
 // float offsets inside the PACK region (parameter images, produced by pack_kernel)
@@ -42,7 +53,8 @@ struct VPack {
   long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
   long long UD, VD, UDT, VDT, VXTT;   // dense group factors + V_x^T, step-wise path only
   long long TKT;                      // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
-  long long WXD, total;               // dense x-side matrix W_x[m][k][slot] of the x-projection wave (I <= 16 only)
+  long long WXD;                      // dense x-side matrix W_x[m][k][slot] of the x-projection wave (I <= 16 only)
+  long long RB, total;                // A-operand images of the row-block kernels (RbGeo offsets are relative to RB)
 };
 
 #ifdef __HIPCC__
@@ -58,13 +70,15 @@ VG_HD int vg_pad8(int v) { return (v + 7) / 8 * 8; }
 
 // Shapes whose x-projection rides inside rec_fwd_kernel (its wave NW): one row per workgroup, at most three
 // compute waves, an input narrow enough that the dense x-side matrix fits that wave's registers.
-VG_HD bool vg_xwave_ok(const VGeo& g) { return !g.generic && !g.flat && g.R == 1 && g.NT <= 192 && g.I <= 16; }
+VG_HD bool vg_xwave_ok(const VGeo& g) { return !g.generic && !g.rb && !g.flat && g.R == 1 && g.NT <= 192 && g.I <= 16; }
 
-VG_HD VPack vg_pack_layout(const VGeo& g) {
+// rb_floats: RbGeo::total of the layer (0 without the row-block kernels)
+VG_HD VPack vg_pack_layout(const VGeo& g, long long rb_floats = 0) {
   VPack p;
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
   const int pk = g.generic ? 0 : 1;   // register images exist only for the persistent kernels
+  const bool dense = g.generic && !g.rb;   // dense group factors: step-wise recurrence only
   p.VE = take(pk * 4LL * g.KH * g.NT);
   p.UR = take(pk * 1LL * g.KQ * g.NT);
   p.VR = take(pk * 4LL * g.KQ * g.NT);
@@ -78,13 +92,14 @@ VG_HD VPack vg_pack_layout(const VGeo& g) {
   p.EXT = take(4LL * g.H);
   p.BBT = take(4LL * g.H);
   const long long GK = (long long)g.G * g.KH, N4 = 4LL * g.NT;
-  p.UD = take(g.generic ? g.H * GK : 0);
-  p.VD = take(g.generic ? GK * N4 : 0);
-  p.UDT = take(g.generic ? GK * g.H : 0);
-  p.VDT = take(g.generic ? N4 * GK : 0);
+  p.UD = take(dense ? g.H * GK : 0);
+  p.VD = take(dense ? GK * N4 : 0);
+  p.UDT = take(dense ? GK * g.H : 0);
+  p.VDT = take(dense ? N4 * GK : 0);
   p.VXTT = take(g.generic ? N4 * g.KX : 0);
   p.TKT = take(g.generic ? VG_GEMM_TICKETS : 0);
   p.WXD = take(vg_xwave_ok(g) ? 4LL * g.I * g.NT : 0);
+  p.RB = take(g.rb ? rb_floats : 0);
   p.total = o;
   return p;
 }

@@ -45,6 +45,20 @@ struct GenericBuf {
 };
 int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s);
 int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s);
+// the non-recurrent tail of generic_backward on its own: dqx = dpre V_x over all rows, then dx (row-block kernels on large layers)
+int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s);
+
+// row-block MFMA recurrent kernels (vmlmf_rb.hip)
+struct RbIo {
+  const float *gx, *EH, *h0, *c0, *img, *dy, *dhT, *dcT;
+  float *y, *hT, *cT, *gates, *cs, *Qs, *dpre, *dQs, *dh0, *dc0;
+  float* xq;        // cluster exchange tiles (S > 1)
+  unsigned* flag;   // cluster epoch words + error word
+};
+bool rb_geometry(const VGeo& g, int S, RbGeo* out);   // false: no instantiation covers the layer with S splits
+int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s);
+int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
+int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 
 // every launcher returns hipGetLastError() of its launch, or VMLMF_E_UNSUPPORTED (-3) when no
 // instantiation covers the geometry
