@@ -90,7 +90,9 @@ const char *vmlmf_last_error(void);
  *   "rb"            -1 automatic (default), 0 never, 1 always where instantiated: the row-block recurrent kernels
  *                   (16 batch rows per workgroup, both products of a step on v_mfma_f32_16x16x4_f32) instead of the
  *                   one-row-per-CU VALU kernels / the step-wise path
- *   "rb_min_batch"  batch size from which automatic mode picks them for layers the VALU kernels also cover (default 1024)
+ *   "rb_min_batch"  batch size from which automatic mode picks them for layers the VALU kernels also cover (default 0 =
+ *                   never: measured, the VALU kernels win there at every batch size; automatic mode uses the row-block
+ *                   kernels only for layers beyond one CU's registers, e.g. H = 650)
  *   "rb_cluster"    workgroups a 16-row block's hidden units are split over for layers beyond one CU (0 = automatic)
  */
 int vmlmf_tune(const char *key, int value);

@@ -49,7 +49,8 @@ def test_query_headline_geometry():
     assert (s.kx, s.kh) == (8, 16)
     # BASELINE config E (PTB group layer): too large for the register-resident kernels -> step-wise path
     s = _lib.query(_lib.make_desc(_lib.V4_LM_GROUP, 256, 35, 650, 650, 32, [32, 32], g=2, time_major=True))
-    assert (s.kx, s.kh, s.threads_per_wg) == (32, 64, 768)
+    # ... now on the clustered row-block MFMA kernels: 16 row blocks x 16 workgroups, 4 compute waves each
+    assert (s.kx, s.kh, s.threads_per_wg, s.rows_per_wg, s.workgroups) == (32, 64, 256, 16, 256)
     # the cells without vm share the geometry of their vm counterparts
     s = _lib.query(_lib.make_desc(_lib.V5_LMF_CELL, 64, 128, 9, 180, 16, [16]))
     assert (s.rows_per_wg, s.threads_per_wg, s.workgroups, s.kx, s.kh) == (1, 192, 64, 16, 16)

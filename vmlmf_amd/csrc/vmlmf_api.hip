@@ -81,7 +81,10 @@ const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 
 // Row-block MFMA kernels (vmlmf_rb.hip): -1 = automatic (large batches, and layers beyond the register-resident VALU kernels),
 // 0 = never, 1 = wherever an instantiation exists.  VMLMF_RB in the environment, or vmlmf_tune("rb", v) at run time.
 int g_rb_mode = []() { const char* e = getenv("VMLMF_RB"); return e ? atoi(e) : -1; }();
-int g_rb_minB = env_pos("VMLMF_RB_MINB", 1024);   // automatic mode: batch rows from which the row-block kernels take over
+// automatic mode: batch rows from which the row-block kernels take over on layers the VALU kernels cover as well.  0 = never:
+// measured on MI355X the one-row-per-CU kernels win at every batch size up to 2048 - sixteen rows' tape
+// traffic through ONE CU's memory pipe (~25 GB/s) costs more than the MFMAs save
+int g_rb_minB = env_pos("VMLMF_RB_MINB", 0);
 int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
 
 // ---- geometry ----
@@ -181,10 +184,13 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
     g.rb = 0;
     if (g_rb_mode != 0 && g.I <= g.H) {
       if (g.generic) {          // factors beyond one CU's registers: a cluster of S workgroups per 16-row block
-        const int cand[] = {g_rb_S, 2, 4, 8};
-        for (int i = (g_rb_S > 0 ? 0 : 1); i < 4 && g.rb == 0; ++i)
+        // measured at H = 650, B = 256: group layer (ranks 32+32) 3.02 / 2.26 / 2.14 ms with clusters of 4 / 8 / 16, plain layer
+        // (rank 32) 1.85 / 1.65 / 1.72 ms: one 16-unit tile per wave for the group layer, two for the plain one
+        const int cand2[] = {g_rb_S, 16, 8, 4, 2}, cand1[] = {g_rb_S, 8, 16, 4, 2};
+        const int* cand = g.G == 2 ? cand2 : cand1;
+        for (int i = (g_rb_S > 0 ? 0 : 1); i < 5 && g.rb == 0; ++i)
           if (cand[i] > 1 && rb_geometry(g, cand[i], &q)) g.rb = cand[i];
-      } else if ((g_rb_mode == 1 || g.B >= g_rb_minB) && rb_geometry(g, 1, &q)) {
+      } else if ((g_rb_mode == 1 || (g_rb_minB > 0 && g.B >= g_rb_minB)) && rb_geometry(g, 1, &q)) {
         g.rb = 1;
       }
     }

@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, Pack
   const int lane = threadIdx.x & 63;
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
-  const int total = (int)L.total, stride = ncopy * 256;
+  const int total = (int)L.RB, stride = ncopy * 256;   // the RB region behind it belongs to rb_pack_kernel
   for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
     float v = 0.f;
     if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
@@ -209,8 +209,8 @@ int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipSt
   D.nEH = 4 * g.NT;
   D.nEXI = (int)(L.UXP - L.EXI) > 0 ? 4 * g.NT : 0;
   D.nEXT = 4 * g.H;
-  D.nWXD = (L.total - L.WXD) > 0 ? 4 * g.I * g.NT : 0;
-  int ncopy = (int)((L.total + 255) / 256);
+  D.nWXD = (L.RB - L.WXD) > 0 ? 4 * g.I * g.NT : 0;
+  int ncopy = (int)((L.RB + 255) / 256);
   if (ncopy > 2048) ncopy = 2048;
   const int ndot = (D.nEH + D.nEXI + D.nEXT + D.nWXD + 7) / 8;
   hipLaunchKernelGGL(pack_kernel, dim3(ncopy + ndot), dim3(256), 0, s, g, p, L, D, ncopy, pack);

@@ -62,50 +62,45 @@ __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int
 //   UB[tv][m][r]      expand (bwd):   unit c of the tile             x  row 16 m + 4 r + kq of the padded rank space
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out) {
+  // 32-bit index arithmetic throughout (64-bit divisions by run-time values cost hundreds of cycles each: the first
+  // version of this kernel took 290 us at the PTB shape, 0.5 M elements)
   const int NTV = g.G * q.TPGV, KS = g.KH / 4, NP = g.NP, NMT = q.NMT;
-  const long long nUA = (long long)NTV * NMT * 4 * 64, nVA = (long long)NTV * 4 * KS * 64, nVB = (long long)NTV * 4 * NP * 4 * 64;
-  const long long total = 2 * nUA + nVA + nVB;
-  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-    const int lane = (int)(e & 63), c = lane & 15, kq = lane >> 4;
-    long long le = e;
-    float v;
-    int grp, sb, n0;
-    if (le < nUA) {                       // UA
-      long long j = le >> 6;
-      const int r = (int)(j & 3);
-      j >>= 2;
-      const int m = (int)(j % NMT), tv = (int)(j / NMT);
-      rb_tile(g, q, tv, grp, sb, n0);
-      v = rb_udz(g, p, 16 * m + rb_pi(c), sb + 4 * kq + r);
-      out[q.UA + le] = v;
-    } else if ((le -= nUA) < nVA) {       // VA
-      long long j = le >> 6;
-      const int s4 = (int)(j % KS);
-      j /= KS;
-      const int k = (int)(j & 3), tv = (int)(j >> 2);
-      rb_tile(g, q, tv, grp, sb, n0);
-      v = rb_vc(g, p, sb + c, k, 4 * s4 + kq);
-      out[q.VA + le] = v;
-    } else if ((le -= nVA) < nVB) {       // VB
-      long long j = le >> 6;
-      const int r = (int)(j & 3);
-      j >>= 2;
-      const int mv = (int)(j % NP);
-      j /= NP;
-      const int k = (int)(j & 3), tv = (int)(j >> 2);
-      rb_tile(g, q, tv, grp, sb, n0);
-      v = rb_vc(g, p, sb + 4 * kq + r, k, 16 * mv + rb_pi(c));
-      out[q.VB + le] = v;
-    } else {                              // UB
-      le -= nVB;
-      long long j = le >> 6;
-      const int r = (int)(j & 3);
-      j >>= 2;
-      const int m = (int)(j % NMT), tv = (int)(j / NMT);
-      rb_tile(g, q, tv, grp, sb, n0);
-      v = rb_udz(g, p, 16 * m + 4 * r + kq, sb + c);
-      out[q.UB + le] = v;
-    }
+  const int nUA = NTV * NMT * 4 * 64, nVA = NTV * 4 * KS * 64, nVB = NTV * 4 * NP * 4 * 64;
+  const int total = 2 * nUA + nVA + nVB;
+  const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (e >= total) return;
+  const int lane = e & 63, c = lane & 15, kq = lane >> 4;
+  int le = e;
+  int grp, sb, n0;
+  if (le < nUA) {                       // UA
+    int j = le >> 6;
+    const int r = j & 3;
+    j >>= 2;
+    const int tv = j / NMT, m = j - tv * NMT;
+    rb_tile(g, q, tv, grp, sb, n0);
+    out[q.UA + le] = rb_udz(g, p, 16 * m + rb_pi(c), sb + 4 * kq + r);
+  } else if ((le -= nUA) < nVA) {       // VA
+    int j = le >> 6;
+    const int j2 = j / KS, s4 = j - j2 * KS;
+    const int k = j2 & 3, tv = j2 >> 2;
+    rb_tile(g, q, tv, grp, sb, n0);
+    out[q.VA + le] = rb_vc(g, p, sb + c, k, 4 * s4 + kq);
+  } else if ((le -= nVA) < nVB) {       // VB
+    int j = le >> 6;
+    const int r = j & 3;
+    j >>= 2;
+    const int j2 = j / NP, mv = j - j2 * NP;
+    const int k = j2 & 3, tv = j2 >> 2;
+    rb_tile(g, q, tv, grp, sb, n0);
+    out[q.VB + le] = rb_vc(g, p, sb + 4 * kq + r, k, 16 * mv + rb_pi(c));
+  } else {                              // UB
+    le -= nVB;
+    int j = le >> 6;
+    const int r = j & 3;
+    j >>= 2;
+    const int tv = j / NMT, m = j - tv * NMT;
+    rb_tile(g, q, tv, grp, sb, n0);
+    out[q.UB + le] = rb_udz(g, p, 16 * m + 4 * r + kq, sb + c);
   }
 }
 
@@ -135,14 +130,15 @@ int rb_dispatch_g2e(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hip
 static bool rb_has(int ks, int mt, int nmu, bool flat, int G) {
   if (mt < 1 || mt > 4) return false;
   if (G == 1) return !flat && (ks == 2 || ks == 4 || ks == 6 || ks == 8) && nmu == (ks + 3) / 4;
-  if (ks == 16) return flat && mt == 3 && nmu == 4;
+  if (ks == 16) return flat && mt <= 3 && nmu == 4;
   return (ks == 4 || ks == 8) && nmu == 2;
 }
 
 bool rb_geometry(const VGeo& g, int S, RbGeo* out) {
   RbGeo q;
   memset(&q, 0, sizeof(q));
-  if (g.KH % 4 != 0 || g.G > 2 || S < 1 || (RB_WAVES * S) % g.G != 0) return false;
+  if (g.KH % 4 != 0 || g.G > 2 || (RB_WAVES * S) % g.G != 0) return false;
+  if (S != 1 && S != 2 && S != 4 && S != 8 && S != 16) return false;   // the cluster sum reads members in chunks of 2 / 4 / 8
   q.S = S;
   q.TPGV = (g.Hg + 15) / 16;
   q.WSG = RB_WAVES * S / g.G;
@@ -186,8 +182,8 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out) {
 }
 
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s) {
-  long long blocks = (q.total + 255) / 256;
-  if (blocks > 2048) blocks = 2048;
+  if (q.total >= (1LL << 30)) return -3;
+  const long long blocks = (q.total + 255) / 256;
   hipLaunchKernelGGL(rb_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, q, p, img);
   return (int)hipGetLastError();
 }
