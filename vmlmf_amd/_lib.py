@@ -9,7 +9,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvmlmf_hip.so")
+# VMLMF_LIB: an instrumented build of the same library (tools/microbench), never a different implementation
+LIB_PATH = os.environ.get("VMLMF_LIB") or os.path.join(_HERE, "lib", "libvmlmf_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_G = 2

@@ -184,10 +184,9 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
     g.rb = 0;
     if (g_rb_mode != 0 && g.I <= g.H) {
       if (g.generic) {          // factors beyond one CU's registers: a cluster of S workgroups per 16-row block
-        // measured at H = 650, B = 256: group layer (ranks 32+32) 3.02 / 2.26 / 2.14 ms with clusters of 4 / 8 / 16, plain layer
-        // (rank 32) 1.85 / 1.65 / 1.72 ms: one 16-unit tile per wave for the group layer, two for the plain one
-        const int cand2[] = {g_rb_S, 16, 8, 4, 2}, cand1[] = {g_rb_S, 8, 16, 4, 2};
-        const int* cand = g.G == 2 ? cand2 : cand1;
+        // measured at H = 650, B = 256 (members of a cluster on one XCD): group layer (ranks 32+32) 2.98 / 2.21 / 2.09 ms with
+        // clusters of 4 / 8 / 16, plain layer (rank 32) 1.84 / 1.64 / 1.60 ms: the largest cluster first
+        const int cand[] = {g_rb_S, 16, 8, 4, 2};
         for (int i = (g_rb_S > 0 ? 0 : 1); i < 5 && g.rb == 0; ++i)
           if (cand[i] > 1 && rb_geometry(g, cand[i], &q)) g.rb = cand[i];
       } else if ((g_rb_mode == 1 || (g_rb_minB > 0 && g.B >= g_rb_minB)) && rb_geometry(g, 1, &q)) {
