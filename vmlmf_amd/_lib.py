@@ -100,6 +100,12 @@ def build(force=False, jobs=8):
     return LIB_PATH
 
 
+def build_torch_binding():
+    """g++ csrc/torch_binding.cpp -> vmlmf_amd/lib/libvmlmf_torch.so (TORCH_LIBRARY "vmlmf": C++ autograd functions over the C ABI)."""
+    subprocess.run(["make", "-C", CSRC, "torch"], check=True, stdout=subprocess.DEVNULL)
+    return os.path.join(_HERE, "lib", "libvmlmf_torch.so")
+
+
 def lib():
     """The loaded shared library.  Raises if it has not been built: there is no fallback path."""
     global _lib

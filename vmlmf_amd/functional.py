@@ -22,6 +22,30 @@ def _ptr(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+# ---- C++ binding (csrc/torch_binding.cpp: TORCH_LIBRARY "vmlmf" with C++ autograd functions over the same C ABI) --------
+# Loaded when vmlmf_amd/lib/libvmlmf_torch.so has been built (`make -C vmlmf_amd/csrc torch`, done by
+# __graft_entry__.build()).  Same kernels, same results; it only takes the per-call bookkeeping out of Python (eager
+# steps of the unchanged reference loop are host-bound at the UCI-HAR shape).  VMLMF_PYBIND=ctypes keeps the classes below.
+_OPS = None
+
+
+def torch_ops():
+    """torch.ops.vmlmf, or None when the C++ binding is not built / disabled."""
+    global _OPS
+    if _OPS is None:
+        _OPS = False
+        import os
+        path = os.path.join(os.path.dirname(_lib.LIB_PATH), "libvmlmf_torch.so")
+        if os.environ.get("VMLMF_PYBIND", "") != "ctypes" and os.path.exists(path) and "VMLMF_LIB" not in os.environ:
+            _lib.lib()                       # libvmlmf_hip.so first (the binding links against it)
+            try:
+                torch.ops.load_library(path)
+                _OPS = torch.ops.vmlmf
+            except OSError:
+                _OPS = False
+    return _OPS or None
+
+
 def _params_struct(tensors, g, variant=_lib.V1_CELL):
     p = _lib.Params()
     if variant == _lib.V5_LMF_CELL:
@@ -176,6 +200,9 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     Returns (y, hT, cT).
     """
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
+    ops = torch_ops()
+    if ops is not None:
+        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major))
     cfg = (variant, g, int(w_rank), ur, bool(time_major))
     return VmlmfSeqFn.apply(cfg, x, h0, c0, *params)
 
@@ -230,6 +257,9 @@ def head_linear(h, weight, bias):
     library op otherwise (it is not part of the VMLMF path and has no CPU restriction of its own)."""
     if (h.is_cuda and h.dim() == 2 and h.dtype == torch.float32 and weight.dtype == torch.float32
             and weight.shape[0] <= _lib.HEAD_MAX_CLASSES):
+        ops = torch_ops()
+        if ops is not None:
+            return ops.head_linear(h, weight, bias)
         return HeadLinearFn.apply(h, weight, bias)
     return torch.nn.functional.linear(h, weight, bias)
 
@@ -304,6 +334,9 @@ def cross_entropy(input, target, ignore_index=-100):
     kernels; anything else goes to the library op."""
     if (input.is_cuda and input.dim() == 2 and input.dtype == torch.float32 and target.dtype == torch.int64
             and target.dim() == 1 and input.numel() <= 65536):
+        ops = torch_ops()
+        if ops is not None:
+            return ops.cross_entropy(input, target, int(ignore_index), unit_gradient(input.device))
         return CrossEntropyFn.apply(input, target, ignore_index)
     return torch.nn.functional.cross_entropy(input, target, ignore_index=ignore_index)
 
