@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 3
+#define VMLMF_ABI_VERSION 4
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -44,7 +44,15 @@ typedef struct vmlmf_desc {
   int32_t u_ranks[VMLMF_MAX_G]; /* rank per shift s (V1/V3/V5: only [0])                        */
   int32_t time_major;        /* 1: (T,B,*)  LM layers;  0: (B,T,*)  MyLSTM batch_first          */
   int32_t training;          /* 1: forward fills `reserve` for backward; 0: inference            */
+  int32_t dtype;             /* VMLMF_DT_F32 (0): the reference's arithmetic.  VMLMF_DT_BF16 (1), ABI 4: both products of a
+                              * step on bf16 MFMA (weights and the activations entering an MFMA rounded to bf16, fp32
+                              * accumulate), bf16 tapes for the x-side pre-activations, the gates and dpre; c, every sum
+                              * and all weight gradients fp32; x, y, states, parameters and gradients stay fp32 tensors.
+                              * Implemented by the row-block kernels for one-group layers (V1, V3, V5) within one CU's
+                              * registers; VMLMF_E_UNSUPPORTED elsewhere.  Tolerance: tests/test_gpu_bf16.py              */
 } vmlmf_desc;
+#define VMLMF_DT_F32 0
+#define VMLMF_DT_BF16 1
 
 /* Parameters in the REFERENCE's own layouts (so a state_dict's tensors are passed as they are):
  *   V1: u_x (I,rw) v_x (4H,rw) u_h[0] (H,ru) v_h[0] (4H,ru) b_x b_h (4H) dia_x (1,I) dia_h (1,H)     vmlmf.py:56-69

@@ -1,0 +1,154 @@
+"""GPU: the bf16-MFMA variant (vmlmf_desc.dtype = VMLMF_DT_BF16; BASELINE configs[2] "bf16 MFMA"): both products of a step
+on v_mfma_f32_16x16x16_bf16 with fp32 accumulation, bf16 tapes (x-side pre-activations, activated gates, dpre), fp32 cell
+state, sums and weight gradients.  All tensors at the boundary stay float32.
+
+Stated tolerance, derived from the fp64 oracle (not guessed): the variant rounds the recurrent factors U_h, V_h to bf16 once
+and the activations that enter an MFMA or a bf16 tape at every step.  The oracle itself, run in fp64 on parameters whose
+U_h / V_h are rounded to bf16, differs from the exact oracle by delta(q) for every output q - the part of the error that
+weight rounding alone explains.  Activation rounding is of the same relative size (2^-9 per value) and enters at T steps,
+so the HIP path must stay within  BF16_K * delta(q) + BF16_FLOOR * max|q|  of the exact oracle, with BF16_K = 6 and
+BF16_FLOOR = 2^-7: two bf16 ulps of the quantity's scale, one for each bf16 tape a gradient passes through (the x-side
+pre-activations forward, dpre backward) - quantities such as dx and the x-side weight gradients do not depend on U_h / V_h
+rounding at first order, so delta alone would bound them by almost nothing.  Measured: 0.5-0.8 of this bound on the cases
+below, 2e-3 (outputs) to 6e-3 (gradients) of scale at the full config C.  The fp32 path's tolerance (tests/hip_util.py) is
+untouched.
+"""
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_oracle as O
+from conftest import load_golden
+from hip_util import ORDER, ranks_of, run_literal
+from vmlmf_amd import _lib, vmlmf_sequence
+
+pytestmark = pytest.mark.gpu
+BF16_K, BF16_FLOOR = 6.0, 2.0 ** -7
+
+
+def bf16_round(a):
+    """numpy float32 -> nearest-even bf16, returned as float32."""
+    u = np.asarray(a, np.float32).view(np.uint32)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint32) << 16
+    return r.view(np.float32).reshape(np.shape(a))
+
+
+def run_hip_dtype(variant, P, x, h0, c0, dy, dhT, dcT, tm, dtype):
+    names = ORDER[variant]
+    params = [torch.tensor(np.asarray(P[k]), dtype=torch.float32, device="cuda").requires_grad_(True) for k in names]
+    xt = torch.tensor(x, device="cuda").requires_grad_(True)
+    h0t = None if h0 is None else torch.tensor(h0, device="cuda").requires_grad_(True)
+    c0t = None if c0 is None else torch.tensor(c0, device="cuda").requires_grad_(True)
+    rw, ru, g = ranks_of(variant, P)
+    y, hT, cT = vmlmf_sequence(variant, xt, h0t, c0t, params, rw, ru, g=g, time_major=tm, dtype=dtype)
+    loss = (y * torch.tensor(dy, device="cuda")).sum() + (hT * torch.tensor(dhT, device="cuda")).sum() + \
+        (cT * torch.tensor(dcT, device="cuda")).sum()
+    loss.backward()
+    out = {"y": y.detach().cpu().numpy(), "hT": hT.detach().cpu().numpy(), "cT": cT.detach().cpu().numpy(),
+           "dx": xt.grad.cpu().numpy(), "G": {k: p.grad.cpu().numpy() for k, p in zip(names, params)}}
+    if h0t is not None:
+        out["dh0"], out["dc0"] = h0t.grad.cpu().numpy(), c0t.grad.cpu().numpy()
+    return out
+
+
+def flat_items(d):
+    for k, v in d.items():
+        if k == "G":
+            for kk, vv in v.items():
+                yield "G." + kk, vv
+        else:
+            yield k, v
+
+
+def check_bf16(variant, P, x, h0, c0, dy, dhT, dcT, tm, report=None):
+    got = run_hip_dtype(variant, P, x, h0, c0, dy, dhT, dcT, tm, "bf16")
+    exact = dict(flat_items(run_literal(variant, P, x, h0, c0, dy, dhT, dcT, time_major=tm)))
+    Pq = dict(P)
+    for k in P:
+        if k.startswith(("u_h", "v_h", "w_h")) or k in ("u", "u1", "u2", "u3", "u4"):
+            Pq[k] = bf16_round(P[k])
+    rounded = dict(flat_items(run_literal(variant, Pq, x, h0, c0, dy, dhT, dcT, time_major=tm)))
+    problems = []
+    for k, v in flat_items(got):
+        ref = np.asarray(exact[k], np.float64)
+        delta = np.abs(np.asarray(rounded[k], np.float64) - ref).max()
+        scale = np.abs(ref).max()
+        err = np.abs(np.asarray(v, np.float64) - ref).max()
+        tol = BF16_K * delta + BF16_FLOOR * scale
+        if report is not None:
+            report.append((k, err, delta, scale, err / max(tol, 1e-30)))
+        assert np.all(np.isfinite(v)), k
+        if err > tol:
+            problems.append(f"{k}: err {err:.3e} > tol {tol:.3e} (delta {delta:.3e}, scale {scale:.3e})")
+    assert not problems, "\n".join(problems)
+    return got
+
+
+CASES = [
+    (O.V1, 17, 6, 9, 180, 16, [16], False, True),     # UCI layer
+    (O.V1, 33, 5, 77, 256, 24, [24], False, False),   # OPP layer (config C, layer 1)
+    (O.V1, 5, 4, 9, 65, 5, [11], True, True),         # ragged tile, odd ranks
+    (O.V3, 6, 5, 24, 24, 4, [6], True, True),         # LM layer
+    (O.V5, 5, 6, 9, 70, 5, [7], False, True),         # low-rank baseline cell
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"v{c[0]}_B{c[1]}_T{c[2]}_I{c[3]}_H{c[4]}_r{c[5]}_{c[6][0]}")
+def test_bf16_variant_within_the_derived_tolerance(case):
+    variant, B, T, I, H, rw, ru, tm, with_state = case
+    s = _lib.query(_lib.make_desc(variant, B, T, I, H, rw, ru, time_major=tm, dtype="bf16"))
+    assert s.rows_per_wg == 16
+    rng = np.random.Generator(np.random.PCG64(3000 + B + 7 * T + 13 * H))
+    P = O.make_params(variant, I, H, rw, ru[0], seed=H + rw)
+    shp = (T, B, I) if tm else (B, T, I)
+    x = rng.standard_normal(shp).astype(np.float32)
+    h0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    c0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if with_state else None
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    dcT = rng.standard_normal((B, H)).astype(np.float32)
+    report = []
+    check_bf16(variant, P, x, h0, c0, dy, dhT, dcT, tm, report)
+    worst = max(report, key=lambda r: r[4])
+    print(f"\nbf16 {case}: worst {worst[0]} err {worst[1]:.3e} = {worst[4]:.2f} x tolerance (delta {worst[2]:.3e}, scale {worst[3]:.3e})")
+
+
+def test_config_c_two_layers_bf16_vs_reference_golden():
+    """BASELINE configs[2]: OPP shape, 2 layers x 256, rank 24, B 128, T 24, through MyLSTM with the bf16 variant, against the
+    imported reference's fp32 vectors (tests/golden/cfgC_v1_opp2.npz).  Two stacked layers compound the per-layer error, so
+    the golden check uses whole-configuration bounds: y and hT within 2^-6 of their scale, every gradient within 3 % of its
+    largest entry (the per-layer, oracle-derived bound is the parametrised test above)."""
+    from vmlmf_amd import MyLSTM, MyVMLMFCell, set_compute_dtype
+    d = load_golden("cfgC_v1_opp2")
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    rnn = MyLSTM(I, hidden_layer_sizes=[H, H], batch_first=True, w_rank=rw, u_ranks=[ru], cell=MyVMLMFCell)
+    for cell, (ins, seed) in zip(rnn.rnncells, ((I, int(d["seeds"][0])), (H, int(d["seeds"][1])))):
+        with torch.no_grad():
+            for k, v in O.make_params(O.V1, ins, H, rw, ru, seed=seed).items():
+                getattr(cell, k).copy_(torch.tensor(v))
+    rnn = rnn.cuda()
+    assert set_compute_dtype(rnn, "bf16") == 2
+    x_np, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][2]), classes=18)
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][3]))).standard_normal((B, T, H)).astype(np.float32)
+    x = torch.tensor(x_np, device="cuda", requires_grad=True)
+    y, hcat = rnn(x)
+    (y * torch.tensor(dy, device="cuda")).sum().backward()
+
+    def close(a, ref, frac, what):
+        err, scale = np.abs(np.asarray(a, np.float64) - ref).max(), np.abs(ref).max()
+        print(f"config C bf16 {what}: err {err:.3e} = {err / scale:.2e} of scale")
+        assert np.all(np.isfinite(a)) and err <= frac * scale, (what, err, scale)
+
+    close(y.detach().cpu().numpy()[:, ::6], d["y_s"], 2.0 ** -6, "y")
+    close(hcat.detach().cpu().numpy(), d["hT"], 2.0 ** -6, "hT")
+    close(x.grad.cpu().numpy()[::4], d["dx_s"], 0.03, "dx")
+    for li, G in ((0, d["G0"]), (1, d["G1"])):
+        for k, v in G.items():
+            close(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, 0.03, f"layer{li}.{k}")
+
+
+def test_bf16_is_refused_where_it_is_not_implemented():
+    with pytest.raises(_lib.VmlmfError):
+        _lib.query(_lib.make_desc(_lib.V2_GROUP_CELL, 8, 4, 9, 64, 8, [8, 8], g=2, dtype="bf16"))
+    with pytest.raises(_lib.VmlmfError):
+        _lib.query(_lib.make_desc(_lib.V3_LM, 8, 4, 650, 650, 32, [32], time_major=True, dtype="bf16"))

@@ -18,7 +18,9 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 3
+ABI_VERSION = 4
+DT_F32, DT_BF16 = 0, 1
+DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
 SUM, AVG = 0, 1
 COMM_ID_BYTES = 128
@@ -30,7 +32,7 @@ class Desc(ctypes.Structure):
     _fields_ = [("variant", ctypes.c_int32), ("B", ctypes.c_int32), ("T", ctypes.c_int32),
                 ("I", ctypes.c_int32), ("H", ctypes.c_int32), ("w_rank", ctypes.c_int32),
                 ("g", ctypes.c_int32), ("u_ranks", ctypes.c_int32 * MAX_G),
-                ("time_major", ctypes.c_int32), ("training", ctypes.c_int32)]
+                ("time_major", ctypes.c_int32), ("training", ctypes.c_int32), ("dtype", ctypes.c_int32)]
 
 
 class Params(ctypes.Structure):
@@ -136,7 +138,7 @@ def check(rc):
         raise VmlmfError(rc, lib().vmlmf_last_error().decode())
 
 
-def make_desc(variant, B, T, I, H, w_rank, u_ranks, g=1, time_major=False, training=True):
+def make_desc(variant, B, T, I, H, w_rank, u_ranks, g=1, time_major=False, training=True, dtype=0):
     d = Desc()
     d.variant, d.B, d.T, d.I, d.H, d.w_rank = variant, B, T, I, H, w_rank
     d.g = g
@@ -145,6 +147,7 @@ def make_desc(variant, B, T, I, H, w_rank, u_ranks, g=1, time_major=False, train
         d.u_ranks[i] = int(ur[i]) if i < len(ur) else 0
     d.time_major = 1 if time_major else 0
     d.training = 1 if training else 0
+    d.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     return d
 
 

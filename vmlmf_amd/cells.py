@@ -61,7 +61,8 @@ class MyVMLMFCell(nn.Module):
         return (self.dia_x, self.dia_h, self.u_x, self.v_x, self.b_x, self.b_h, self.u_h, self.v_h)
 
     def kernel_cfg(self):
-        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1)
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
+                    dtype=getattr(self, "compute_dtype", "f32"))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         """Whole-sequence evaluation: (y, hT, cT)."""
@@ -115,7 +116,8 @@ class MyVMLMFCellg2(nn.Module):
         return tuple(out)
 
     def kernel_cfg(self):
-        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g)
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g,
+                    dtype=getattr(self, "compute_dtype", "f32"))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
@@ -214,7 +216,8 @@ class MyLSTMCell(nn.Module):
                 self.bias_i, self.bias_f, self.bias_o, self.bias_c)
 
     def kernel_cfg(self):
-        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1)
+        return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
+                    dtype=getattr(self, "compute_dtype", "f32"))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         """Whole-sequence evaluation on the HIP kernels (low-rank mode only): (y, hT, cT)."""

@@ -81,12 +81,12 @@ int64_t hidden_size(int variant, const std::vector<Tensor>& params) {
 }
 
 vmlmf_desc make_desc(int variant, int64_t B, int64_t T, int64_t I, int64_t H, int64_t w_rank, const std::vector<int64_t>& ur,
-                     int64_t g, bool time_major, bool training) {
+                     int64_t g, bool time_major, bool training, int64_t dtype) {
   vmlmf_desc d;
   memset(&d, 0, sizeof(d));
   d.variant = variant, d.B = (int)B, d.T = (int)T, d.I = (int)I, d.H = (int)H, d.w_rank = (int)w_rank, d.g = (int)g;
   for (size_t i = 0; i < VMLMF_MAX_G; ++i) d.u_ranks[i] = i < ur.size() ? (int)ur[i] : 0;
-  d.time_major = time_major ? 1 : 0, d.training = training ? 1 : 0;
+  d.time_major = time_major ? 1 : 0, d.training = training ? 1 : 0, d.dtype = (int)dtype;
   return d;
 }
 
@@ -96,7 +96,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
   // of autograd's argument walker and the parameters would get no gradient)
   static variable_list forward(AutogradContext* ctx, Tensor x, c10::optional<Tensor> h0o, c10::optional<Tensor> c0o,
                                at::TensorList params_in, int64_t variant, int64_t g, int64_t w_rank,
-                               std::vector<int64_t> u_ranks, bool time_major, bool training) {
+                               std::vector<int64_t> u_ranks, bool time_major, bool training, int64_t dtype) {
     ctx->set_materialize_grads(false);
     require_hip_f32(x, "input");
     x = x.contiguous();
@@ -108,7 +108,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor h0 = h0o.has_value() ? h0o->contiguous() : Tensor(), c0 = c0o.has_value() ? c0o->contiguous() : Tensor();
     const int64_t B = time_major ? x.size(1) : x.size(0), T = time_major ? x.size(0) : x.size(1), I = x.size(2);
     const int64_t H = hidden_size((int)variant, params);
-    const vmlmf_desc d = make_desc((int)variant, B, T, I, H, w_rank, u_ranks, g, time_major, training);
+    const vmlmf_desc d = make_desc((int)variant, B, T, I, H, w_rank, u_ranks, g, time_major, training, dtype);
     vmlmf_sizes sz;
     check(vmlmf_query(&d, &sz));
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
@@ -130,7 +130,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       ctx->saved_data["np"] = (int64_t)params.size();
       ctx->saved_data["h0"] = h0.defined();
       ctx->saved_data["c0"] = c0.defined();
-      ctx->saved_data["cfg"] = std::vector<int64_t>{variant, g, w_rank, time_major ? 1 : 0, B, T, I, H};
+      ctx->saved_data["cfg"] = std::vector<int64_t>{variant, g, w_rank, time_major ? 1 : 0, B, T, I, H, dtype};
       ctx->saved_data["ur"] = u_ranks;
     }
     return {y, hT, cT};
@@ -151,7 +151,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
     Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
     Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
-    const vmlmf_desc d = make_desc((int)variant, B, T, I, H, w_rank, ur, g, time_major, true);
+    const vmlmf_desc d = make_desc((int)variant, B, T, I, H, w_rank, ur, g, time_major, true, cfg[8]);
     vmlmf_sizes sz;
     check(vmlmf_query(&d, &sz));
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
@@ -178,20 +178,20 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
                              stream_of(x)));
     variable_list out = {dx, dh0, dc0};
     for (auto& gt : grads) out.push_back(gt);
-    for (int i = 0; i < 6; ++i) out.push_back(Tensor());   // the integer configuration
+    for (int i = 0; i < 7; ++i) out.push_back(Tensor());   // the integer configuration
     return out;
   }
 };
 
 std::tuple<Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::optional<Tensor>& h0, const c10::optional<Tensor>& c0,
                                             at::TensorList params, int64_t variant, int64_t g, int64_t w_rank,
-                                            at::IntArrayRef u_ranks, bool time_major) {
+                                            at::IntArrayRef u_ranks, bool time_major, int64_t dtype) {
   // grad mode is off inside Function::forward: whether the tape is needed is decided here (False under torch.no_grad():
   // inference kernels, no reserve buffer)
   bool training = x.requires_grad() || (h0.has_value() && h0->requires_grad()) || (c0.has_value() && c0->requires_grad());
   for (const auto& p : params) training = training || p.requires_grad();
   training = training && at::GradMode::is_enabled();
-  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training);
+  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype);
   return {out[0], out[1], out[2]};
 }
 
@@ -286,7 +286,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 }  // namespace
 
 TORCH_LIBRARY(vmlmf, m) {
-  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major) -> (Tensor, Tensor, Tensor)");
+  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype) -> (Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }

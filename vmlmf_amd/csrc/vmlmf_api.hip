@@ -98,6 +98,8 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
   g.I = d->I;
   g.H = d->H;
   g.rw = d->w_rank;
+  if (d->dtype != VMLMF_DT_F32 && d->dtype != VMLMF_DT_BF16) return fail(VMLMF_E_BADARG, "dtype must be VMLMF_DT_F32 or VMLMF_DT_BF16");
+  g.bf = d->dtype == VMLMF_DT_BF16 ? 1 : 0;
   if (g.variant < 1 || g.variant > 6) return fail(VMLMF_E_BADARG, "variant must be 1..6");
   if (g.B < 1 || g.T < 1 || g.I < 1 || g.H < 1 || g.rw < 1)
     return fail(VMLMF_E_BADARG, "B, T, I, H, w_rank must be positive");
@@ -182,7 +184,11 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
     RbGeo q;
     memset(&q, 0, sizeof(q));
     g.rb = 0;
-    if (g_rb_mode != 0 && g.I <= g.H) {
+    if (g.bf) {   // the bf16 variant IS the row-block family
+      if (!g.generic && g.I <= g.H && rb_geometry(g, 1, &q)) g.rb = 1;
+      else return fail(VMLMF_E_UNSUPPORTED, "dtype bf16: implemented by the row-block MFMA kernels for one-group layers (V1, V3, V5) "
+                                            "with padded rank <= 32 and <= 512 thread slots");
+    } else if (g_rb_mode != 0 && g.I <= g.H) {
       if (g.generic) {          // factors beyond one CU's registers: a cluster of S workgroups per 16-row block
         // measured at H = 650, B = 256 (members of a cluster on one XCD): group layer (ranks 32+32) 2.98 / 2.21 / 2.09 ms with
         // clusters of 4 / 8 / 16, plain layer (rank 32) 1.84 / 1.64 / 1.60 ms: the largest cluster first

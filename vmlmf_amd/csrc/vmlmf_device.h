@@ -164,6 +164,17 @@ __device__ __forceinline__ float4 f4add(float4 a, float4 b) {
   return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
 }
 
+// Element i of a tape that holds fp32 (bf = 0) or bf16 (bf = 1) values, with ONE unconditional load either way: a load
+// under a condition is not issued before the one in front of it has returned (hipcc puts a vmcnt(0) there)
+__device__ __forceinline__ float tape_elem(const float* base, unsigned i, int bf) {
+  const unsigned w = reinterpret_cast<const unsigned*>(base)[bf ? (i >> 1) : i];
+  return __uint_as_float(bf ? ((i & 1u) ? (w & 0xffff0000u) : (w << 16)) : w);
+}
+__device__ __forceinline__ unsigned short vg_f2bf(float f) {   // round to nearest even
+  const unsigned u = __float_as_uint(f);
+  return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // canonical element <- reference layouts (oracle/vmlmf_oracle.py: canonicalize)
 // ---------------------------------------------------------------------------------------------------

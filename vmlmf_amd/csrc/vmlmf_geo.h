@@ -35,6 +35,7 @@ struct VGeo {
                 //    yields G = dpre^T x; finish_kernel derives dV_x = G U_x and dU_x = G^T V_x from it, so neither dqx
                 //    nor the x^T dqx product is needed unless the layer's input wants a gradient
   int generic;  // 1: step-wise path (vmlmf_generic.hip): factors do not fit the register-resident kernels
+  int bf;       // 1: desc.dtype = bf16: bf16 MFMA in the recurrence, bf16 tapes (x-side pre-activations, gates, dpre)
   int rb;       // > 0: the recurrence runs on the row-block MFMA kernels (vmlmf_rb.hip), 16 batch rows per workgroup;
                 //      the value is S, the workgroups a row block's hidden units are split over (1 = no cluster)
 };

@@ -328,7 +328,14 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
         }
         out = make_float4(pre[0], pre[1], pre[2], pre[3]);
       }
-      st4(gx + ((size_t)rp * NT + slot) * 4, out);
+      if (g.bf) {   // bf16 tape: 8 bytes per slot
+        uint2 pk;
+        pk.x = (unsigned)vg_f2bf(out.x) | ((unsigned)vg_f2bf(out.y) << 16);
+        pk.y = (unsigned)vg_f2bf(out.z) | ((unsigned)vg_f2bf(out.w) << 16);
+        reinterpret_cast<uint2*>(gx)[(size_t)rp * NT + slot] = pk;
+      } else {
+        st4(gx + ((size_t)rp * NT + slot) * 4, out);
+      }
     }
   }
 }

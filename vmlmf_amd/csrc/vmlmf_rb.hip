@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(256) rb_zero_pad_kernel(VGeo g, RbGeo q, float
   const int per = 64 * g.W - 16 * q.TPGV;   // uncovered slots per group
   for (int i = threadIdx.x; i < g.G * per; i += 256) {
     const int grp = i / per, slot = grp * 64 * g.W + 16 * q.TPGV + (i - grp * per);
-    st4(dpre + (row * g.NT + slot) * 4, f4zero());
+    if (g.bf) reinterpret_cast<uint2*>(dpre)[row * g.NT + slot] = make_uint2(0u, 0u);
+    else st4(dpre + (row * g.NT + slot) * 4, f4zero());
   }
 }
 
@@ -125,10 +126,13 @@ int rb_dispatch_g1b(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hip
 int rb_dispatch_g2(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s);
 int rb_dispatch_g2f(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s);
 int rb_dispatch_g2e(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s);
+int rb_dispatch_g1a_bf(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s);   // bf16-MFMA variant
+int rb_dispatch_g1b_bf(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s);
 
 // the instantiated (contraction steps, tiles per wave, M-tiles per group, flat, groups) combinations
-static bool rb_has(int ks, int mt, int nmu, bool flat, int G) {
+static bool rb_has(int ks, int mt, int nmu, bool flat, int G, bool bf) {
   if (mt < 1 || mt > 4) return false;
+  if (bf && G != 1) return false;   // the bf16 variant is instantiated for the plain (one-group) layers
   if (G == 1) return !flat && (ks == 2 || ks == 4 || ks == 6 || ks == 8) && nmu == (ks + 3) / 4;
   if (ks == 16) return flat && mt <= 3 && nmu == 4;
   return (ks == 4 || ks == 8) && nmu == 2;
@@ -176,7 +180,7 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out) {
   q.total = o;
   q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * q.NMT * 256 : 0;
   q.flag_words = S > 1 ? (long long)q.nrb * S + 64 : 0;
-  if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G)) return false;
+  if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G, g.bf != 0)) return false;
   *out = q;
   return true;
 }
@@ -189,6 +193,7 @@ int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hip
 }
 
 static int rb_dispatch(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, hipStream_t s) {
+  if (g.bf) return g.KH / 4 <= 4 ? rb_dispatch_g1a_bf(g, q, io, fwd, s) : rb_dispatch_g1b_bf(g, q, io, fwd, s);
   if (g.G == 1) return g.KH / 4 <= 4 ? rb_dispatch_g1a(g, q, io, fwd, s) : rb_dispatch_g1b(g, q, io, fwd, s);
   if (g.KH / 4 == 16) return rb_dispatch_g2e(g, q, io, fwd, s);
   return g.flat ? rb_dispatch_g2f(g, q, io, fwd, s) : rb_dispatch_g2(g, q, io, fwd, s);

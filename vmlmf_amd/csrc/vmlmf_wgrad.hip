@@ -40,11 +40,25 @@ __global__ void __launch_bounds__(MAXT) dqx_dx_kernel(VGeo g, WgxArgs a) {
   const int row_end = (blockIdx.x + 1) * g.RC < TB ? (blockIdx.x + 1) * g.RC : TB;
   for (int row0 = blockIdx.x * g.RC; row0 < row_end; row0 += RG) {
     float4 d[RG];
+    if (g.bf) {   // bf16 tape: 8 bytes per slot (wave-uniform branch around the whole batch of loads)
+      uint2 raw[RG];
 #pragma unroll
-    for (int rl = 0; rl < RG; ++rl) {
-      const int row = row0 + rl < row_end ? row0 + rl : row_end - 1;
-      const int t = row / B, b = row - t * B;
-      d[rl] = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);  // slot-padded: zeros in pad slots
+      for (int rl = 0; rl < RG; ++rl) {
+        const int row = row0 + rl < row_end ? row0 + rl : row_end - 1;
+        const int t = row / B, b = row - t * B;
+        raw[rl] = reinterpret_cast<const uint2*>(a.dpre)[(size_t)(t * g.Bp + b) * NT + tid];
+      }
+#pragma unroll
+      for (int rl = 0; rl < RG; ++rl)
+        d[rl] = make_float4(__uint_as_float(raw[rl].x << 16), __uint_as_float(raw[rl].x & 0xffff0000u),
+                            __uint_as_float(raw[rl].y << 16), __uint_as_float(raw[rl].y & 0xffff0000u));
+    } else {
+#pragma unroll
+      for (int rl = 0; rl < RG; ++rl) {
+        const int row = row0 + rl < row_end ? row0 + rl : row_end - 1;
+        const int t = row / B, b = row - t * B;
+        d[rl] = ld4(a.dpre + ((size_t)(t * g.Bp + b) * NT + tid) * 4);  // slot-padded: zeros in pad slots
+      }
     }
 #pragma unroll
     for (int rl = 0; rl < RG; ++rl) {
@@ -211,7 +225,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
       const float hm = (t > 0 || has_h0) ? 1.f : 0.f;
       const float okf = ok ? 1.f : 0.f;
       if (MODE == 1) {
-        av[u] = okf * a.dpre[(t * (unsigned)g.Bp + b) * (unsigned)(NT * 4) + col];
+        av[u] = okf * tape_elem(a.dpre, (t * (unsigned)g.Bp + b) * (unsigned)(NT * 4) + col, g.bf);
         hv[u] = hmask * hm * hp[an];
         xv[u] = xm ? a.x[t * usxT + b * usxB + xn] : 0.f;
       } else if (MODE == 2) {

@@ -74,7 +74,7 @@ def _hidden_size(variant, params):
     return params[1].shape[-1]                 # dia_h (1, H)
 
 
-# (variant, g, w_rank, u_ranks, time_major, B, T, I, H, training) -> (Desc, Sizes): host-side descriptor cache
+# (variant, g, w_rank, u_ranks, time_major, dtype, B, T, I, H, training) -> (Desc, Sizes): host-side descriptor cache
 _DESC_CACHE = {}
 # one grow-only scratch buffer per device: workspace contents never outlive the call that fills them and all
 # calls on a device are serialised on the current stream
@@ -85,8 +85,8 @@ def _desc_for(cfg, B, T, I, H, training):
     key = cfg + (B, T, I, H, training)
     hit = _DESC_CACHE.get(key)
     if hit is None:
-        variant, g, w_rank, u_ranks, time_major = cfg
-        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major, training=training)
+        variant, g, w_rank, u_ranks, time_major, dtype = cfg
+        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major, training=training, dtype=dtype)
         hit = (desc, _lib.query(desc))
         _DESC_CACHE[key] = hit
     return hit
@@ -113,11 +113,11 @@ def _require_hip(t, what):
 
 
 class VmlmfSeqFn(torch.autograd.Function):
-    """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major)."""
+    """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major, dtype)."""
 
     @staticmethod
     def forward(ctx, cfg, x, h0, c0, *params):
-        variant, g, w_rank, u_ranks, time_major = cfg
+        variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
         for p in params:
@@ -155,7 +155,7 @@ class VmlmfSeqFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT):
-        variant, g, w_rank, u_ranks, time_major = ctx.cfg
+        variant, g, w_rank, u_ranks, time_major, _ = ctx.cfg
         saved = ctx.saved_tensors
         x, y, reserve = saved[0], saved[1], saved[2]
         params = saved[3:3 + ctx.nparams]
@@ -192,18 +192,20 @@ class VmlmfSeqFn(torch.autograd.Function):
         return (None, dx, dh0, dc0) + grads
 
 
-def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False):
+def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32"):
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
     each in the reference's layout (the cells without vm: see the table at the top of this file).
-    Returns (y, hT, cT).
+    dtype: "f32" (the reference's arithmetic) or "bf16" (bf16 MFMA with fp32 accumulation and state, bf16 tapes; all
+    tensors stay float32 - include/vmlmf_hip.h: vmlmf_desc.dtype).  Returns (y, hT, cT).
     """
+    dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     ops = torch_ops()
     if ops is not None:
-        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major))
-    cfg = (variant, g, int(w_rank), ur, bool(time_major))
+        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt)
+    cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     return VmlmfSeqFn.apply(cfg, x, h0, c0, *params)
 
 
@@ -250,6 +252,20 @@ class HeadLinearFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmlmf_head_backward(B, H, C, _ptr(h), h.stride(0), _ptr(weight), _ptr(dl),
                                                       _ptr(dh), _ptr(dW), _ptr(db), stream))
         return dh, dW, db
+
+
+def set_compute_dtype(module, dtype):
+    """Select the arithmetic of every VMLMF layer under `module`: "f32" (default, the reference's) or "bf16" (bf16 MFMA in
+    the recurrence with fp32 accumulation and state, bf16 tapes; BASELINE configs[2]).  Parameters, inputs, outputs and
+    gradients stay float32 tensors either way; a layer the bf16 kernels do not cover raises when it is run."""
+    if dtype not in _lib.DTYPES:
+        raise ValueError(f"dtype must be one of {sorted(_lib.DTYPES)}")
+    n = 0
+    for m in module.modules():
+        if hasattr(m, "kernel_params"):
+            m.compute_dtype = dtype
+            n += 1
+    return n
 
 
 def head_linear(h, weight, bias):
