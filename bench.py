@@ -410,11 +410,20 @@ def main():
         dom = max(rec, key=rec.get)                      # dominant kernel by measured time
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; they were collected
         # with rocprofv3 in separate passes on this same command and committed under profiles/
-        traffic, traffic_note = None, None
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
-            traffic_note = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x FETCH correction)"
+        traffic, traffic_note, util, util_note = None, None, None, None
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic_note = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x FETCH correction)"
+                break
+            except (OSError, KeyError, ValueError):
+                pass
+        try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
+            u = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_util.json")))["kernels"][dom]["derived"]
+            util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
+                                          "lds_conflict_frac", "valu_insts_per_wave", "mfma_insts_per_wave")}
+            util_note = "profiles/r02_pmc_util.json (rocprofv3 --pmc SQ_*; fractions of SQ_WAVE_CYCLES resp. of busy-CU cycles)"
         except (OSError, KeyError, ValueError):
             pass
         rows = rows_gpu * T                              # sample-timesteps one launch processes
@@ -445,6 +454,10 @@ def main():
                          "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                          "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
+                         # one batch row per CU: rows_gpu of 256 CUs are busy; the same rate against THEIR share of the peak
+                         "active_cus": min(rows_gpu, 256),
+                         "frac_of_active_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * min(rows_gpu, 256) / 256.0), 5),
+                         "utilisation": util, "utilisation_source": util_note,
                          "flops_per_launch": flops,
                          "measured": "HIP event pairs on the launch stream over the eager timed region of the same K "
                                      "steps (events cannot be read inside a replayed hipGraph)",
