@@ -102,6 +102,8 @@ const char *vmlmf_last_error(void);
  *                   never: measured, the VALU kernels win there at every batch size; automatic mode uses the row-block
  *                   kernels only for layers beyond one CU's registers, e.g. H = 650)
  *   "rb_cluster"    workgroups a 16-row block's hidden units are split over for layers beyond one CU (0 = automatic)
+ *   "rb_rows"       live batch rows of a row-block workgroup: 16, 8 or 4 of the 16 MFMA columns (0 = automatic); fewer rows
+ *                   = more workgroups, each streaming fewer tape bytes through its CU
  */
 int vmlmf_tune(const char *key, int value);
 

@@ -24,7 +24,7 @@ def force_row_block_kernels():
 def uses_rb(variant, B, T, I, H, rw, ru, tm=False):
     g = 2 if variant in (O.V2, O.V4, O.V6) else 1
     s = _lib.query(_lib.make_desc(variant, B, T, I, H, rw, ru, g=g, time_major=tm))
-    return s.rows_per_wg == 16, s.workgroups
+    return s.rows_per_wg in (4, 8, 16), s.workgroups   # the VALU kernels own one row per workgroup
 
 
 RB_CASES = [

@@ -106,6 +106,13 @@ if __name__ == "__main__":
         for B in (64, 256, 512, 1024, 2048):
             for rb in (0, 1):
                 run(f"UCI V1 H=180 r=16 T=128 B={B}", *har(B), rb, 30)
+    if which == "uci_rows":     # live rows per row-block workgroup: 16 / 8 / 4
+        for B in (512, 1024, 2048, 4096):
+            run(f"UCI V1 H=180 r=16 T=128 B={B}", *har(B), 0, 20)
+            for rows in (16, 8, 4):
+                _lib.tune("rb_rows", rows)
+                run(f"UCI V1 H=180 r=16 T=128 B={B}, {rows} live rows per workgroup", *har(B), 1, 20)
+            _lib.tune("rb_rows", 0)
     if which in ("all", "c"):
         for rb in (0, 1):
             run("C: OPP V1 2x256 r=24 B=128 T=24", *har(128, 24, 77, 256, 24, (24,), 2), rb, 50)

@@ -86,6 +86,7 @@ int g_rb_mode = []() { const char* e = getenv("VMLMF_RB"); return e ? atoi(e) : 
 // traffic through ONE CU's memory pipe (~25 GB/s) costs more than the MFMAs save
 int g_rb_minB = env_pos("VMLMF_RB_MINB", 0);
 int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
+int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgroup: 16 / 8 / 4 (0 = automatic)
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -185,7 +186,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
     memset(&q, 0, sizeof(q));
     g.rb = 0;
     if (g.bf) {   // the bf16 variant IS the row-block family
-      if (!g.generic && g.I <= g.H && rb_geometry(g, 1, &q)) g.rb = 1;
+      if (!g.generic && g.I <= g.H && rb_geometry(g, 1, &q, g_rb_rows)) g.rb = 1;
       else return fail(VMLMF_E_UNSUPPORTED, "dtype bf16: implemented by the row-block MFMA kernels for one-group layers (V1, V3, V5) "
                                             "with padded rank <= 32 and <= 512 thread slots");
     } else if (g_rb_mode != 0 && g.I <= g.H) {
@@ -194,8 +195,8 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
         // clusters of 4 / 8 / 16, plain layer (rank 32) 1.84 / 1.64 / 1.60 ms: the largest cluster first
         const int cand[] = {g_rb_S, 16, 8, 4, 2};
         for (int i = (g_rb_S > 0 ? 0 : 1); i < 5 && g.rb == 0; ++i)
-          if (cand[i] > 1 && rb_geometry(g, cand[i], &q)) g.rb = cand[i];
-      } else if ((g_rb_mode == 1 || (g_rb_minB > 0 && g.B >= g_rb_minB)) && rb_geometry(g, 1, &q)) {
+          if (cand[i] > 1 && rb_geometry(g, cand[i], &q, g_rb_rows)) g.rb = cand[i];
+      } else if ((g_rb_mode == 1 || (g_rb_minB > 0 && g.B >= g_rb_minB)) && rb_geometry(g, 1, &q, g_rb_rows)) {
         g.rb = 1;
       }
     }
@@ -326,7 +327,7 @@ int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
   const long long ws = L.f_total > L.b_total ? L.f_total : L.b_total;
   out->workspace_bytes = (size_t)ws * sizeof(float);
   out->reserve_bytes = (size_t)L.r_total * sizeof(float);
-  out->rows_per_wg = g.rb ? 16 : g.R;
+  out->rows_per_wg = g.rb ? q.rbl : g.R;
   out->threads_per_wg = g.rb ? 256 : g.NT;
   out->workgroups = g.rb ? q.nrb * q.S : g.nwg;
   out->kx = g.KX;
@@ -516,6 +517,7 @@ int vmlmf_tune(const char* key, int value) {
   if (k == "rb") g_rb_mode = value;
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
+  else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;
   else return fail(VMLMF_E_BADARG, "tune: unknown key " + k);
   return 0;
 }

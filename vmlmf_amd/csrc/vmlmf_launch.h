@@ -55,7 +55,8 @@ struct RbIo {
   float* xq;        // cluster exchange tiles (S > 1)
   unsigned* flag;   // cluster epoch words + error word
 };
-bool rb_geometry(const VGeo& g, int S, RbGeo* out);   // false: no instantiation covers the layer with S splits
+// false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
+bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s);
 int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);

@@ -138,7 +138,7 @@ static bool rb_has(int ks, int mt, int nmu, bool flat, int G, bool bf) {
   return (ks == 4 || ks == 8) && nmu == 2;
 }
 
-bool rb_geometry(const VGeo& g, int S, RbGeo* out) {
+bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
   RbGeo q;
   memset(&q, 0, sizeof(q));
   if (g.KH % 4 != 0 || g.G > 2 || (RB_WAVES * S) % g.G != 0) return false;
@@ -148,7 +148,16 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out) {
   q.WSG = RB_WAVES * S / g.G;
   q.MT = (q.TPGV + q.WSG - 1) / q.WSG;
   q.NMT = g.G * g.NP;
-  q.nrb = (g.B + RB - 1) / RB;
+  // live rows per workgroup: 16, or fewer for a cluster at a small batch - the exchange volume and with it the step time
+  // fall with the live rows (config E per GPU of an 8-GPU node, B = 32: 7.5 us per step with 16 rows), as long as all
+  // clusters stay co-resident (one workgroup per CU, 256 CUs)
+  q.rbl = RB;
+  if (rows == 4 || rows == 8 || rows == 16) {
+    q.rbl = rows;
+  } else if (S > 1) {
+    while (q.rbl > 4 && (long long)((g.B + q.rbl / 2 - 1) / (q.rbl / 2)) * S <= 256) q.rbl /= 2;
+  }
+  q.nrb = (g.B + q.rbl - 1) / q.rbl;
   // M-tiles of the padded rank space the units of group `grp` couple to (vmlmf_geo.h: block s of the rank space feeds
   // destination (grp - s) mod G)
   int nmu = 0;
