@@ -148,3 +148,43 @@ def test_row_block_and_valu_kernels_agree_at_large_batch():
     assert_grad(a["dx"], b["dx"], "dx", rel=2e-5)
     for k in a["G"]:
         assert_grad(a["G"][k], b["G"][k], "G." + k, rel=5e-5)
+
+
+def test_cluster_exchange_is_bit_stable_under_uneven_load():
+    """The cluster hand-offs (write-through partials + epoch words, agent scope) must not depend on timing or placement:
+    the PTB group layer runs forward + backward 12 times while a second stream streams copies through HBM at random
+    intervals; every repetition must reproduce the first one bit for bit (sums are taken in member order, so any stale or
+    torn read shows up as a different bit pattern).  Idle, evenly loaded chips hide such failures."""
+    from vmlmf_amd import MyVMLSTMGroup
+    torch.manual_seed(0)
+    H, B, T = 650, 48, 12
+    layer = MyVMLSTMGroup(H, H, w_rank=32, u_ranks=[32, 32]).cuda()
+    for p in layer.parameters():
+        torch.nn.init.uniform_(p, -0.05, 0.05)
+    assert uses_rb(O.V4, B, T, H, H, 32, [32, 32], True)[1] > 16
+    x = (0.05 * torch.randn(T, B, H, device="cuda")).requires_grad_(True)
+    st = (torch.zeros(B, H, device="cuda"), torch.zeros(B, H, device="cuda"))
+    dy = torch.randn(T, B, H, device="cuda")
+    hog_stream = torch.cuda.Stream()
+    a = torch.empty(64 << 20, device="cuda", dtype=torch.float32)
+    b = torch.empty_like(a)
+    g = torch.Generator().manual_seed(1)
+    first = None
+    for it in range(12):
+        n_hog = int(torch.randint(0, 4, (1,), generator=g))
+        with torch.cuda.stream(hog_stream):
+            for _ in range(n_hog):
+                b.copy_(a)
+                a.mul_(1.0001)
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y, (hT, cT) = layer(x, st)
+        (y * dy).sum().backward()
+        torch.cuda.synchronize()
+        got = [y.detach().clone(), hT.detach().clone(), x.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+        assert all(torch.isfinite(t).all() for t in got)
+        if first is None:
+            first = got
+        else:
+            for k, (u, v) in enumerate(zip(first, got)):
+                assert torch.equal(u, v), f"repetition {it}: tensor {k} differs from the first run (max {float((u - v).abs().max()):.3e})"
