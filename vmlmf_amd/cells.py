@@ -62,7 +62,7 @@ class MyVMLMFCell(nn.Module):
 
     def kernel_cfg(self):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
-                    dtype=getattr(self, "compute_dtype", "f32"))
+                    dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         """Whole-sequence evaluation: (y, hT, cT)."""
@@ -117,7 +117,7 @@ class MyVMLMFCellg2(nn.Module):
 
     def kernel_cfg(self):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g,
-                    dtype=getattr(self, "compute_dtype", "f32"))
+                    dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
@@ -217,7 +217,7 @@ class MyLSTMCell(nn.Module):
 
     def kernel_cfg(self):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
-                    dtype=getattr(self, "compute_dtype", "f32"))
+                    dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
     def sequence(self, x, h0=None, c0=None, time_major=False):
         """Whole-sequence evaluation on the HIP kernels (low-rank mode only): (y, hT, cT)."""

@@ -96,7 +96,11 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
   // of autograd's argument walker and the parameters would get no gradient)
   static variable_list forward(AutogradContext* ctx, Tensor x, c10::optional<Tensor> h0o, c10::optional<Tensor> c0o,
                                at::TensorList params_in, int64_t variant, int64_t g, int64_t w_rank,
-                               std::vector<int64_t> u_ranks, bool time_major, bool training, int64_t dtype) {
+                               std::vector<int64_t> u_ranks, bool time_major, bool training, int64_t dtype,
+                               c10::optional<Tensor> packed_o) {
+    // packed_o: parameter images kept by the caller (vmlmf_pack_params; functional.PackCache): nothing is packed in this call.
+    // It travels as a non-differentiable input and is saved for the backward, which reads the same images.
+    Tensor packed = packed_o.has_value() ? *packed_o : Tensor();
     ctx->set_materialize_grads(false);
     require_hip_f32(x, "input");
     x = x.contiguous();
@@ -118,14 +122,16 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor reserve = training ? at::empty({(int64_t)sz.reserve_bytes}, x.options().dtype(at::kByte)) : Tensor();
     vmlmf_params ps;
     fill_params(ps, params, (int)variant, (int)g);
-    check(vmlmf_seq_forward(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),
-                            cT.data_ptr<float>(), training ? reserve.data_ptr() : nullptr, ws.data_ptr(), sz.workspace_bytes,
-                            stream_of(x)));
+    check(vmlmf_seq_forward_packed(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),
+                                   cT.data_ptr<float>(), training ? reserve.data_ptr() : nullptr, ws.data_ptr(),
+                                   sz.workspace_bytes, stream_of(x), packed.defined() ? packed.data_ptr() : nullptr));
     if (training) {
       variable_list saved = {x, y, reserve};
       for (auto& p : params) saved.push_back(p);
       if (h0.defined()) saved.push_back(h0);
       if (c0.defined()) saved.push_back(c0);
+      if (packed.defined()) saved.push_back(packed);
+      ctx->saved_data["packed"] = packed.defined();
       ctx->save_for_backward(saved);
       ctx->saved_data["np"] = (int64_t)params.size();
       ctx->saved_data["h0"] = h0.defined();
@@ -148,6 +154,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     std::vector<Tensor> params(saved.begin() + 3, saved.begin() + 3 + np);
     size_t k = 3 + np;
     Tensor h0 = has_h0 ? saved[k++] : Tensor(), c0 = has_c0 ? saved[k++] : Tensor();
+    Tensor packed = ctx->saved_data["packed"].toBool() ? saved[k++] : Tensor();
     Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
     Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
     Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
@@ -173,25 +180,26 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     vmlmf_grads gs;
     fill_params(ps, params, (int)variant, (int)g);
     fill_params(gs, grads, (int)variant, (int)g);
-    check(vmlmf_seq_backward(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(), cptr(dy),
-                             cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(), sz.workspace_bytes,
-                             stream_of(x)));
+    check(vmlmf_seq_backward_packed(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(),
+                                    cptr(dy), cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(),
+                                    sz.workspace_bytes, stream_of(x), packed.defined() ? packed.data_ptr() : nullptr));
     variable_list out = {dx, dh0, dc0};
     for (auto& gt : grads) out.push_back(gt);
-    for (int i = 0; i < 7; ++i) out.push_back(Tensor());   // the integer configuration
+    for (int i = 0; i < 8; ++i) out.push_back(Tensor());   // the integer configuration and the kept parameter images
     return out;
   }
 };
 
 std::tuple<Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::optional<Tensor>& h0, const c10::optional<Tensor>& c0,
                                             at::TensorList params, int64_t variant, int64_t g, int64_t w_rank,
-                                            at::IntArrayRef u_ranks, bool time_major, int64_t dtype) {
+                                            at::IntArrayRef u_ranks, bool time_major, int64_t dtype,
+                                            const c10::optional<Tensor>& packed) {
   // grad mode is off inside Function::forward: whether the tape is needed is decided here (False under torch.no_grad():
   // inference kernels, no reserve buffer)
   bool training = x.requires_grad() || (h0.has_value() && h0->requires_grad()) || (c0.has_value() && c0->requires_grad());
   for (const auto& p : params) training = training || p.requires_grad();
   training = training && at::GradMode::is_enabled();
-  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype);
+  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed);
   return {out[0], out[1], out[2]};
 }
 
@@ -286,7 +294,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 }  // namespace
 
 TORCH_LIBRARY(vmlmf, m) {
-  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype) -> (Tensor, Tensor, Tensor)");
+  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed) -> (Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }

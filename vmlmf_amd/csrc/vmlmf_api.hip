@@ -87,6 +87,7 @@ int g_rb_mode = []() { const char* e = getenv("VMLMF_RB"); return e ? atoi(e) : 
 int g_rb_minB = env_pos("VMLMF_RB_MINB", 0);
 int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
 int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgroup: 16 / 8 / 4 (0 = automatic)
+int g_tune_generation = 0;                        // bumped by every vmlmf_tune(): kept parameter images of an older one are stale
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -335,9 +336,56 @@ int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
   return 0;
 }
 
+// ---- parameter images kept by the caller (vmlmf_pack_params / *_packed) ----
+// header in front of the image: what geometry it was packed for (a forward with another one refuses it)
+constexpr int PK_HDR = 64;   // floats
+static void pack_signature(const VGeo& g, const VPack& P, const RbGeo& q, float* sig) {
+  const long long v[8] = {0x564d4c4dLL, P.total, g.rb, g.generic, g.bf, g.NT, (long long)g.KH * 1000 + g.KX, q.total};
+  for (int i = 0; i < 8; ++i) sig[i] = (float)(v[i] % 16777216LL);
+}
+
+int vmlmf_pack_bytes(const vmlmf_desc* d, size_t* bytes) {
+  if (bytes == nullptr) return fail(VMLMF_E_BADARG, "null size");
+  VGeo g;
+  RbGeo q;
+  const int rc = make_geo(d, &g, &q);
+  if (rc != 0) return rc;
+  if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers (their image carries per-call state)");
+  const VPack P = vg_pack_layout(g, q.total);
+  *bytes = sizeof(float) * (size_t)(PK_HDR + P.total);
+  return 0;
+}
+
+int vmlmf_pack_params(const vmlmf_desc* d, const vmlmf_params* p, void* packed, void* stream) {
+  VGeo g;
+  RbGeo q;
+  int rc = make_geo(d, &g, &q);
+  if (rc != 0) return rc;
+  if ((rc = check_params(g, p)) != 0) return rc;
+  if (packed == nullptr) return fail(VMLMF_E_BADARG, "null packed buffer");
+  if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
+  const VPack P = vg_pack_layout(g, q.total);
+  hipStream_t s = (hipStream_t)stream;
+  float* img = (float*)packed + PK_HDR;
+  float sig[PK_HDR] = {0};
+  pack_signature(g, P, q, sig);
+  if ((rc = (int)hipMemcpyAsync(packed, sig, sizeof(sig), hipMemcpyHostToDevice, s)) != 0) return hip_fail(rc, "pack header");
+  const RefP rp = to_refp(p);
+  Scope sc(0, s);
+  if ((rc = hip_fail(launch_pack(g, rp, P, img, s), "pack")) != 0) return rc;
+  if (g.rb && (rc = hip_fail(launch_rb_pack(g, q, rp, img + P.RB, s), "rb_pack")) != 0) return rc;
+  return 0;
+}
+
 int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
                       const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                       size_t workspace_bytes, void* stream) {
+  return vmlmf_seq_forward_packed(d, p, x, h0, c0, y, hT, cT, reserve, workspace, workspace_bytes, stream, nullptr);
+}
+
+int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                             const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
+                             size_t workspace_bytes, void* stream, const void* packed) {
   VGeo g;
   RbGeo q;
   int rc = make_geo(d, &g, &q);
@@ -353,9 +401,13 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
   float* ws = (float*)workspace;
   float* rs = (float*)reserve;
   float* pack = g.training ? rs + L.r_pack : ws + L.f_pack;
+  if (packed != nullptr) {   // the caller's image (vmlmf_pack_params): nothing is packed here
+    if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
+    pack = const_cast<float*>((const float*)packed) + PK_HDR;
+  }
   float* gx = ws + L.f_gx;
   const RefP rp = to_refp(p);
-  {
+  if (packed == nullptr) {
     Scope sc(0, s);
     if ((rc = hip_fail(launch_pack(g, rp, P, pack, s), "pack")) != 0) return rc;
   }
@@ -367,7 +419,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
       return rc;
   }
   if (g.rb) {
-    {
+    if (packed == nullptr) {
       Scope sc(0, s);
       if ((rc = hip_fail(launch_rb_pack(g, q, rp, pack + P.RB, s), "rb_pack")) != 0) return rc;
     }
@@ -417,6 +469,15 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
                        const float* c0, const float* y, const void* reserve, const float* dy,
                        const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
                        const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream) {
+  return vmlmf_seq_backward_packed(d, p, x, h0, c0, y, reserve, dy, dhT, dcT, dx, dh0, dc0, gr, workspace, workspace_bytes, stream,
+                                   nullptr);
+}
+
+int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                              const float* c0, const float* y, const void* reserve, const float* dy,
+                              const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
+                              const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
+                              const void* packed) {
   VGeo g;
   RbGeo q;
   int rc = make_geo(d, &g, &q);
@@ -433,6 +494,10 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   float* ws = (float*)workspace;
   const float* rs = (const float*)reserve;
   const float* pack = rs + L.r_pack;
+  if (packed != nullptr) {   // the image the matching forward was given
+    if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
+    pack = (const float*)packed + PK_HDR;
+  }
   if (g.rb) {
     RbIo io;
     memset(&io, 0, sizeof(io));
@@ -511,6 +576,8 @@ int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* 
   return 0;
 }
 
+int vmlmf_tune_generation(void) { return g_tune_generation; }
+
 int vmlmf_tune(const char* key, int value) {
   if (key == nullptr) return fail(VMLMF_E_BADARG, "tune: null key");
   const std::string k(key);
@@ -519,6 +586,7 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
   else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;
   else return fail(VMLMF_E_BADARG, "tune: unknown key " + k);
+  ++g_tune_generation;
   return 0;
 }
 

@@ -103,6 +103,57 @@ def _workspace(dev, nbytes):
     return buf
 
 
+class PackCache:
+    """Kept parameter images of one layer (C ABI: vmlmf_pack_params / vmlmf_seq_*_packed), opt-in through
+    vmlmf_amd.cache_packed_parameters(module).  The library packs the reference-layout parameters into the kernels' register
+    images on every forward (6 us of the 185 us headline step); while the parameters are unchanged the images can be
+    reused - inference, evaluation, gradient accumulation, a loop without an optimizer step.  "Unchanged" is judged by
+    (data_ptr, _version) of every parameter tensor: in-place updates under torch.no_grad() (torch.optim, the reference's
+    `param -= lr * grad`, vmlmf_amd.optim) are seen; writes through `param.data` are NOT (they do not bump the version) -
+    that is why the cache is opt-in.  During a stream capture the cache is only read, never filled."""
+    __slots__ = ("key", "packed", "hits", "fills")
+
+    def __init__(self):
+        self.key, self.packed, self.hits, self.fills = None, None, 0, 0
+
+    def get(self, cfg, params, x, B, T, I, H):
+        if self.key == "unsupported":
+            return None
+        key = (cfg, B, I, H, x.device.index, _lib.lib().vmlmf_tune_generation(),
+               tuple((p.data_ptr(), p._version) for p in params))
+        if key == self.key:
+            self.hits += 1
+            return self.packed
+        if torch.cuda.is_current_stream_capturing():
+            return None                       # packed inside the captured call, as without a cache
+        variant, g, w_rank, u_ranks, time_major, dtype = cfg
+        desc = _lib.make_desc(variant, B, T, I, H, w_rank, u_ranks, g=g, time_major=time_major, training=True, dtype=dtype)
+        n = ctypes.c_size_t()
+        rc = _lib.lib().vmlmf_pack_bytes(ctypes.byref(desc), ctypes.byref(n))
+        if rc == _lib.E_UNSUPPORTED:          # step-wise / clustered layers keep per-call state in their image
+            self.key, self.packed = "unsupported", None
+            return None
+        _lib.check(rc)
+        packed = torch.empty(n.value, device=x.device, dtype=torch.uint8)   # a NEW buffer: an earlier forward's backward may still need the old one
+        ps = _params_struct(params, g, variant)
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().vmlmf_pack_params(ctypes.byref(desc), ctypes.byref(ps), _ptr(packed), _lib.raw_stream(x.device)))
+        self.key, self.packed = key, packed
+        self.fills += 1
+        return packed
+
+
+def cache_packed_parameters(module, enable=True):
+    """Let every VMLMF layer under `module` keep its packed parameter images between forward calls while its parameters are
+    unchanged (see PackCache for what "unchanged" can and cannot see).  Returns the number of layers switched."""
+    n = 0
+    for m in module.modules():
+        if hasattr(m, "kernel_params"):
+            m._pack_cache = PackCache() if enable else None
+            n += 1
+    return n
+
+
 def _require_hip(t, what):
     if not t.is_cuda:
         raise RuntimeError(
@@ -116,7 +167,7 @@ class VmlmfSeqFn(torch.autograd.Function):
     """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major, dtype)."""
 
     @staticmethod
-    def forward(ctx, cfg, x, h0, c0, *params):
+    def forward(ctx, cfg, packed, x, h0, c0, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -130,6 +181,7 @@ class VmlmfSeqFn(torch.autograd.Function):
             B, T, I = x.shape
         H = _hidden_size(variant, params)
         training = bool(any(ctx.needs_input_grad))   # False under torch.no_grad(): inference kernels
+        ctx.packed = packed                           # kept parameter images (PackCache) or None
         desc, sizes = _desc_for(cfg, B, T, I, H, training)
         dev = x.device
         y = torch.empty((T, B, H) if time_major else (B, T, H), device=dev, dtype=torch.float32)
@@ -142,9 +194,9 @@ class VmlmfSeqFn(torch.autograd.Function):
         ps = _params_struct(params, g, variant)
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().vmlmf_seq_forward(
+            _lib.check(_lib.lib().vmlmf_seq_forward_packed(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
-                _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream))
+                _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream, _ptr(packed)))
         if training:
             ctx.cfg, ctx.desc, ctx.sizes = cfg, desc, sizes
             ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
@@ -167,7 +219,7 @@ class VmlmfSeqFn(torch.autograd.Function):
         dy = None if dy is None else dy.contiguous()
         dhT = None if dhT is None else dhT.contiguous()
         dcT = None if dcT is None else dcT.contiguous()
-        need_dx = ctx.needs_input_grad[1]
+        need_dx = ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_dx else None
         B, H = y.shape[1 if time_major else 0], y.shape[2]
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
@@ -185,14 +237,14 @@ class VmlmfSeqFn(torch.autograd.Function):
         gs = _params_struct(grads, g, variant)
         stream = _lib.raw_stream(dev)
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().vmlmf_seq_backward(
+            _lib.check(_lib.lib().vmlmf_seq_backward_packed(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
                 _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
-                _ptr(ws), sizes.workspace_bytes, stream))
-        return (None, dx, dh0, dc0) + grads
+                _ptr(ws), sizes.workspace_bytes, stream, _ptr(ctx.packed)))
+        return (None, None, dx, dh0, dc0) + grads
 
 
-def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32"):
+def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", pack_cache=None):
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
@@ -201,12 +253,17 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     tensors stay float32 - include/vmlmf_hip.h: vmlmf_desc.dtype).  Returns (y, hT, cT).
     """
     dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    packed = None
+    if pack_cache is not None and x.is_cuda:
+        T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
+        cfg0 = (variant, g, int(w_rank), tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),), bool(time_major), dt)
+        packed = pack_cache.get(cfg0, params, x, B, T, x.shape[2], _hidden_size(variant, params))
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     ops = torch_ops()
     if ops is not None:
-        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt)
+        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt, packed)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
-    return VmlmfSeqFn.apply(cfg, x, h0, c0, *params)
+    return VmlmfSeqFn.apply(cfg, packed, x, h0, c0, *params)
 
 
 class HeadLinearFn(torch.autograd.Function):

@@ -40,6 +40,7 @@ class GraphedTrainStep:
         if dev.type != "cuda":
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         params = [p for group in optimizer.param_groups for p in group["params"]]
+        self._params = list(params)
         seen = {id(p) for p in params}
         params += [p for p in model.parameters() if id(p) not in seen]
         with torch.no_grad():
@@ -95,4 +96,8 @@ class GraphedTrainStep:
         self.x.copy_(x, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self.graph.replay()
+        # the replayed optimizer kernels changed the parameters on the device; the host-side version counters only moved
+        # while the step was captured: move them now, so that nothing keyed on them (kept parameter images) goes stale
+        for p in self._params:
+            torch.autograd.graph.increment_version(p)
         return self.loss

@@ -48,7 +48,7 @@ class MyVMLSTM(nn.Module):
 
     def _run(self, x, h, c):
         return vmlmf_sequence(self.variant, x, h, c, self.kernel_params(), self.w_rank, [self.u_ranks],
-                              g=1, time_major=True, dtype=getattr(self, "compute_dtype", "f32"))
+                              g=1, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
     def lstm_step(self, x, h, c):
         """One timestep (vmlmf_lm.py:222-269): T = 1 of the sequence kernels."""
@@ -95,7 +95,7 @@ class MyVMLSTMGroup(nn.Module):
 
     def _run(self, x, h, c):
         return vmlmf_sequence(self.variant, x, h, c, self.kernel_params(), self.w_rank, list(self.u_ranks),
-                              g=self.g, time_major=True, dtype=getattr(self, "compute_dtype", "f32"))
+                              g=self.g, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
     def lstm_step(self, x, h, c):
         _, hn, cn = self._run(x.unsqueeze(0), h, c)

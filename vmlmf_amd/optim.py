@@ -118,7 +118,15 @@ class Adam(torch.optim.Optimizer):
                     _lib.check(lib.vmlmf_adam_step(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(),
                                                    gs["steps"].data_ptr(), float(group["lr"]), float(b1), float(b2),
                                                    float(group["eps"]), float(group["weight_decay"]), stream))
+            _bump_versions(live)
         return loss
+
+
+def _bump_versions(params):
+    """The kernels write parameters through raw pointers: tell autograd's version counters (kept parameter images,
+    functional.PackCache, and any saved-tensor check key on them) that the tensors changed in place."""
+    for p in params:
+        torch.autograd.graph.increment_version(p)
 
 
 class _Scratch:
@@ -153,4 +161,5 @@ def clip_sgd_step(parameters, lr, max_norm):
     with _lib.on_device(dev):
         _lib.check(_lib.lib().vmlmf_sgd_clip_step(ctypes.byref(tl), float(lr), float(max_norm), norm.data_ptr(),
                                                   scratch.data_ptr(), stream))
+    _bump_versions(live)
     return norm
