@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 5
+#define VMLMF_ABI_VERSION 6
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -143,6 +143,38 @@ int vmlmf_seq_backward_packed(const vmlmf_desc *d, const vmlmf_params *p, const 
                               const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream,
                               const void *packed);
 int vmlmf_tune_generation(void);
+
+/*
+ * Classifier riding on a layer (ABI 6): Net applies nn.Linear(H, 18) to the last layer's final hidden state
+ * (V/src/models/vmlmf.py:345,353-355).  Given with the layer's forward / backward it costs no launch of its own: the
+ * logits come out of the epilogue of the forward recurrence, d(hT) = dlogits W is formed in the prologue of the backward
+ * one, dweight / dbias are extra outputs of the final gradient kernel (two launches and their boundaries less per training
+ * step: 0.1787 -> 0.167 ms at the headline shape).  Layers on the row-block / step-wise kernels get the same results from
+ * the stand-alone head kernels, launched inside the call.  classes <= 32.
+ *   forward : weight (C,H), bias (C) or NULL, logits (B,C) out
+ *   backward: weight, dlogits (B,C) in; dweight (C,H), dbias (C) out (either may be NULL).  The gradient that reaches
+ *             the final hidden state is dhT (if given) + dlogits W.
+ * vmlmf_extra gathers the optional arguments of a call; NULL members are "not used".
+ */
+typedef struct vmlmf_head {
+  int32_t classes;
+  const float *weight, *bias;
+  float *logits;
+  const float *dlogits;
+  float *dweight, *dbias;
+} vmlmf_head;
+typedef struct vmlmf_extra {
+  const void *packed;        /* kept parameter images (vmlmf_pack_params) or NULL */
+  const vmlmf_head *head;    /* classifier on the final hidden state or NULL      */
+} vmlmf_extra;
+int vmlmf_seq_forward_ex(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                         const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,
+                         size_t workspace_bytes, void *stream, const vmlmf_extra *ex);
+int vmlmf_seq_backward_ex(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
+                          const float *c0, const float *y, const void *reserve, const float *dy,
+                          const float *dhT, const float *dcT, float *dx, float *dh0, float *dc0,
+                          const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream,
+                          const vmlmf_extra *ex);
 
 /*
  * Sequence backward: replaces autograd's replay of the ~75 ATen ops per timestep.

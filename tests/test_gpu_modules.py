@@ -565,3 +565,31 @@ def test_kept_parameter_images_follow_every_visible_parameter_change():
     for _ in range(3):
         assert torch.equal(sa(x, t), sb(x, t))
     same()
+
+
+@pytest.mark.parametrize("layers,B,T", [([180], 64, 16), ([24, 40], 7, 5), ([600], 5, 3)])
+def test_classifier_riding_on_the_last_layer_equals_the_separate_head(layers, B, T):
+    """Net.forward hands Net.lin to the last layer's call (vmlmf_seq_*_ex: logits from the recurrence's epilogue, d(hT) in the
+    backward's prologue, dW / db from the final gradient kernel; stand-alone head kernels inside the call for the row-block /
+    step-wise layers): same logits, loss and gradients as the layer followed by vmlmf_amd.head_linear."""
+    import copy
+    import vmlmf_amd
+    from vmlmf_amd.functional import head_linear
+    torch.manual_seed(7)
+    a = Net(9, layer_sizes=layers, w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    b = copy.deepcopy(a)
+    x = torch.randn(B, T, 9, device=DEV)
+    t = torch.randint(0, 18, (B,), device=DEV)
+    la = vmlmf_amd.cross_entropy(a(x), t)
+    la.backward()
+    _, hid = b.rnn.run_layers(x)
+    lb = vmlmf_amd.cross_entropy(head_linear(hid[-1], b.lin.weight, b.lin.bias), t)
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-6 * abs(float(lb))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None, k
+            continue
+        assert_grad(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), k, rel=2e-5)
+    with torch.no_grad():
+        assert_out(a(x).cpu().numpy(), head_linear(b.rnn.run_layers(x)[1][-1], b.lin.weight, b.lin.bias).cpu().numpy(), "logits")

@@ -18,7 +18,7 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
@@ -40,6 +40,16 @@ class Params(ctypes.Structure):
                 ("v_x", ctypes.c_void_p), ("b_x", ctypes.c_void_p), ("b_h", ctypes.c_void_p),
                 ("u_h", ctypes.c_void_p * MAX_G), ("v_h", ctypes.c_void_p * MAX_G),
                 ("w_gate", ctypes.c_void_p * 4), ("u_gate", ctypes.c_void_p * 4), ("b_gate", ctypes.c_void_p * 4)]
+
+
+class Head(ctypes.Structure):
+    _fields_ = [("classes", ctypes.c_int32), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("logits", ctypes.c_void_p), ("dlogits", ctypes.c_void_p), ("dweight", ctypes.c_void_p),
+                ("dbias", ctypes.c_void_p)]
+
+
+class Extra(ctypes.Structure):
+    _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head))]
 
 
 class Sizes(ctypes.Structure):
@@ -71,6 +81,10 @@ SYMBOLS = {
     "vmlmf_seq_backward_packed": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp, _vp]),
     "vmlmf_tune_generation": (_i, []),
+    "vmlmf_seq_forward_ex": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                                  _vp, _vp, _sz, _vp, ctypes.POINTER(Extra)]),
+    "vmlmf_seq_backward_ex": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp, ctypes.POINTER(Extra)]),
     "vmlmf_seq_backward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                 _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp]),
     "vmlmf_head_forward": (_i, [_i, _i, _i, _vp, ctypes.c_longlong, _vp, _vp, _vp, _vp]),

@@ -64,9 +64,9 @@ class MyVMLMFCell(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False):
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
         """Whole-sequence evaluation: (y, hT, cT)."""
-        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
                               **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
@@ -119,8 +119,8 @@ class MyVMLMFCellg2(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False):
-        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
                               **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
@@ -219,12 +219,12 @@ class MyLSTMCell(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False):
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
         """Whole-sequence evaluation on the HIP kernels (low-rank mode only): (y, hT, cT)."""
         if not self.low_rank:
             raise RuntimeError("vmlmf_amd: MyLSTMCell.sequence needs w_rank and u_ranks (the vanilla cell is "
                                "not on the HIP path)")
-        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major,
+        return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
                               **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
@@ -276,12 +276,15 @@ class MyLSTM(nn.Module):
             in_size = hidden_size
         self.rnncells = nn.ModuleList(cells)
 
-    def run_layers(self, x):
-        """(output sequence of the last layer, [final h of every layer])."""
-        hiddens = []
+    def run_layers(self, x, head=None):
+        """(output sequence of the last layer, [final h of every layer]); with `head` = (weight, bias) of a classifier on the
+        last layer's final hidden state also its logits (None when the last layer cannot carry it)."""
+        hiddens, logits = [], None
         for i, cell in enumerate(self.rnncells):
             fused = hasattr(cell, "sequence") and (not isinstance(cell, MyLSTMCell) or (cell.low_rank and x.is_cuda))
-            if fused:
+            if fused and head is not None and i == len(self.rnncells) - 1:
+                x, h, _, logits = cell.sequence(x, None, None, time_major=not self.batch_first, head=head)
+            elif fused:
                 x, h, _ = cell.sequence(x, None, None, time_major=not self.batch_first)
             else:
                 B = x.size(self.batch_index)
@@ -293,6 +296,8 @@ class MyLSTM(nn.Module):
                     outs.append(h)
                 x = torch.stack(outs, self.time_index)
             hiddens.append(h)
+        if head is not None:
+            return x, hiddens, logits
         return x, hiddens
 
     def forward(self, x):
@@ -321,7 +326,16 @@ class Net(nn.Module):
         if isinstance(self.rnn, MyLSTM) and self.rnn.batch_first:
             # y[:, -1] IS the last layer's final h (same kernel value): taking it from there keeps autograd
             # from materialising a zero (B,T,H) gradient for y just to carry its last slice
-            _, hiddens = self.rnn.run_layers(x)
+            # ... and the classifier rides on the last layer's kernels when it can (HIP tensors, <= 32 classes): its logits come
+            # out of the recurrence's epilogue, its backward is folded into the layer's backward (no launches of its own)
+            ride = (x.is_cuda and x.dtype == torch.float32 and self.lin.weight.shape[0] <= _lib.HEAD_MAX_CLASSES
+                    and self.lin.weight.dtype == torch.float32)
+            if ride:
+                _, hiddens, logits = self.rnn.run_layers(x, head=(self.lin.weight, self.lin.bias))
+                if logits is not None:
+                    return logits.squeeze(1)
+            else:
+                _, hiddens = self.rnn.run_layers(x)
             last = hiddens[-1]
         else:
             y, _ = self.rnn(x)

@@ -97,7 +97,11 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
   static variable_list forward(AutogradContext* ctx, Tensor x, c10::optional<Tensor> h0o, c10::optional<Tensor> c0o,
                                at::TensorList params_in, int64_t variant, int64_t g, int64_t w_rank,
                                std::vector<int64_t> u_ranks, bool time_major, bool training, int64_t dtype,
-                               c10::optional<Tensor> packed_o) {
+                               c10::optional<Tensor> packed_o, c10::optional<Tensor> head_w_o, c10::optional<Tensor> head_b_o) {
+    // head_w / head_b: a classifier riding on the layer's final hidden state (Net.lin): its logits are the 4th output
+    Tensor head_w = head_w_o.has_value() ? head_w_o->contiguous() : Tensor();
+    Tensor head_b = head_b_o.has_value() ? head_b_o->contiguous() : Tensor();
+    if (head_w.defined()) require_hip_f32(head_w, "head weight");
     // packed_o: parameter images kept by the caller (vmlmf_pack_params; functional.PackCache): nothing is packed in this call.
     // It travels as a non-differentiable input and is saved for the backward, which reads the same images.
     Tensor packed = packed_o.has_value() ? *packed_o : Tensor();
@@ -122,9 +126,18 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor reserve = training ? at::empty({(int64_t)sz.reserve_bytes}, x.options().dtype(at::kByte)) : Tensor();
     vmlmf_params ps;
     fill_params(ps, params, (int)variant, (int)g);
-    check(vmlmf_seq_forward_packed(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),
-                                   cT.data_ptr<float>(), training ? reserve.data_ptr() : nullptr, ws.data_ptr(),
-                                   sz.workspace_bytes, stream_of(x), packed.defined() ? packed.data_ptr() : nullptr));
+    Tensor logits = head_w.defined() ? at::empty({B, head_w.size(0)}, x.options()) : at::empty({0}, x.options());
+    vmlmf_head hd;
+    memset(&hd, 0, sizeof(hd));
+    if (head_w.defined()) {
+      TORCH_CHECK(head_w.dim() == 2 && head_w.size(1) == H, "vmlmf_amd: head weight must be (classes, hidden_size)");
+      hd.classes = (int)head_w.size(0), hd.weight = head_w.data_ptr<float>(), hd.bias = cptr(head_b), hd.logits = logits.data_ptr<float>();
+    }
+    vmlmf_extra ex;
+    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = head_w.defined() ? &hd : nullptr;
+    check(vmlmf_seq_forward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),
+                               cT.data_ptr<float>(), training ? reserve.data_ptr() : nullptr, ws.data_ptr(), sz.workspace_bytes,
+                               stream_of(x), &ex));
     if (training) {
       variable_list saved = {x, y, reserve};
       for (auto& p : params) saved.push_back(p);
@@ -132,6 +145,9 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       if (c0.defined()) saved.push_back(c0);
       if (packed.defined()) saved.push_back(packed);
       ctx->saved_data["packed"] = packed.defined();
+      if (head_w.defined()) saved.push_back(head_w);
+      ctx->saved_data["head"] = head_w.defined();
+      ctx->saved_data["head_b"] = head_b.defined();
       ctx->save_for_backward(saved);
       ctx->saved_data["np"] = (int64_t)params.size();
       ctx->saved_data["h0"] = h0.defined();
@@ -139,7 +155,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       ctx->saved_data["cfg"] = std::vector<int64_t>{variant, g, w_rank, time_major ? 1 : 0, B, T, I, H, dtype};
       ctx->saved_data["ur"] = u_ranks;
     }
-    return {y, hT, cT};
+    return {y, hT, cT, logits};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list gout) {
@@ -155,6 +171,9 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     size_t k = 3 + np;
     Tensor h0 = has_h0 ? saved[k++] : Tensor(), c0 = has_c0 ? saved[k++] : Tensor();
     Tensor packed = ctx->saved_data["packed"].toBool() ? saved[k++] : Tensor();
+    Tensor head_w = ctx->saved_data["head"].toBool() ? saved[k++] : Tensor();
+    const bool has_head_b = ctx->saved_data["head_b"].toBool();
+    Tensor dlogits = (head_w.defined() && gout.size() > 3 && gout[3].defined()) ? gout[3].contiguous() : Tensor();
     Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
     Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
     Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
@@ -180,27 +199,45 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     vmlmf_grads gs;
     fill_params(ps, params, (int)variant, (int)g);
     fill_params(gs, grads, (int)variant, (int)g);
-    check(vmlmf_seq_backward_packed(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(),
-                                    cptr(dy), cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(),
-                                    sz.workspace_bytes, stream_of(x), packed.defined() ? packed.data_ptr() : nullptr));
+    // classifier gradients: weight and bias share one allocation (contiguous for the data-parallel all-reduce)
+    Tensor hflat, dW, db;
+    vmlmf_head hd;
+    memset(&hd, 0, sizeof(hd));
+    if (dlogits.defined()) {
+      const int64_t C = head_w.size(0);
+      hflat = at::empty({C * H + C}, x.options());
+      dW = hflat.narrow(0, 0, C * H).view({C, H});
+      if (has_head_b) db = hflat.narrow(0, C * H, C);
+      hd.classes = (int)C, hd.weight = head_w.data_ptr<float>(), hd.dlogits = dlogits.data_ptr<float>();
+      hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
+    }
+    vmlmf_extra ex;
+    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = dlogits.defined() ? &hd : nullptr;
+    check(vmlmf_seq_backward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(),
+                                cptr(dy), cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(),
+                                sz.workspace_bytes, stream_of(x), &ex));
     variable_list out = {dx, dh0, dc0};
     for (auto& gt : grads) out.push_back(gt);
     for (int i = 0; i < 8; ++i) out.push_back(Tensor());   // the integer configuration and the kept parameter images
+    out.push_back(dW);                                     // head weight, head bias
+    out.push_back(db);
     return out;
   }
 };
 
-std::tuple<Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::optional<Tensor>& h0, const c10::optional<Tensor>& c0,
+std::tuple<Tensor, Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::optional<Tensor>& h0, const c10::optional<Tensor>& c0,
                                             at::TensorList params, int64_t variant, int64_t g, int64_t w_rank,
                                             at::IntArrayRef u_ranks, bool time_major, int64_t dtype,
-                                            const c10::optional<Tensor>& packed) {
+                                            const c10::optional<Tensor>& packed, const c10::optional<Tensor>& head_w,
+                                            const c10::optional<Tensor>& head_b) {
   // grad mode is off inside Function::forward: whether the tape is needed is decided here (False under torch.no_grad():
   // inference kernels, no reserve buffer)
   bool training = x.requires_grad() || (h0.has_value() && h0->requires_grad()) || (c0.has_value() && c0->requires_grad());
   for (const auto& p : params) training = training || p.requires_grad();
+  training = training || (head_w.has_value() && head_w->requires_grad()) || (head_b.has_value() && head_b->requires_grad());
   training = training && at::GradMode::is_enabled();
-  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed);
-  return {out[0], out[1], out[2]};
+  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed, head_w, head_b);
+  return {out[0], out[1], out[2], out[3]};
 }
 
 // ---- classifier head ---------------------------------------------------------------------------------------------
@@ -294,7 +331,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 }  // namespace
 
 TORCH_LIBRARY(vmlmf, m) {
-  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed) -> (Tensor, Tensor, Tensor)");
+  m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }

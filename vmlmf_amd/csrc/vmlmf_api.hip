@@ -221,7 +221,7 @@ struct Layout {
   // forward workspace  : PACK (inference only) | gx
   long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_headdh, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
@@ -267,6 +267,7 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   }
   L.b_xq = o, o += align64(g.rb ? q.xq_floats : 0);
   L.b_flag = o, o += align64(g.rb ? q.flag_words : 0);
+  L.b_headdh = o, o += align64((g.rb || g.generic) ? (long long)g.B * g.H : 0);   // d(hT) of a classifier on the row-block / step-wise families
   L.b_total = o;
   return L;
 }
@@ -386,6 +387,23 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
 int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
                              const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                              size_t workspace_bytes, void* stream, const void* packed) {
+  vmlmf_extra ex;
+  ex.packed = packed, ex.head = nullptr;
+  return vmlmf_seq_forward_ex(d, p, x, h0, c0, y, hT, cT, reserve, workspace, workspace_bytes, stream, &ex);
+}
+
+static int check_head(const VGeo& g, const vmlmf_head* hd, bool fwd) {
+  if (hd == nullptr || hd->classes == 0) return 0;
+  if (hd->classes < 0 || hd->classes > head_max_classes()) return fail(VMLMF_E_UNSUPPORTED, "head: 1..32 classes");
+  if (hd->weight == nullptr || (fwd ? hd->logits == nullptr : hd->dlogits == nullptr)) return fail(VMLMF_E_BADARG, "head: null pointer");
+  return 0;
+}
+
+int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                         const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
+                         size_t workspace_bytes, void* stream, const vmlmf_extra* ex) {
+  const void* packed = ex != nullptr ? ex->packed : nullptr;
+  const vmlmf_head* head = (ex != nullptr && ex->head != nullptr && ex->head->classes != 0) ? ex->head : nullptr;
   VGeo g;
   RbGeo q;
   int rc = make_geo(d, &g, &q);
@@ -393,6 +411,11 @@ int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const f
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "null x / y / workspace");
   if (g.training && reserve == nullptr) return fail(VMLMF_E_BADARG, "training forward needs a reserve buffer");
+  if ((rc = check_head(g, head, true)) != 0) return rc;
+  // the classifier rides inside the VALU recurrent kernels; the other families run the stand-alone head kernel after
+  // their recurrence (same values up to summation order)
+  const bool head_inside = head != nullptr && !g.rb && !g.generic;
+  if (head != nullptr && !head_inside && hT == nullptr) return fail(VMLMF_E_BADARG, "head on this layer needs the hT output");
   const VPack P = vg_pack_layout(g, q.total);
   const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.f_total * sizeof(float))
@@ -429,8 +452,16 @@ int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const f
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
     io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag);
-    Scope sc(2, s);
-    return hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd");
+    {
+      Scope sc(2, s);
+      if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
+    }
+    if (head != nullptr) {
+      Scope sc(8, s);
+      const hipError_t e = launch_head_fwd(g.B, g.H, head->classes, hT, g.H, head->weight, head->bias, head->logits, s);
+      if (e != hipSuccess) return hip_fail((int)e, "head_fwd");
+    }
+    return 0;
   }
   if (g.generic) {
     GenericBuf w;
@@ -446,8 +477,16 @@ int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const f
       rc = (int)hipMemsetAsync(ws + L.f_zeros, 0, sizeof(float) * (size_t)g.B * g.H, s);
       if (rc != 0) return hip_fail(rc, "memset");
     }
-    Scope sc(2, s);
-    return hip_fail(generic_forward(g, w, s), "generic_forward");
+    {
+      Scope sc(2, s);
+      if ((rc = hip_fail(generic_forward(g, w, s), "generic_forward")) != 0) return rc;
+    }
+    if (head != nullptr) {
+      Scope sc(8, s);
+      const hipError_t e = launch_head_fwd(g.B, g.H, head->classes, hT, g.H, head->weight, head->bias, head->logits, s);
+      if (e != hipSuccess) return hip_fail((int)e, "head_fwd");
+    }
+    return 0;
   }
   FwdArgs a;
   a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
@@ -457,6 +496,8 @@ int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const f
   a.Qs = g.training ? rs + L.r_Qs : nullptr;
   XwArgs xw;
   xw.x = x, xw.UXP = pack + P.UXP, xw.WXD = pack + P.WXD, xw.BBT = pack + P.BBT;
+  memset(&xw.hd, 0, sizeof(xw.hd));
+  if (head_inside) xw.hd.W = head->weight, xw.hd.bias = head->bias, xw.hd.logits = head->logits, xw.hd.C = head->classes;
   a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
   {
     Scope sc(2, s);
@@ -478,6 +519,18 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
                               const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
                               const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
                               const void* packed) {
+  vmlmf_extra ex;
+  ex.packed = packed, ex.head = nullptr;
+  return vmlmf_seq_backward_ex(d, p, x, h0, c0, y, reserve, dy, dhT, dcT, dx, dh0, dc0, gr, workspace, workspace_bytes, stream, &ex);
+}
+
+int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
+                          const float* c0, const float* y, const void* reserve, const float* dy,
+                          const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
+                          const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
+                          const vmlmf_extra* ex) {
+  const void* packed = ex != nullptr ? ex->packed : nullptr;
+  const vmlmf_head* head = (ex != nullptr && ex->head != nullptr && ex->head->classes != 0) ? ex->head : nullptr;
   VGeo g;
   RbGeo q;
   int rc = make_geo(d, &g, &q);
@@ -486,6 +539,8 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
   if (x == nullptr || y == nullptr || reserve == nullptr || workspace == nullptr || gr == nullptr)
     return fail(VMLMF_E_BADARG, "null x / y / reserve / workspace / grads");
   if ((rc = check_pointers(g, gr, "grads")) != 0) return rc;
+  if ((rc = check_head(g, head, false)) != 0) return rc;
+  const bool head_inside = head != nullptr && !g.rb && !g.generic;
   const VPack P = vg_pack_layout(g, q.total);
   const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.b_total * sizeof(float))
@@ -493,6 +548,23 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const float* rs = (const float*)reserve;
+  // final hidden state of the layer = last time slice of y
+  const float* hlast = y + (size_t)(g.T - 1) * g.syT;
+  HeadBwd hb;
+  memset(&hb, 0, sizeof(hb));
+  if (head != nullptr && !head_inside) {
+    // stand-alone head kernel: dh into scratch, which then is the dhT of the recurrence
+    if (dhT != nullptr) return fail(VMLMF_E_UNSUPPORTED, "head together with an explicit dhT: only on the VALU recurrent kernels");
+    float* tmp = ws + L.b_headdh;
+    Scope sc(9, s);
+    const hipError_t e = launch_head_bwd(g.B, g.H, head->classes, hlast, g.syB, head->weight, head->dlogits, tmp, head->dweight,
+                                         head->dbias, s);
+    if (e != hipSuccess) return hip_fail((int)e, "head_bwd");
+    dhT = tmp;
+  } else if (head_inside) {
+    hb.W = head->weight, hb.dl = head->dlogits, hb.hlast = hlast, hb.ldh = g.syB, hb.dW = head->dweight, hb.db = head->dbias;
+    hb.C = head->classes;
+  }
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -542,6 +614,7 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
   a.gates = rs + L.r_gates, a.cs = rs + L.r_cs, a.c0 = c0, a.dy = dy, a.dhT = dhT, a.dcT = dcT;
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
   a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
+  a.hd = hb;
   {
     Scope sc(3, s);
     if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
@@ -571,7 +644,7 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
   for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   {
     Scope sc(7, s);
-    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, s), "finish")) != 0) return rc;
+    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s), "finish")) != 0) return rc;
   }
   return 0;
 }

@@ -3,6 +3,21 @@
 #include <hip/hip_runtime.h>
 #include "vmlmf_device.h"
 
+// Classifier riding on a layer (Net.lin on the final hidden state, vmlmf.py:345,353-355): logits in the epilogue of the
+// forward recurrence, d(hT) = dlogits W in the prologue of the backward one, dW / db among finish_kernel's outputs.  C = 0: none.
+struct HeadFwd {
+  const float *W, *bias;   // (C,H), (C) or NULL
+  float* logits;           // (B,C)
+  int C, pad;
+};
+struct HeadBwd {
+  const float *W, *dl;     // (C,H), dlogits (B,C)
+  const float* hlast;      // final hidden state: row b at hlast + b * ldh
+  float *dW, *db;          // (C,H), (C); may be NULL
+  long long ldh;
+  int C, pad;
+};
+
 struct FwdArgs {
   const float *gx, *VE, *UR, *EH, *h0, *c0;
   float *y, *hT, *cT, *gates, *cs, *Qs;
@@ -14,11 +29,13 @@ struct FwdArgs {
 // from the kernel-argument segment, so it costs the recurrent waves no registers)
 struct XwArgs {
   const float *x, *UXP, *WXD, *BBT;
+  HeadFwd hd;   // read from the kernel-argument segment by the epilogue only
 };
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
   float *dpre, *dQs, *dh0, *dc0;
   float* trash;
+  HeadBwd hd;   // read from the kernel-argument segment by the prologue only
 };
 struct WgxArgs {
   const float *dpre, *VRX, *UXO, *EXI;
@@ -71,7 +88,7 @@ int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s);
-int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s);
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s);
 
 // classifier head (vmlmf_head.hip)
 int head_max_classes();

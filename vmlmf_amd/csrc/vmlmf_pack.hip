@@ -396,8 +396,38 @@ __device__ __forceinline__ float* vx_dest(const VGeo& g, const RefG& o, long lon
   return o.v_x + e;
 }
 
-__global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o) {
+__global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o, HeadBwd hd,
+                                                     long long nbody) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
+  {
+    // classifier gradients (HeadBwd) ride at the end of the grid: dW[c][n] = sum_b dlogits[b][c] hT[b][n], db[c] = sum_b
+    // dlogits[b][c], each a fixed-order sum over the batch (four independent chains)
+    const long long eh = (long long)blockIdx.x * blockDim.x + threadIdx.x - nbody;
+    if (eh >= 0) {
+      if (hd.C <= 0 || eh >= (long long)hd.C * H + hd.C) return;
+      const bool isb = eh >= (long long)hd.C * H;
+      const int c = isb ? (int)(eh - (long long)hd.C * H) : (int)(eh / H), n = isb ? 0 : (int)(eh % H);
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int b0 = 0; b0 < g.B; b0 += 16) {   // 32 independent loads per pass (clamped), then the FMAs
+        float dv[16], hv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int b = b0 + j < g.B ? b0 + j : g.B - 1;
+          dv[j] = hd.dl[(size_t)b * hd.C + c];
+          hv[j] = hd.hlast[(size_t)b * hd.ldh + n];
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s[j & 3] = fmaf(b0 + j < g.B ? dv[j] : 0.f, isb ? 1.f : hv[j], s[j & 3]);
+      }
+      const float v = (s[0] + s[1]) + (s[2] + s[3]);
+      if (isb) {
+        if (hd.db != nullptr) hd.db[c] = v;
+      } else if (hd.dW != nullptr) {
+        hd.dW[(size_t)c * H + n] = v;
+      }
+      return;
+    }
+  }
   auto CG = [&](int a, int n) { return cg[(size_t)a * NT + vg_slot(g, n)]; };
   const long long n_ux = (long long)I * rw, n_vx = 4LL * H * rw, n_dx = I, n_dh = H, n_b = 4LL * H;
   const long long n_uh0 = (long long)H * g.ru0, n_vh0 = 4LL * H * g.ru0;
@@ -541,10 +571,12 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   }
 }
 
-int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, hipStream_t s) {
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s) {
   long long n = (long long)g.I * g.rw * (g.foldx ? 64 : 1) + 4LL * g.H * g.rw + g.I + g.H + 4LL * g.H;
   n += (long long)g.H * g.ru0 + 4LL * g.H * g.ru0;
   if (g.G == 2) n += (long long)g.H * g.ru1 + 4LL * g.H * g.ru1;
-  hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out);
+  const long long nbody = (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
+  const long long nhead = hd.C > 0 ? (long long)hd.C * g.H + hd.C : 0;
+  hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((nbody + nhead + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out, hd, nbody);
   return (int)hipGetLastError();
 }

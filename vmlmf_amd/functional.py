@@ -167,7 +167,7 @@ class VmlmfSeqFn(torch.autograd.Function):
     """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major, dtype)."""
 
     @staticmethod
-    def forward(ctx, cfg, packed, x, h0, c0, *params):
+    def forward(ctx, cfg, packed, x, h0, c0, head_w, head_b, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -193,20 +193,33 @@ class VmlmfSeqFn(torch.autograd.Function):
         c0c = None if c0 is None else c0.contiguous()
         ps = _params_struct(params, g, variant)
         stream = _lib.raw_stream(dev)
+        # a classifier riding on the final hidden state (Net.lin): its logits are the 4th output
+        hw = None if head_w is None else head_w.contiguous()
+        hb = None if head_b is None else head_b.contiguous()
+        logits = torch.empty((B, hw.shape[0]) if hw is not None else (0,), device=dev, dtype=torch.float32)
+        hd = _lib.Head()
+        if hw is not None:
+            _require_hip(hw, "head weight")
+            hd.classes, hd.weight, hd.logits = hw.shape[0], hw.data_ptr(), logits.data_ptr()
+            hd.bias = None if hb is None else hb.data_ptr()
+        ex = _lib.Extra()
+        ex.packed = None if packed is None else packed.data_ptr()
+        ex.head = ctypes.pointer(hd) if hw is not None else None
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().vmlmf_seq_forward_packed(
+            _lib.check(_lib.lib().vmlmf_seq_forward_ex(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
-                _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream, _ptr(packed)))
+                _ptr(cT), _ptr(reserve), _ptr(ws), sizes.workspace_bytes, stream, ctypes.byref(ex)))
         if training:
             ctx.cfg, ctx.desc, ctx.sizes = cfg, desc, sizes
             ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
+            ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
             ctx.save_for_backward(x, y, reserve, *params, *([h0c] if h0 is not None else []),
-                                  *([c0c] if c0 is not None else []))
+                                  *([c0c] if c0 is not None else []), *([hw] if hw is not None else []))
             ctx.nparams = len(params)
-        return y, hT, cT
+        return y, hT, cT, logits
 
     @staticmethod
-    def backward(ctx, dy, dhT, dcT):
+    def backward(ctx, dy, dhT, dcT, dlogits):
         variant, g, w_rank, u_ranks, time_major, _ = ctx.cfg
         saved = ctx.saved_tensors
         x, y, reserve = saved[0], saved[1], saved[2]
@@ -214,12 +227,13 @@ class VmlmfSeqFn(torch.autograd.Function):
         rest = list(saved[3 + ctx.nparams:])
         h0 = rest.pop(0) if ctx.has_h0 else None
         c0 = rest.pop(0) if ctx.has_c0 else None
+        hw = rest.pop(0) if ctx.has_head else None
         dev = x.device
         desc, sizes = ctx.desc, ctx.sizes
         dy = None if dy is None else dy.contiguous()
         dhT = None if dhT is None else dhT.contiguous()
         dcT = None if dcT is None else dcT.contiguous()
-        need_dx = ctx.needs_input_grad[2]
+        need_dx = ctx.needs_input_grad[2]   # (cfg, packed, x, h0, c0, head_w, head_b, *params)
         dx = torch.empty_like(x) if need_dx else None
         B, H = y.shape[1 if time_major else 0], y.shape[2]
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
@@ -236,21 +250,38 @@ class VmlmfSeqFn(torch.autograd.Function):
         ps = _params_struct(params, g, variant)
         gs = _params_struct(grads, g, variant)
         stream = _lib.raw_stream(dev)
+        dW = db = None
+        hd = _lib.Head()
+        use_head = hw is not None and dlogits is not None
+        if use_head:
+            dl = dlogits.contiguous()
+            C = hw.shape[0]
+            hflat = torch.empty(C * H + C, device=dev, dtype=torch.float32)   # weight + bias gradients in one allocation
+            dW = hflat[:C * H].view(C, H)
+            db = hflat[C * H:] if ctx.has_head_b else None
+            hd.classes, hd.weight, hd.dlogits, hd.dweight = C, hw.data_ptr(), dl.data_ptr(), dW.data_ptr()
+            hd.dbias = None if db is None else db.data_ptr()
+        ex = _lib.Extra()
+        ex.packed = None if ctx.packed is None else ctx.packed.data_ptr()
+        ex.head = ctypes.pointer(hd) if use_head else None
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().vmlmf_seq_backward_packed(
+            _lib.check(_lib.lib().vmlmf_seq_backward_ex(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
                 _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
-                _ptr(ws), sizes.workspace_bytes, stream, _ptr(ctx.packed)))
-        return (None, None, dx, dh0, dc0) + grads
+                _ptr(ws), sizes.workspace_bytes, stream, ctypes.byref(ex)))
+        return (None, None, dx, dh0, dc0, dW, db) + grads
 
 
-def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", pack_cache=None):
+def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", pack_cache=None,
+                   head=None):
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
     each in the reference's layout (the cells without vm: see the table at the top of this file).
     dtype: "f32" (the reference's arithmetic) or "bf16" (bf16 MFMA with fp32 accumulation and state, bf16 tapes; all
     tensors stay float32 - include/vmlmf_hip.h: vmlmf_desc.dtype).  Returns (y, hT, cT).
+    head: (weight (C, H), bias (C) or None) of a classifier on the layer's final hidden state (Net.lin); the call then
+    returns (y, hT, cT, logits) and neither the logits nor their backward cost a launch of their own on the VALU kernels.
     """
     dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     packed = None
@@ -261,9 +292,13 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     ops = torch_ops()
     if ops is not None:
-        return ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt, packed)
+        out = ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt, packed,
+                           None if head is None else head[0], None if head is None else head[1])
+        return out if head is not None else out[:3]
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
-    return VmlmfSeqFn.apply(cfg, packed, x, h0, c0, *params)
+    out = VmlmfSeqFn.apply(cfg, packed, x, h0, c0, None if head is None else head[0], None if head is None else head[1],
+                           *params)
+    return out if head is not None else out[:3]
 
 
 class HeadLinearFn(torch.autograd.Function):
