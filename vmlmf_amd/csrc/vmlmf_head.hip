@@ -186,16 +186,18 @@ namespace {
 // Four lanes share a row (classes c = q, q + 4, ...: the loads of a row are independent and issued together, the row
 // maximum and sum meet through two quad shuffles), 64 rows per pass of the single workgroup.  CQ = classes per lane
 // held in registers (rows up to 4 CQ wide); wider rows re-read z (L1-resident) instead.
+constexpr int CE_T = 1024;   // one workgroup of 16 waves: 256 rows per pass (the row loop is a chain of memory latencies:
+                             // with 256 threads, 64 rows per pass, the kernel took 32 us at B = 512)
 template <int CQ>
-__global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* __restrict__ z,
+__global__ __launch_bounds__(CE_T) void ce_fwd_kernel(int B, int C, const float* __restrict__ z,
                                                      const long long* __restrict__ tgt, long long ignore_index,
                                                      float* __restrict__ loss, float* __restrict__ lse,
                                                      float* __restrict__ nvalid, float* __restrict__ dz_unit) {
-  __shared__ float ssum[256];
-  __shared__ float scnt[256];
+  __shared__ float ssum[CE_T];
+  __shared__ float scnt[CE_T];
   const int q = threadIdx.x & 3;
   float part = 0.f, cnt = 0.f;
-  for (int b0 = 0; b0 < B; b0 += 64) {
+  for (int b0 = 0; b0 < B; b0 += CE_T / 4) {
     const int b = b0 + (threadIdx.x >> 2);
     const bool rok = b < B;
     const float* zb = z + (size_t)(rok ? b : 0) * C;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* 
   ssum[threadIdx.x] = part;
   scnt[threadIdx.x] = cnt;
   __syncthreads();
-  for (int o = 128; o >= 1; o >>= 1) {   // fixed-shape tree: run-to-run identical
+  for (int o = CE_T / 2; o >= 1; o >>= 1) {   // fixed-shape tree: run-to-run identical
     if ((int)threadIdx.x < o) {
       ssum[threadIdx.x] += ssum[threadIdx.x + o];
       scnt[threadIdx.x] += scnt[threadIdx.x + o];
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void ce_fwd_kernel(int B, int C, const float* 
   // one needs no launch of its own (ce_bwd_kernel's arithmetic, same operation order)
   if (dz_unit != nullptr) {
     const float scale = 1.f / scnt[0];
-    for (int e = threadIdx.x; e < B * C; e += 256) {
+    for (int e = threadIdx.x; e < B * C; e += CE_T) {
       const int b = e / C, c = e - b * C;
       const long long t = tgt[b];
       const float p = expf(z[e] - lse[b]);   // lse[b] was written by this workgroup before the barriers above
@@ -281,9 +283,9 @@ __global__ __launch_bounds__(256) void ce_bwd_kernel(int B, int C, const float* 
 hipError_t launch_ce_fwd(int B, int C, const float* z, const long long* tgt, long long ignore_index, float* loss,
                          float* lse, float* nvalid, float* dz_unit, hipStream_t s) {
   if (C <= 32)
-    hipLaunchKernelGGL(ce_fwd_kernel<8>, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
+    hipLaunchKernelGGL(ce_fwd_kernel<8>, dim3(1), dim3(CE_T), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
   else
-    hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(1), dim3(256), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
+    hipLaunchKernelGGL(ce_fwd_kernel<0>, dim3(1), dim3(CE_T), 0, s, B, C, z, tgt, ignore_index, loss, lse, nvalid, dz_unit);
   return hipGetLastError();
 }
 

@@ -402,28 +402,43 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   {
     // classifier gradients (HeadBwd) ride at the end of the grid: dW[c][n] = sum_b dlogits[b][c] hT[b][n], db[c] = sum_b
     // dlogits[b][c], each a fixed-order sum over the batch (four independent chains)
-    const long long eh = (long long)blockIdx.x * blockDim.x + threadIdx.x - nbody;
-    if (eh >= 0) {
-      if (hd.C <= 0 || eh >= (long long)hd.C * H + hd.C) return;
-      const bool isb = eh >= (long long)hd.C * H;
-      const int c = isb ? (int)(eh - (long long)hd.C * H) : (int)(eh / H), n = isb ? 0 : (int)(eh % H);
-      float s[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int b0 = 0; b0 < g.B; b0 += 16) {   // 32 independent loads per pass (clamped), then the FMAs
-        float dv[16], hv[16];
+    // sixteen lanes per output, lane j takes the rows b = j, j + 16, ... (eight independent loads per pass), the sixteen
+    // partial sums meet in a fixed-order butterfly over the DPP row: as one thread per output the kernel took 37 us at B = 512
+    const long long th = (long long)blockIdx.x * blockDim.x + threadIdx.x - nbody;
+    if (th >= 0) {
+      const long long eh = th >> 4;
+      const int j16 = (int)(th & 15);
+      if (hd.C <= 0) return;
+      const bool live = eh < (long long)hd.C * H + hd.C;   // (whole 16-lane rows stay together for the butterfly)
+      const long long ec = live ? eh : 0;
+      const bool isb = ec >= (long long)hd.C * H;
+      const int c = isb ? (int)(ec - (long long)hd.C * H) : (int)(ec / H), n = isb ? 0 : (int)(ec % H);
+      float s0 = 0.f, s1 = 0.f;
+      for (int b0 = j16; b0 < g.B; b0 += 16 * 8) {
+        float dv[8], hv[8];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int b = b0 + j < g.B ? b0 + j : g.B - 1;
+        for (int j = 0; j < 8; ++j) {
+          const int b = b0 + 16 * j < g.B ? b0 + 16 * j : g.B - 1;
           dv[j] = hd.dl[(size_t)b * hd.C + c];
           hv[j] = hd.hlast[(size_t)b * hd.ldh + n];
         }
 #pragma unroll
-        for (int j = 0; j < 16; ++j) s[j & 3] = fmaf(b0 + j < g.B ? dv[j] : 0.f, isb ? 1.f : hv[j], s[j & 3]);
+        for (int j = 0; j < 8; j += 2) {
+          s0 = fmaf(b0 + 16 * j < g.B ? dv[j] : 0.f, isb ? 1.f : hv[j], s0);
+          s1 = fmaf(b0 + 16 * (j + 1) < g.B ? dv[j + 1] : 0.f, isb ? 1.f : hv[j + 1], s1);
+        }
       }
-      const float v = (s[0] + s[1]) + (s[2] + s[3]);
-      if (isb) {
-        if (hd.db != nullptr) hd.db[c] = v;
-      } else if (hd.dW != nullptr) {
-        hd.dW[(size_t)c * H + n] = v;
+      float v = s0 + s1;
+      v = add_ror16<8>(v);
+      v = add_ror16<4>(v);
+      v = add_ror16<2>(v);
+      v = add_ror16<1>(v);
+      if (live && j16 == 0) {
+        if (isb) {
+          if (hd.db != nullptr) hd.db[c] = v;
+        } else if (hd.dW != nullptr) {
+          hd.dW[(size_t)c * H + n] = v;
+        }
       }
       return;
     }
@@ -576,7 +591,7 @@ int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& 
   n += (long long)g.H * g.ru0 + 4LL * g.H * g.ru0;
   if (g.G == 2) n += (long long)g.H * g.ru1 + 4LL * g.H * g.ru1;
   const long long nbody = (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
-  const long long nhead = hd.C > 0 ? (long long)hd.C * g.H + hd.C : 0;
+  const long long nhead = hd.C > 0 ? 16 * ((long long)hd.C * g.H + hd.C) : 0;   // sixteen lanes per classifier output
   hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((nbody + nhead + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out, hd, nbody);
   return (int)hipGetLastError();
 }
