@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 6
+#define VMLMF_ABI_VERSION 7
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -183,6 +183,38 @@ int vmlmf_seq_backward_ex(const vmlmf_desc *d, const vmlmf_params *p, const floa
  * `g` (overwritten, reference layouts; deterministic summation order).  `reserve` and `y` must be the
  * ones the matching forward produced; `workspace` may be a different buffer.
  */
+/* ---- stacked layers in one launch per direction (ABI 7) -------------------------------------------------------
+ * The layer loop of MyLSTM.forward (V/src/models/vmlmf.py:300-314: `x = h` between the cells of a time step) and of the
+ * LM network (V/src/models/vmlmf_lm.py:437-439) as a WAVEFRONT: every layer's recurrence runs in the same launch, layer
+ * l+1 consuming the hidden states of layer l a few time steps behind it, and each layer forms its x-side products inside
+ * that launch (no x-projection / input-gradient launches, no (T,B,4H) pre-activation round trip).  Results are those of
+ * L calls of vmlmf_seq_forward / vmlmf_seq_backward chained through y (same arithmetic per element; the order of the
+ * rank-space sums differs in the last bits).
+ * Covered: 1..4 layers of one-group variants (V1, V3, V5) with equal B, T, H, ranks and layout, padded w_rank == padded
+ * u_rank, hidden_size <= 256, layer l > 0 with input_size == hidden_size.  Anything else: VMLMF_E_UNSUPPORTED from
+ * vmlmf_stack_query() - the caller then chains the per-layer calls.
+ * Per layer: desc (training flag and shapes must agree across the stack), params, optional initial / final states, the
+ * layer's output y (B,T,H or T,B,H; layer l's y is layer l+1's x) and its reserve (training).  Backward additionally:
+ * gradients of the final states (or NULL), of the initial states (or NULL) and the parameter gradients. */
+#define VMLMF_STACK_MAX 4
+typedef struct vmlmf_stack_layer {
+  vmlmf_desc desc;
+  const vmlmf_params *params;
+  const float *h0, *c0;
+  float *y, *hT, *cT;
+  void *reserve;
+  const float *dhT, *dcT;
+  float *dh0, *dc0;
+  const vmlmf_grads *grads;
+} vmlmf_stack_layer;
+/* sizes for the stack: reserve_bytes[l] per layer, one workspace for either direction */
+int vmlmf_stack_query(int L, const vmlmf_stack_layer *layers, size_t *reserve_bytes, size_t *workspace_bytes);
+int vmlmf_stack_forward(int L, const vmlmf_stack_layer *layers, const float *x, void *workspace, size_t workspace_bytes,
+                        void *stream);
+/* dy: gradient of the top layer's y (or NULL); dx: gradient of x (or NULL when not wanted) */
+int vmlmf_stack_backward(int L, const vmlmf_stack_layer *layers, const float *x, const float *dy, float *dx,
+                         void *workspace, size_t workspace_bytes, void *stream);
+
 int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
                        const float *c0, const float *y, const void *reserve, const float *dy,
                        const float *dhT, const float *dcT, float *dx, float *dh0, float *dc0,

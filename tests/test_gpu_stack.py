@@ -1,0 +1,110 @@
+"""GPU: stacked layers in one wavefront launch per direction (C ABI vmlmf_stack_*, vmlmf_wave.inc) against the chained
+per-layer calls of the same library (VMLMF_STACK=0) and against the fp64 oracle.  The reference's layer loop:
+V/src/models/vmlmf.py:300-314."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(model, x, mode, head_grad=None):
+    os.environ["VMLMF_STACK"] = mode
+    try:
+        for p in model.parameters():
+            p.grad = None
+        xx = x.clone().requires_grad_(True)
+        y, hid = model(xx)
+        loss = (y * head_grad[0]).sum() + (hid * head_grad[1]).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+        return (y.detach().clone(), hid.detach().clone(), xx.grad.clone(),
+                {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None})
+    finally:
+        os.environ.pop("VMLMF_STACK", None)
+
+
+CASES = [
+    # L, B, T, I, H, rank, cell
+    (2, 8, 5, 12, 40, 8, "vm"),
+    (2, 5, 7, 40, 40, 16, "vm"),
+    (3, 16, 9, 20, 100, 16, "vm"),
+    (2, 128, 24, 77, 256, 24, "vm"),      # BASELINE configs[2] (fp32)
+    (2, 19, 11, 9, 180, 16, "vm"),
+    (4, 3, 6, 30, 64, 24, "vm"),
+    (2, 7, 8, 33, 130, 32, "vm"),
+    (1, 9, 6, 77, 180, 8, "vm"),
+    (2, 6, 5, 24, 72, 16, "lmf"),         # MyLSTMCell in low-rank mode (variant 5)
+    (2, 300, 4, 10, 64, 8, "vm"),         # more workgroups than CUs
+]
+
+
+@pytest.mark.parametrize("L,B,T,I,H,r,kind", CASES)
+def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
+    import vmlmf_amd
+    from vmlmf_amd import functional as F
+    torch.manual_seed(1234 + L * 7 + B)
+    cell = vmlmf_amd.MyVMLMFCell if kind == "vm" else vmlmf_amd.MyLSTMCell
+    model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=r, u_ranks=r, cell=cell).cuda()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.5)       # livelier gates than the reference's init
+    x = torch.randn(B, T, I, device="cuda")
+    gy = torch.randn(B, T, H, device="cuda")
+    gh = torch.randn(B, L * H, device="cuda")
+    ref = _run(model, x, "0", (gy, gh))
+    got = _run(model, x, "1", (gy, gh))
+    # the stack really ran on the wavefront launch
+    cfg = model.rnncells[0].kernel_cfg()
+    assert F._stack_plan((cfg["variant"], 1, r, (r,), False, 0), L, B, T, I, H, True) is not None
+    for a, b, what in ((got[0], ref[0], "y"), (got[1], ref[1], "hidden"), (got[2], ref[2], "dx")):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, scale), what
+    for name, gref in ref[3].items():
+        scale = float(gref.abs().max()) + 1e-12
+        err = float((got[3][name] - gref).abs().max())
+        assert err <= 1e-4 * scale + 1e-6, (name, err, scale)
+
+
+def test_stack_inference_matches_training_forward():
+    import vmlmf_amd
+    torch.manual_seed(5)
+    model = vmlmf_amd.MyLSTM(20, hidden_layer_sizes=[96, 96], batch_first=True, w_rank=16, u_ranks=16,
+                             cell=vmlmf_amd.MyVMLMFCell).cuda()
+    x = torch.randn(12, 10, 20, device="cuda")
+    os.environ["VMLMF_STACK"] = "1"
+    try:
+        y1, h1 = model(x)
+        with torch.no_grad():
+            y2, h2 = model(x)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("VMLMF_STACK", None)
+    assert torch.equal(y1.detach(), y2) and torch.equal(h1.detach(), h2)
+
+
+def test_stack_repeats_bit_identically_under_load():
+    """The layer hand-over (progress words) must not depend on timing: the same launch repeated while a second stream keeps
+    the chip busy gives the same bits."""
+    import vmlmf_amd
+    torch.manual_seed(9)
+    model = vmlmf_amd.MyLSTM(77, hidden_layer_sizes=[256, 256], batch_first=True, w_rank=24, u_ranks=24,
+                             cell=vmlmf_amd.MyVMLMFCell).cuda()
+    x = torch.randn(128, 24, 77, device="cuda")
+    os.environ["VMLMF_STACK"] = "1"
+    try:
+        with torch.no_grad():
+            y0, h0 = model(x)
+            side = torch.cuda.Stream()
+            a = torch.randn(4096, 4096, device="cuda")
+            for i in range(6):
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        a = (a @ a).clamp_(-1, 1)
+                y, h = model(x)
+                assert torch.equal(y, y0) and torch.equal(h, h0), i
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("VMLMF_STACK", None)

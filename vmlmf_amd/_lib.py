@@ -18,7 +18,7 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
@@ -52,6 +52,17 @@ class Extra(ctypes.Structure):
     _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head))]
 
 
+class StackLayer(ctypes.Structure):
+    """vmlmf_stack_layer (ABI 7): one layer of a stack run by the wavefront launches."""
+    _fields_ = [("desc", Desc), ("params", ctypes.POINTER(Params)), ("h0", ctypes.c_void_p), ("c0", ctypes.c_void_p),
+                ("y", ctypes.c_void_p), ("hT", ctypes.c_void_p), ("cT", ctypes.c_void_p), ("reserve", ctypes.c_void_p),
+                ("dhT", ctypes.c_void_p), ("dcT", ctypes.c_void_p), ("dh0", ctypes.c_void_p), ("dc0", ctypes.c_void_p),
+                ("grads", ctypes.POINTER(Params))]
+
+
+STACK_MAX = 4
+
+
 class Sizes(ctypes.Structure):
     _fields_ = [("workspace_bytes", ctypes.c_size_t), ("reserve_bytes", ctypes.c_size_t),
                 ("rows_per_wg", ctypes.c_int32), ("threads_per_wg", ctypes.c_int32),
@@ -71,6 +82,9 @@ SYMBOLS = {
     "vmlmf_build_info": (ctypes.c_char_p, []),
     "vmlmf_last_error": (ctypes.c_char_p, []),
     "vmlmf_tune": (_i, [ctypes.c_char_p, _i]),
+    "vmlmf_stack_query": (_i, [_i, _vp, _vp, _vp]),
+    "vmlmf_stack_forward": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
+    "vmlmf_stack_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),
     "vmlmf_seq_forward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),

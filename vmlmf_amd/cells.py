@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .functional import head_linear, vmlmf_sequence
+from .functional import head_linear, vmlmf_sequence, vmlmf_stack
 
 TIME_STEPS = 128
 RECURRENT_MAX = pow(2, 1 / TIME_STEPS)
@@ -280,6 +280,17 @@ class MyLSTM(nn.Module):
         """(output sequence of the last layer, [final h of every layer]); with `head` = (weight, bias) of a classifier on the
         last layer's final hidden state also its logits (None when the last layer cannot carry it)."""
         hiddens, logits = [], None
+        # every layer in one wavefront launch per direction when the stack is covered (same cell type and sizes above the
+        # first layer; include/vmlmf_hip.h: vmlmf_stack_*); a classifier then runs as its own (head) kernels
+        cells = list(self.rnncells)
+        if (x.is_cuda and all(type(c) is type(cells[0]) and hasattr(c, "kernel_cfg") for c in cells)
+                and len(set(self.hidden_layer_sizes)) == 1 and getattr(cells[0], "low_rank", True)):
+            cfg = cells[0].kernel_cfg()
+            cfg.pop("pack_cache", None)
+            if all({k: v for k, v in c.kernel_cfg().items() if k != "pack_cache"} == cfg for c in cells[1:]):
+                out = vmlmf_stack(x=x, layer_params=[c.kernel_params() for c in cells], time_major=not self.batch_first, **cfg)
+                if out is not None:
+                    return (out[0], out[1], None) if head is not None else (out[0], out[1])
         for i, cell in enumerate(self.rnncells):
             fused = hasattr(cell, "sequence") and (not isinstance(cell, MyLSTMCell) or (cell.low_rank and x.is_cuda))
             if fused and head is not None and i == len(self.rnncells) - 1:

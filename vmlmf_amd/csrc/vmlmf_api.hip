@@ -305,6 +305,33 @@ int hip_fail(int rc, const char* what) {
   return fail(rc, std::string(what) + ": " + hipGetErrorString((hipError_t)rc));
 }
 
+// the batched half of a layer's backward: every weight gradient (MFMA products over all rows), their fixed-order sum, and
+// the reference-layout gradients
+static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
+                         const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s) {
+  int rc;
+  WghArgs wh;
+  wh.dpre = ws + L.b_dpre, wh.x = x, wh.y = y, wh.h0 = h0, wh.qx = rs + L.r_qx, wh.dqx = ws + L.b_dqx;
+  wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs, wh.wpart = ws + L.b_wpart;
+  {
+    Scope sc(5, s);
+    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
+  }
+  {
+    Scope sc(6, s);
+    if ((rc = hip_fail(launch_reduce(g, ws + L.b_wpart, ws + L.b_cgrad, s), "reduce")) != 0) return rc;
+  }
+  RefG og;
+  og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
+  og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+  for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
+  {
+    Scope sc(7, s);
+    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s), "finish")) != 0) return rc;
+  }
+  return 0;
+}
+
 }  // namespace
 
 // error text for the other translation units of the C ABI (vmlmf_comm.cpp)
@@ -627,24 +654,191 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  WghArgs wh;
-  wh.dpre = ws + L.b_dpre, wh.x = x, wh.y = y, wh.h0 = h0, wh.qx = rs + L.r_qx, wh.dqx = ws + L.b_dqx;
-  wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs, wh.wpart = ws + L.b_wpart;
-  {
-    Scope sc(5, s);
-    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
+  return backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s);
+}
+
+
+// ---- stacked layers: wavefront launches (vmlmf_wave.inc) ----
+namespace {
+// VMLMF_WF_BWD=0: the stack's backward chains the per-layer kernels (A/B runs and bring-up); the forward is the wavefront
+// launch either way
+const bool g_wf_bwd = []() { const char* e = getenv("VMLMF_WF_BWD"); return e == nullptr || e[0] != '0'; }();
+
+struct StackPlan {
+  int L;
+  VGeo g[WF_MAXL];
+  VPack P[WF_MAXL];
+  WfPack W;
+  Layout lay[WF_MAXL];
+  long long ws_flag, ws_layer[WF_MAXL], ws_dx[WF_MAXL], ws_total;   // float offsets in the workspace
+  long long flag_words;
+};
+
+static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
+  if (ly == nullptr) return fail(VMLMF_E_BADARG, "stack: null layers");
+  if (L < 1 || L > WF_MAXL) return fail(VMLMF_E_UNSUPPORTED, "stack: 1..4 layers");
+  StackPlan& S = *out;
+  S.L = L;
+  for (int l = 0; l < L; ++l) {
+    RbGeo q;
+    const int rc = make_geo(&ly[l].desc, &S.g[l], &q);
+    if (rc != 0) return rc;
+    const VGeo& g = S.g[l];
+    if (!wf_supported(g))
+      return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (one group, padded w_rank == padded u_rank, "
+                                       "hidden_size <= 256, fp32)");
+    if (l > 0) {
+      const VGeo& g0 = S.g[0];
+      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.ru0 != g0.ru0 || g.rw != g0.rw ||
+          g.time_major != g0.time_major || g.training != g0.training)
+        return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, H, ranks, layout and training flag");
+      if (g.I != g.H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: input_size must equal hidden_size");
+    }
   }
-  {
-    Scope sc(6, s);
-    if ((rc = hip_fail(launch_reduce(g, ws + L.b_wpart, ws + L.b_cgrad, s), "reduce")) != 0) return rc;
+  S.W = wf_pack_layout(S.g[0]);
+  long long o = 0;
+  S.flag_words = ((long long)(L > 1 ? L - 1 : 0) * S.g[0].B + 1) * WF_FLAG_STRIDE;
+  S.ws_flag = o, o += align64(S.flag_words);
+  RbGeo q0;
+  memset(&q0, 0, sizeof(q0));
+  for (int l = 0; l < L; ++l) {
+    S.P[l] = vg_pack_layout(S.g[l], 0, S.W.total);
+    S.lay[l] = make_layout(S.g[l], S.P[l], q0);
+    const long long per = S.lay[l].f_total > S.lay[l].b_total ? S.lay[l].f_total : S.lay[l].b_total;
+    S.ws_layer[l] = o, o += align64(per);
+    S.ws_dx[l] = o, o += align64(l > 0 ? (long long)S.g[0].T * S.g[0].B * S.g[0].H : 0);   // dx of layer l = dy of layer l - 1
   }
-  RefG og;
-  og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
-  og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
-  for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
+  S.ws_total = o;
+  return 0;
+}
+}  // namespace
+
+int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_bytes, size_t* workspace_bytes) {
+  StackPlan S;
+  const int rc = stack_plan(L, layers, &S);
+  if (rc != 0) return rc;
+  for (int l = 0; l < L; ++l)
+    if (reserve_bytes != nullptr) reserve_bytes[l] = (size_t)S.lay[l].r_total * sizeof(float);
+  if (workspace_bytes != nullptr) *workspace_bytes = (size_t)S.ws_total * sizeof(float);
+  return 0;
+}
+
+int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void* workspace, size_t workspace_bytes,
+                        void* stream) {
+  StackPlan S;
+  int rc = stack_plan(L, ly, &S);
+  if (rc != 0) return rc;
+  if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
+  if (workspace_bytes < (size_t)S.ws_total * sizeof(float)) return fail(VMLMF_E_WORKSPACE, "stack: workspace smaller than vmlmf_stack_query() reported");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const bool training = S.g[0].training != 0;
+  WfFwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+  for (int l = 0; l < L; ++l) {
+    const VGeo& g = S.g[l];
+    if ((rc = check_params(g, ly[l].params)) != 0) return rc;
+    if (ly[l].y == nullptr) return fail(VMLMF_E_BADARG, "stack: null y");
+    if (training && ly[l].reserve == nullptr) return fail(VMLMF_E_BADARG, "stack: training forward needs the layers' reserve buffers");
+    float* rs = (float*)ly[l].reserve;
+    const Layout& Lr = S.lay[l];
+    float* pack = training ? rs + Lr.r_pack : ws + S.ws_layer[l] + Lr.f_pack;
+    const RefP rp = to_refp(ly[l].params);
+    {
+      Scope sc(0, s);
+      if ((rc = hip_fail(launch_pack(g, rp, S.P[l], pack, s), "pack")) != 0) return rc;
+      if ((rc = hip_fail(launch_wf_pack(g, rp, S.W, pack + S.P[l].WF, s), "wf_pack")) != 0) return rc;
+    }
+    WfFwdLayer& w = a.l[l];
+    w.x = l == 0 ? x : ly[l - 1].y;
+    w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
+    w.VE = pack + S.P[l].VE, w.EH = pack + S.P[l].EH, w.VXT = pack + S.P[l].VXT, w.EXT = pack + S.P[l].EXT, w.BBT = pack + S.P[l].BBT;
+    w.UR = pack + S.P[l].WF + S.W.UR, w.URX = pack + S.P[l].WF + S.W.URX;
+    w.h0 = ly[l].h0, w.c0 = ly[l].c0, w.y = ly[l].y, w.hT = ly[l].hT, w.cT = ly[l].cT;
+    w.gates = training ? rs + Lr.r_gates : nullptr, w.cs = training ? rs + Lr.r_cs : nullptr;
+    w.Qs = training ? rs + Lr.r_Qs : nullptr, w.qx = training ? rs + Lr.r_qx : nullptr;
+  }
+  if (L > 1 && (rc = (int)hipMemsetAsync(ws + S.ws_flag, 0, sizeof(float) * (size_t)S.flag_words, s)) != 0) return hip_fail(rc, "memset");
   {
-    Scope sc(7, s);
-    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s), "finish")) != 0) return rc;
+    Scope sc(2, s);
+    if ((rc = hip_fail(launch_wf_fwd(S.g[0], a, s), "wf_fwd")) != 0) return rc;
+  }
+  return 0;
+}
+
+int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, const float* dy, float* dx, void* workspace,
+                         size_t workspace_bytes, void* stream) {
+  StackPlan S;
+  int rc = stack_plan(L, ly, &S);
+  if (rc != 0) return rc;
+  if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
+  if (workspace_bytes < (size_t)S.ws_total * sizeof(float)) return fail(VMLMF_E_WORKSPACE, "stack: workspace smaller than vmlmf_stack_query() reported");
+  hipStream_t s = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  for (int l = 0; l < L; ++l) {
+    if ((rc = check_params(S.g[l], ly[l].params)) != 0) return rc;
+    if ((rc = check_pointers(S.g[l], ly[l].grads, "grads")) != 0) return rc;
+    if (ly[l].y == nullptr || ly[l].reserve == nullptr) return fail(VMLMF_E_BADARG, "stack: null y / reserve");
+  }
+  HeadBwd hb;
+  memset(&hb, 0, sizeof(hb));
+  const bool wave = g_wf_bwd && wf_bwd_built();
+  if (wave) {
+    WfBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+    for (int l = 0; l < L; ++l) {
+      const VGeo& g = S.g[l];
+      const Layout& Lr = S.lay[l];
+      const float* rs = (const float*)ly[l].reserve;
+      const float* pack = rs + Lr.r_pack;
+      float* wl = ws + S.ws_layer[l];
+      WfBwdLayer& w = a.l[l];
+      w.gates = rs + Lr.r_gates, w.cs = rs + Lr.r_cs;
+      w.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
+      w.dhT = ly[l].dhT, w.dcT = ly[l].dcT, w.dh0 = ly[l].dh0, w.dc0 = ly[l].dc0;
+      w.UE = pack + S.P[l].UE, w.EH = pack + S.P[l].EH, w.UXO = pack + S.P[l].UXO, w.EXI = pack + S.P[l].EXI;
+      w.VR = pack + S.P[l].WF + S.W.VR, w.VRX = pack + S.P[l].WF + S.W.VRX;
+      w.dpre = wl + Lr.b_dpre, w.dQs = wl + Lr.b_dQs, w.dqx = wl + Lr.b_dqx;
+      w.dx = l == 0 ? dx : ws + S.ws_dx[l];
+      w.want_dx = w.dx != nullptr ? 1 : 0;
+      w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
+    }
+    if (L > 1 && (rc = (int)hipMemsetAsync(ws + S.ws_flag, 0, sizeof(float) * (size_t)S.flag_words, s)) != 0) return hip_fail(rc, "memset");
+    {
+      Scope sc(3, s);
+      if ((rc = hip_fail(launch_wf_bwd(S.g[0], a, s), "wf_bwd")) != 0) return rc;
+    }
+  }
+  for (int l = L - 1; l >= 0; --l) {
+    const VGeo& g = S.g[l];
+    const Layout& Lr = S.lay[l];
+    const VPack& P = S.P[l];
+    const float* rs = (const float*)ly[l].reserve;
+    const float* pack = rs + Lr.r_pack;
+    float* wl = ws + S.ws_layer[l];
+    const float* xl = l == 0 ? x : ly[l - 1].y;
+    if (!wave) {   // the per-layer kernels, chained through the dx buffers
+      BwdArgs b;
+      b.gates = rs + Lr.r_gates, b.cs = rs + Lr.r_cs, b.c0 = ly[l].c0, b.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
+      b.dhT = ly[l].dhT, b.dcT = ly[l].dcT;
+      b.VR = pack + P.VR, b.UE = pack + P.UE, b.EH = pack + P.EH;
+      b.dpre = wl + Lr.b_dpre, b.dQs = wl + Lr.b_dQs, b.dh0 = ly[l].dh0, b.dc0 = ly[l].dc0, b.trash = wl + Lr.b_trash;
+      b.hd = hb;
+      {
+        Scope sc(3, s);
+        if ((rc = hip_fail(launch_rec_bwd(g, b, s), "rec_bwd")) != 0) return rc;
+      }
+      WgxArgs wx;
+      wx.dpre = wl + Lr.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
+      wx.dx = l == 0 ? dx : ws + S.ws_dx[l], wx.dqx = wl + Lr.b_dqx;
+      if (!(g.foldx && wx.dx == nullptr)) {
+        Scope sc(4, s);
+        if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
+      }
+    }
+    if ((rc = backward_tail(g, Lr, ly[l].params, ly[l].grads, xl, ly[l].y, ly[l].h0, rs, wl, hb, s)) != 0) return rc;
   }
   return 0;
 }

@@ -56,7 +56,8 @@ struct VPack {
   long long UD, VD, UDT, VDT, VXTT;   // dense group factors + V_x^T, step-wise path only
   long long TKT;                      // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
   long long WXD;                      // dense x-side matrix W_x[m][k][slot] of the x-projection wave (I <= 16 only)
-  long long RB, total;                // A-operand images of the row-block kernels (RbGeo offsets are relative to RB)
+  long long RB;                       // A-operand images of the row-block kernels (RbGeo offsets are relative to RB)
+  long long WF, total;                // rotated images of the wavefront kernels (WfPack offsets are relative to WF)
 };
 
 #ifdef __HIPCC__
@@ -75,7 +76,7 @@ VG_HD int vg_pad8(int v) { return (v + 7) / 8 * 8; }
 VG_HD bool vg_xwave_ok(const VGeo& g) { return !g.generic && !g.rb && !g.flat && g.R == 1 && g.NT <= 192 && g.I <= 16; }
 
 // rb_floats: RbGeo::total of the layer (0 without the row-block kernels)
-VG_HD VPack vg_pack_layout(const VGeo& g, long long rb_floats = 0) {
+VG_HD VPack vg_pack_layout(const VGeo& g, long long rb_floats = 0, long long wf_floats = 0) {
   VPack p;
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
@@ -102,6 +103,7 @@ VG_HD VPack vg_pack_layout(const VGeo& g, long long rb_floats = 0) {
   p.TKT = take(g.generic ? VG_GEMM_TICKETS : 0);
   p.WXD = take(vg_xwave_ok(g) ? 4LL * g.I * g.NT : 0);
   p.RB = take(g.rb ? rb_floats : 0);
+  p.WF = take(wf_floats);
   p.total = o;
   return p;
 }

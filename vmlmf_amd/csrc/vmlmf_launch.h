@@ -108,5 +108,51 @@ hipError_t launch_nll_fwd(int R, int V, const float* scores, const long long* y,
 hipError_t launch_nll_bwd(int R, int V, const float* scores, const long long* y, float scale, const float* lse,
                           const float* dloss, float* dscores, hipStream_t s);
 
+// ---- wavefront kernels for stacked layers (vmlmf_wave.inc) ----
+// One launch runs every layer of a stack: workgroup = (layer, batch row).  Besides the recurrence's compute waves a
+// workgroup has an "x-team" of as many waves that forms the layer's x-side pre-activations in-kernel (forward) / the
+// gradient of the layer's input (backward), so a layer above the first consumes the rows of the layer below as that one
+// produces them (progress words in L2), a few steps behind.
+constexpr int WF_MAXL = 4;          // layers per launch
+constexpr int WF_FLAG_STRIDE = 32;  // unsigned words between two progress words (one 128-byte line each)
+struct WfPack {                     // float offsets inside the WF region of PACK (images with the half-pass layout)
+  long long UR, VR, URX, VRX, total;
+};
+struct WfFwdLayer {
+  const float* x;                   // input rows of the layer (above the first: the y of the layer below)
+  const float *VE, *EH, *VXT, *EXT, *BBT;   // pack_kernel images
+  const float *UR, *URX;            // wf_pack_kernel images
+  const float *h0, *c0;
+  float *y, *hT, *cT, *gates, *cs, *Qs, *qx;
+  long long sxT, sxB;
+  int I, pad;
+};
+struct WfBwdLayer {
+  const float *gates, *cs, *dy, *dhT, *dcT;
+  const float *UE, *EH, *UXO, *EXI; // pack_kernel images
+  const float *VR, *VRX;            // wf_pack_kernel images
+  float *dpre, *dQs, *dqx, *dx, *dh0, *dc0;
+  long long sxT, sxB;               // strides of dx (= the layer's x)
+  int I, want_dx;
+};
+struct WfCommon {
+  unsigned* flag;                   // [L - 1][B][WF_FLAG_STRIDE] progress words, then the error word
+  int L, pad;
+};
+struct WfFwdArgs {
+  WfCommon c;
+  WfFwdLayer l[WF_MAXL];
+};
+struct WfBwdArgs {
+  WfCommon c;
+  WfBwdLayer l[WF_MAXL];
+};
+bool wf_supported(const VGeo& g);   // an instantiation exists for the layer's (rank, waves)
+WfPack wf_pack_layout(const VGeo& g);
+int launch_wf_pack(const VGeo& g, const RefP& p, const WfPack& W, float* img, hipStream_t s);
+int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
+int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
+bool wf_bwd_built();   // (bring-up) the backward wavefront kernel exists
+
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

@@ -301,6 +301,148 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     return out if head is not None else out[:3]
 
 
+# ---- stacked layers: one wavefront launch per direction (C ABI 7: vmlmf_stack_*) ----------------------------------------
+# (cfg, L, B, T, I, H, training) -> None (not covered: chain the per-layer calls) or (descs, reserve bytes, workspace bytes)
+_STACK_CACHE = {}
+
+
+def _stack_plan(cfg, L, B, T, I, H, training):
+    key = (cfg, L, B, T, I, H, training, _lib.lib().vmlmf_tune_generation())
+    if key in _STACK_CACHE:
+        return _STACK_CACHE[key]
+    variant, g, w_rank, u_ranks, time_major, dtype = cfg
+    plan = None
+    if 1 <= L <= _lib.STACK_MAX and g == 1 and dtype == _lib.DT_F32:
+        layers = (_lib.StackLayer * L)()
+        descs = []
+        for l in range(L):
+            d = _lib.make_desc(variant, B, T, I if l == 0 else H, H, w_rank, u_ranks, g=g, time_major=time_major,
+                               training=training, dtype=dtype)
+            layers[l].desc = d
+            descs.append(d)
+        rb = (ctypes.c_size_t * L)()
+        wb = ctypes.c_size_t()
+        rc = _lib.lib().vmlmf_stack_query(L, ctypes.addressof(layers), ctypes.addressof(rb), ctypes.addressof(wb))
+        if rc == 0:
+            plan = (descs, [int(v) for v in rb], int(wb.value))
+        elif rc not in (_lib.E_UNSUPPORTED, _lib.E_SHAPE):
+            _lib.check(rc)
+    _STACK_CACHE[key] = plan
+    return plan
+
+
+class VmlmfStackFn(torch.autograd.Function):
+    """y_top, hT_0 .. hT_{L-1}, cT_0 .. cT_{L-1} = f(x, params of layer 0, ..., params of layer L-1): every layer of a stack in
+    one launch per direction (include/vmlmf_hip.h: vmlmf_stack_forward / vmlmf_stack_backward).  Initial states are zero
+    (MyLSTM.forward, vmlmf.py:296-298)."""
+
+    @staticmethod
+    def forward(ctx, cfg, L, x, *params):
+        variant, g, w_rank, u_ranks, time_major, _ = cfg
+        ctx.set_materialize_grads(False)
+        _require_hip(x, "input")
+        x = x.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        nper = len(params) // L
+        if time_major:
+            T, B, I = x.shape
+        else:
+            B, T, I = x.shape
+        H = _hidden_size(variant, params[:nper])
+        training = bool(any(ctx.needs_input_grad))
+        plan = _stack_plan(cfg, L, B, T, I, H, training)
+        if plan is None:
+            raise RuntimeError("vmlmf_amd: this stack is not covered by the wavefront kernels (vmlmf_stack_supported)")
+        descs, rbytes, wbytes = plan
+        dev = x.device
+        ys = [torch.empty((T, B, H) if time_major else (B, T, H), device=dev, dtype=torch.float32) for _ in range(L)]
+        hc = torch.empty((2, L, B, H), device=dev, dtype=torch.float32)
+        reserves = [torch.empty(rbytes[l], device=dev, dtype=torch.uint8) if training else None for l in range(L)]
+        ws = _workspace(dev, wbytes)
+        layers = (_lib.StackLayer * L)()
+        keep = []
+        for l in range(L):
+            ps = _params_struct(params[l * nper:(l + 1) * nper], g, variant)
+            keep.append(ps)
+            ly = layers[l]
+            ly.desc, ly.params = descs[l], ctypes.pointer(ps)
+            ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[0, l].data_ptr(), hc[1, l].data_ptr()
+            ly.reserve = None if reserves[l] is None else reserves[l].data_ptr()
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().vmlmf_stack_forward(L, ctypes.addressof(layers), x.data_ptr(), ws.data_ptr(), wbytes,
+                                                      _lib.raw_stream(dev)))
+        if training:
+            ctx.cfg, ctx.L, ctx.nper, ctx.plan = cfg, L, nper, plan
+            ctx.save_for_backward(x, *ys, *reserves, *params)
+        return (ys[-1],) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L))
+
+    @staticmethod
+    def backward(ctx, dy, *dstates):
+        variant, g, w_rank, u_ranks, time_major, _ = ctx.cfg
+        L, nper = ctx.L, ctx.nper
+        descs, rbytes, wbytes = ctx.plan
+        saved = ctx.saved_tensors
+        x, ys, reserves, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
+        dev = x.device
+        dy = None if dy is None else dy.contiguous()
+        dhT = [None if d is None else d.contiguous() for d in dstates[:L]]
+        dcT = [None if d is None else d.contiguous() for d in dstates[L:]]
+        need_dx = ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_dx else None
+        # one flat buffer for the parameter gradients of the whole stack (views are returned)
+        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        grads, o = [], 0
+        for p in params:
+            grads.append(flat[o:o + p.numel()].view(p.shape))
+            o += p.numel()
+        ws = _workspace(dev, wbytes)
+        layers = (_lib.StackLayer * L)()
+        keep = []
+        for l in range(L):
+            ps = _params_struct(params[l * nper:(l + 1) * nper], g, variant)
+            gs = _params_struct(grads[l * nper:(l + 1) * nper], g, variant)
+            keep += [ps, gs]
+            ly = layers[l]
+            ly.desc, ly.params, ly.grads = descs[l], ctypes.pointer(ps), ctypes.pointer(gs)
+            ly.y, ly.reserve = ys[l].data_ptr(), reserves[l].data_ptr()
+            ly.dhT = None if dhT[l] is None else dhT[l].data_ptr()
+            ly.dcT = None if dcT[l] is None else dcT[l].data_ptr()
+        with _lib.on_device(dev):
+            _lib.check(_lib.lib().vmlmf_stack_backward(L, ctypes.addressof(layers), x.data_ptr(), _ptr(dy), _ptr(dx),
+                                                       ws.data_ptr(), wbytes, _lib.raw_stream(dev)))
+        return (None, None, dx) + tuple(grads)
+
+
+def stack_mode():
+    """VMLMF_STACK: "auto" (default: stacks of two or more covered layers whose layers x rows fit the chip's 256 CUs at once),
+    "0" (never: chain the per-layer calls), "1" (whenever the wavefront kernels cover the stack, single layers included)."""
+    import os
+    return os.environ.get("VMLMF_STACK", "auto")
+
+
+def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32"):
+    """Run a stack of VMLMF layers (zero initial states) in one wavefront launch per direction.  layer_params: one parameter
+    tuple per layer, in vmlmf_sequence's order.  Returns (y of the top layer, [hT per layer], [cT per layer]) or None when
+    the stack is not covered / not worth it (the caller then chains vmlmf_sequence calls)."""
+    mode = stack_mode()
+    L = len(layer_params)
+    if mode == "0" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3:
+        return None
+    dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
+    cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
+    T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
+    if mode != "1" and (L < 2 or L * B > 256):
+        return None
+    H = _hidden_size(variant, layer_params[0])
+    training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps))
+    if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
+        return None
+    flat = [p for ps in layer_params for p in ps]
+    out = VmlmfStackFn.apply(cfg, L, x, *flat)
+    return out[0], list(out[1:1 + L]), list(out[1 + L:])
+
+
 class HeadLinearFn(torch.autograd.Function):
     """logits = h @ W^T + bias for the classifier on the last timestep (Net.lin, V/src/models/vmlmf.py:345,
     353-355): two latency-sized kernels instead of three library GEMM launches and a bias-gradient reduction."""
