@@ -794,7 +794,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       const float* rs = (const float*)ly[l].reserve;
       const float* pack = rs + Lr.r_pack;
       float* wl = ws + S.ws_layer[l];
-      WfBwdLayer& w = a.l[l];
+      WfBwdLayer& w = a.l[L - 1 - l];   // launch position 0 is the top layer
       w.gates = rs + Lr.r_gates, w.cs = rs + Lr.r_cs;
       w.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
       w.dhT = ly[l].dhT, w.dcT = ly[l].dcT, w.dh0 = ly[l].dh0, w.dc0 = ly[l].dc0;
