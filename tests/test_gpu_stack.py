@@ -108,3 +108,23 @@ def test_stack_repeats_bit_identically_under_load():
         torch.cuda.synchronize()
     finally:
         os.environ.pop("VMLMF_STACK", None)
+
+
+def test_stack_backward_twice_over_one_graph():
+    """retain_graph: the second backward finds the progress words of the backward launch cleared again."""
+    import vmlmf_amd
+    torch.manual_seed(3)
+    model = vmlmf_amd.MyLSTM(12, hidden_layer_sizes=[64, 64, 64], batch_first=True, w_rank=16, u_ranks=16,
+                             cell=vmlmf_amd.MyVMLMFCell).cuda()
+    x = torch.randn(9, 13, 12, device="cuda", requires_grad=True)
+    os.environ["VMLMF_STACK"] = "1"
+    try:
+        y, hid = model(x)
+        loss = y.square().sum() + hid.sum()
+        g1 = torch.autograd.grad(loss, [x] + list(model.parameters()), retain_graph=True)
+        g2 = torch.autograd.grad(loss, [x] + list(model.parameters()))
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("VMLMF_STACK", None)
+    for a, b in zip(g1, g2):
+        assert torch.equal(a, b)

@@ -717,8 +717,8 @@ int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_by
   StackPlan S;
   const int rc = stack_plan(L, layers, &S);
   if (rc != 0) return rc;
-  for (int l = 0; l < L; ++l)
-    if (reserve_bytes != nullptr) reserve_bytes[l] = (size_t)S.lay[l].r_total * sizeof(float);
+  for (int l = 0; l < L; ++l)   // (layer 0's reserve ends with the progress words of the backward launch: the forward clears them)
+    if (reserve_bytes != nullptr) reserve_bytes[l] = (size_t)(S.lay[l].r_total + (l == 0 ? align64(S.flag_words) : 0)) * sizeof(float);
   if (workspace_bytes != nullptr) *workspace_bytes = (size_t)S.ws_total * sizeof(float);
   return 0;
 }
@@ -736,6 +736,8 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+  RefP rps[WF_MAXL];
+  float* packs[WF_MAXL];
   for (int l = 0; l < L; ++l) {
     const VGeo& g = S.g[l];
     if ((rc = check_params(g, ly[l].params)) != 0) return rc;
@@ -744,12 +746,7 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void
     float* rs = (float*)ly[l].reserve;
     const Layout& Lr = S.lay[l];
     float* pack = training ? rs + Lr.r_pack : ws + S.ws_layer[l] + Lr.f_pack;
-    const RefP rp = to_refp(ly[l].params);
-    {
-      Scope sc(0, s);
-      if ((rc = hip_fail(launch_pack(g, rp, S.P[l], pack, s), "pack")) != 0) return rc;
-      if ((rc = hip_fail(launch_wf_pack(g, rp, S.W, pack + S.P[l].WF, s), "wf_pack")) != 0) return rc;
-    }
+    rps[l] = to_refp(ly[l].params), packs[l] = pack;
     WfFwdLayer& w = a.l[l];
     w.x = l == 0 ? x : ly[l - 1].y;
     w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
@@ -759,7 +756,13 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void
     w.gates = training ? rs + Lr.r_gates : nullptr, w.cs = training ? rs + Lr.r_cs : nullptr;
     w.Qs = training ? rs + Lr.r_Qs : nullptr, w.qx = training ? rs + Lr.r_qx : nullptr;
   }
-  if (L > 1 && (rc = (int)hipMemsetAsync(ws + S.ws_flag, 0, sizeof(float) * (size_t)S.flag_words, s)) != 0) return hip_fail(rc, "memset");
+  {
+    // one launch: every layer's parameter images, and the progress words of this launch and of the backward one cleared
+    unsigned* z0 = L > 1 ? reinterpret_cast<unsigned*>(ws + S.ws_flag) : nullptr;
+    unsigned* z1 = (L > 1 && training) ? reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total) : nullptr;
+    Scope sc(0, s);
+    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, S.W, packs, z0, (int)S.flag_words, z1, (int)S.flag_words, s), "pack")) != 0) return rc;
+  }
   {
     Scope sc(2, s);
     if ((rc = hip_fail(launch_wf_fwd(S.g[0], a, s), "wf_fwd")) != 0) return rc;
@@ -787,7 +790,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
   if (wave) {
     WfBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+    a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L;   // cleared by the forward
     for (int l = 0; l < L; ++l) {
       const VGeo& g = S.g[l];
       const Layout& Lr = S.lay[l];
@@ -805,7 +808,6 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       w.want_dx = w.dx != nullptr ? 1 : 0;
       w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
     }
-    if (L > 1 && (rc = (int)hipMemsetAsync(ws + S.ws_flag, 0, sizeof(float) * (size_t)S.flag_words, s)) != 0) return hip_fail(rc, "memset");
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_wf_bwd(S.g[0], a, s), "wf_bwd")) != 0) return rc;

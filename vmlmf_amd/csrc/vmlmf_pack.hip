@@ -5,6 +5,7 @@
 //   finish_kernel  canonical gradients -> reference-layout gradients (folds d(ex), d(eh) into dia/U/V)
 #include "vmlmf_launch.h"
 #include <stdlib.h>
+#include <string.h>
 
 // ---------------------------------------------------------------------------------------------------
 // pack
@@ -35,11 +36,12 @@ __device__ __forceinline__ float dot_ex(const VGeo& g, const RefP& p, int n, int
   return p.dia_x[n] - half_wave_sum(acc);
 }
 
-__global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, PackDots D, int ncopy, float* __restrict__ out) {
+__device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VPack& L, const PackDots& D, const int ncopy,
+                                          float* __restrict__ out, const int bid) {
   const int NT = g.NT;
-  if ((int)blockIdx.x >= ncopy) {   // ---- dot elements: 8 per workgroup ----
+  if (bid >= ncopy) {   // ---- dot elements: 8 per workgroup ----
     const int l32 = threadIdx.x & 31;
-    int d = ((int)blockIdx.x - ncopy) * 8 + (threadIdx.x >> 5);
+    int d = (bid - ncopy) * 8 + (threadIdx.x >> 5);
     float v = 0.f;
     long long dst = -1;
     if (d < D.nEH) {            // EH[k][slot] = dia_h[n] - sum_r uc(n,r) vc(n,k,r)   (block 0 of the rank space)
@@ -82,7 +84,7 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, Pack
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
   const int total = (int)L.RB, stride = ncopy * 256;   // the RB region behind it belongs to rb_pack_kernel
-  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < total; e += stride) {
+  for (int e = bid * 256 + threadIdx.x; e < total; e += stride) {
     float v = 0.f;
     if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
       const int le = e - (int)L.VE;
@@ -203,17 +205,130 @@ __global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, Pack
   }
 }
 
-int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s) {
-  if (L.total >= (1LL << 31)) return -3;
-  PackDots D;
+__global__ void __launch_bounds__(256) pack_kernel(VGeo g, RefP p, VPack L, PackDots D, int ncopy, float* __restrict__ out) {
+  pack_body(g, p, L, D, ncopy, out, (int)blockIdx.x);
+}
+
+static void pack_counts(const VGeo& g, const VPack& L, PackDots& D, int& ncopy, int& ndot) {
   D.nEH = 4 * g.NT;
   D.nEXI = (int)(L.UXP - L.EXI) > 0 ? 4 * g.NT : 0;
   D.nEXT = 4 * g.H;
   D.nWXD = (L.RB - L.WXD) > 0 ? 4 * g.I * g.NT : 0;
-  int ncopy = (int)((L.RB + 255) / 256);
+  ncopy = (int)((L.RB + 255) / 256);
   if (ncopy > 2048) ncopy = 2048;
-  const int ndot = (D.nEH + D.nEXI + D.nEXT + D.nWXD + 7) / 8;
+  ndot = (D.nEH + D.nEXI + D.nEXT + D.nWXD + 7) / 8;
+}
+
+int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s) {
+  if (L.total >= (1LL << 31)) return -3;
+  PackDots D;
+  int ncopy, ndot;
+  pack_counts(g, L, D, ncopy, ndot);
   hipLaunchKernelGGL(pack_kernel, dim3(ncopy + ndot), dim3(256), 0, s, g, p, L, D, ncopy, pack);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// pack of a whole stack (wavefront launches, vmlmf_wave.inc): every layer's images - pack_kernel's and the rotated
+// images with the half-pass layout - in ONE launch (grid.y = layer), which also zeroes the progress words of the two
+// wavefront launches (no memset nodes).  Two launches per layer plus two memsets were 28 us of config C's 188.
+// ---------------------------------------------------------------------------------------------------
+// Rotated images for the DPP rank reduce of vmlmf_wave.inc.  Register j of the thread in `slot`:
+//   j <  16 NPF : full pass p = j / 16, rotation kk = j % 16: the lane multiplies what it receives from lane src = i + sgn kk
+//                 (mod 16) of its row with the weight that couples that unit to rank 16 p + i
+//   j >= 16 NPF : half pass, rotation kk = j - 16 NPF (0..7), rank 16 NPF + (i mod 8)
+// Four images: UR (U_h), VR[4] (V_h per gate), URX (U_x, inputs by slot), VRX[4] (V_x per gate).
+__device__ __forceinline__ void wf_pack_body(const VGeo& g, const RefP& p, const WfPack& W, float* __restrict__ out, const int bid,
+                                             const int nblk) {
+  const int NT = g.NT, K = g.KH, NPF = K / 16;
+  const int lane = threadIdx.x & 63;
+  const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
+  const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
+  const int total = (int)W.total;
+  for (int e = bid * 256 + threadIdx.x; e < total; e += nblk * 256) {
+    float v = 0.f;
+    int le, kind;   // kind 0: UR, 1: VR, 2: URX, 3: VRX
+    if (e < W.VR) le = e - (int)W.UR, kind = 0;
+    else if (e < W.URX) le = e - (int)W.VR, kind = 1;
+    else if (e < W.VRX) le = e - (int)W.URX, kind = 2;
+    else le = e - (int)W.VRX, kind = 3;
+    const int nreg = (kind & 1) ? 4 * K : K;
+    if (le < nreg * NT) {
+      const int jj = le / NT, slot = le - jj * NT, k = jj / K, j = jj - k * K, i = slot & 15;
+      const bool full = j < 16 * NPF;
+      const int kk = full ? (j & 15) : (j - 16 * NPF);
+      const int rank = full ? (j >> 4) * 16 + i : 16 * NPF + (i & 7);
+      const int src = (slot & ~15) | ((i + sgn * kk) & 15);
+      int n;
+      if (vg_slot_unit(g, src, n)) {
+        if (kind == 0) v = ref_uc(g, p, n, rank);
+        else if (kind == 1) v = ref_vc(g, p, n, k, rank);
+        else if (kind == 2) v = n < g.I ? ref_ux(g, p, n, rank) : 0.f;
+        else v = ref_vx(g, p, n, k, rank);
+      }
+    }
+    out[e] = v;
+  }
+}
+
+struct PackStackLayer {
+  VGeo g;
+  RefP p;
+  VPack L;
+  WfPack W;
+  PackDots D;
+  int ncopy, ndot, nwf, pad;
+  float* out;
+};
+struct PackStackArgs {
+  PackStackLayer l[WF_MAXL];
+  unsigned* zero[2];   // progress words of the forward / backward wavefront launch (or NULL)
+  int nzero[2];
+};
+
+__global__ void __launch_bounds__(256) pack_stack_kernel(PackStackArgs a) {
+  typedef __attribute__((address_space(4))) int karg_i;
+  const karg_i* ka = (const karg_i*)__builtin_amdgcn_kernarg_segment_ptr();
+  const int layer = blockIdx.y, bid = blockIdx.x;
+  PackStackLayer ly;   // this layer's block of the argument array, by scalar loads (a dynamic index into `a` would go through scratch)
+  {
+    const karg_i* w = ka + (size_t)layer * (sizeof(PackStackLayer) / 4);
+    int tmp[sizeof(PackStackLayer) / 4];
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(PackStackLayer) / 4; ++i) tmp[i] = w[i];
+    __builtin_memcpy(&ly, tmp, sizeof(PackStackLayer));
+  }
+  if (layer == 0) {
+    const int nthr = (int)gridDim.x * 256;
+#pragma unroll
+    for (int z = 0; z < 2; ++z)
+      if (a.zero[z] != nullptr)
+        for (int i = bid * 256 + (int)threadIdx.x; i < a.nzero[z]; i += nthr) a.zero[z][i] = 0u;
+  }
+  const int npk = ly.ncopy + ly.ndot;
+  if (bid < npk) pack_body(ly.g, ly.p, ly.L, ly.D, ly.ncopy, ly.out, bid);
+  else if (bid < npk + ly.nwf) wf_pack_body(ly.g, ly.p, ly.W, ly.out + ly.L.WF, bid - npk, ly.nwf);
+}
+
+int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const WfPack& W, float* const* pack, unsigned* zero0,
+                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s) {
+  static_assert(sizeof(PackStackArgs) <= 4096, "kernel-argument segment");
+  static_assert(sizeof(PackStackLayer) % 8 == 0, "layer blocks are read as dwords at a multiple of their size");
+  PackStackArgs a;
+  memset(&a, 0, sizeof(a));
+  int gx = 0;
+  for (int l = 0; l < L; ++l) {
+    if (P[l].total >= (1LL << 31)) return -3;
+    PackStackLayer& y = a.l[l];
+    y.g = g[l], y.p = p[l], y.L = P[l], y.W = W, y.out = pack[l];
+    pack_counts(g[l], P[l], y.D, y.ncopy, y.ndot);
+    y.nwf = (int)((W.total + 255) / 256);
+    if (y.nwf > 256) y.nwf = 256;
+    const int n = y.ncopy + y.ndot + y.nwf;
+    gx = n > gx ? n : gx;
+  }
+  a.zero[0] = zero0, a.nzero[0] = nzero0, a.zero[1] = zero1, a.nzero[1] = nzero1;
+  hipLaunchKernelGGL(pack_stack_kernel, dim3(gx, L), dim3(256), 0, s, a);
   return (int)hipGetLastError();
 }
 

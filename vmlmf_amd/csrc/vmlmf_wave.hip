@@ -1,43 +1,6 @@
-// Wavefront kernels for stacked layers: parameter images with the half-pass rotation layout, and the dispatch over
-// the per-rank translation units (vmlmf_wave_k*.hip).
+// Wavefront kernels for stacked layers: layout of the rotated parameter images (produced by pack_stack_kernel, vmlmf_pack.hip),
+// eligibility, and the dispatch over the per-rank translation units (vmlmf_wave_k*.hip).
 #include "vmlmf_launch.h"
-
-// Rotated images for the DPP rank reduce of vmlmf_wave.inc.  Register j of the thread in `slot`:
-//   j <  16 NPF : full pass p = j / 16, rotation kk = j % 16: the lane multiplies what it receives from lane src = i + sgn kk
-//                 (mod 16) of its row with the weight that couples that unit to rank 16 p + i
-//   j >= 16 NPF : half pass, rotation kk = j - 16 NPF (0..7), rank 16 NPF + (i mod 8)
-// Four images: UR (U_h), VR[4] (V_h per gate), URX (U_x, inputs by slot), VRX[4] (V_x per gate).
-__global__ void __launch_bounds__(256) wf_pack_kernel(VGeo g, RefP p, WfPack W, int K, float* __restrict__ out) {
-  const int NT = g.NT, NPF = K / 16;
-  const int lane = threadIdx.x & 63;
-  const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
-  const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
-  const int total = (int)W.total;
-  for (int e = (int)blockIdx.x * 256 + threadIdx.x; e < total; e += (int)gridDim.x * 256) {
-    float v = 0.f;
-    int le, kind;   // kind 0: UR, 1: VR, 2: URX, 3: VRX
-    if (e < W.VR) le = e - (int)W.UR, kind = 0;
-    else if (e < W.URX) le = e - (int)W.VR, kind = 1;
-    else if (e < W.VRX) le = e - (int)W.URX, kind = 2;
-    else le = e - (int)W.VRX, kind = 3;
-    const int nreg = (kind & 1) ? 4 * K : K;
-    if (le < nreg * NT) {
-      const int jj = le / NT, slot = le - jj * NT, k = jj / K, j = jj - k * K, i = slot & 15;
-      const bool full = j < 16 * NPF;
-      const int kk = full ? (j & 15) : (j - 16 * NPF);
-      const int rank = full ? (j >> 4) * 16 + i : 16 * NPF + (i & 7);
-      const int src = (slot & ~15) | ((i + sgn * kk) & 15);
-      int n;
-      if (vg_slot_unit(g, src, n)) {
-        if (kind == 0) v = ref_uc(g, p, n, rank);
-        else if (kind == 1) v = ref_vc(g, p, n, k, rank);
-        else if (kind == 2) v = n < g.I ? ref_ux(g, p, n, rank) : 0.f;
-        else v = ref_vx(g, p, n, k, rank);
-      }
-    }
-    out[e] = v;
-  }
-}
 
 WfPack wf_pack_layout(const VGeo& g) {
   WfPack W;
@@ -50,13 +13,6 @@ WfPack wf_pack_layout(const VGeo& g) {
   W.VRX = take(4 * K * g.NT);
   W.total = o;
   return W;
-}
-
-int launch_wf_pack(const VGeo& g, const RefP& p, const WfPack& W, float* img, hipStream_t s) {
-  int nb = (int)((W.total + 255) / 256);
-  if (nb > 512) nb = 512;
-  hipLaunchKernelGGL(wf_pack_kernel, dim3(nb), dim3(256), 0, s, g, p, W, g.KH, img);
-  return (int)hipGetLastError();
 }
 
 // one group, x rank padded like the h rank, at most four waves of units; rank 32 with four waves would need more than the
