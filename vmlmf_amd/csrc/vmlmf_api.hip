@@ -813,6 +813,42 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       if ((rc = hip_fail(launch_wf_bwd(S.g[0], a, s), "wf_bwd")) != 0) return rc;
     }
   }
+  if (wave) {   // the batched half of every layer's backward: one launch each for the whole stack
+    WghArgs wh[WF_MAXL];
+    RefP rps[WF_MAXL];
+    RefG ogs[WF_MAXL];
+    const float* wparts[WF_MAXL];
+    float* cgs[WF_MAXL];
+    const float* ccgs[WF_MAXL];
+    for (int l = 0; l < L; ++l) {
+      const Layout& Lr = S.lay[l];
+      const float* rs = (const float*)ly[l].reserve;
+      float* wl = ws + S.ws_layer[l];
+      WghArgs& w = wh[l];
+      w.dpre = wl + Lr.b_dpre, w.x = l == 0 ? x : ly[l - 1].y, w.y = ly[l].y, w.h0 = ly[l].h0, w.qx = rs + Lr.r_qx, w.dqx = wl + Lr.b_dqx;
+      w.Qs = rs + Lr.r_Qs, w.dQs = wl + Lr.b_dQs, w.wpart = wl + Lr.b_wpart;
+      wparts[l] = wl + Lr.b_wpart, cgs[l] = wl + Lr.b_cgrad, ccgs[l] = wl + Lr.b_cgrad;
+      rps[l] = to_refp(ly[l].params);
+      const vmlmf_grads* gr = ly[l].grads;
+      RefG& og = ogs[l];
+      og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
+      og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+      for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
+    }
+    {
+      Scope sc(5, s);
+      if ((rc = hip_fail(launch_wgrad_h_stack(L, S.g, wh, s), "wgrad")) != 0) return rc;
+    }
+    {
+      Scope sc(6, s);
+      if ((rc = hip_fail(launch_reduce_stack(L, S.g, wparts, cgs, s), "reduce")) != 0) return rc;
+    }
+    {
+      Scope sc(7, s);
+      if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, s), "finish")) != 0) return rc;
+    }
+    return 0;
+  }
   for (int l = L - 1; l >= 0; --l) {
     const VGeo& g = S.g[l];
     const Layout& Lr = S.lay[l];

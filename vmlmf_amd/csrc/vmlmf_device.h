@@ -175,6 +175,17 @@ __device__ __forceinline__ unsigned short vg_f2bf(float f) {   // round to neare
   return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 
+// Element of an array of argument structs inside the kernel-argument segment, at a run-time (wave-uniform) byte offset.
+// The reference goes through a generic pointer derived from the segment pointer: the compiler infers the constant
+// address space back and loads just the fields that are used, as scalar loads - like any by-value kernel argument.  (A
+// dynamic index into the by-value argument itself is copied through scratch; loading the whole 600-byte struct into
+// registers up front overflows the SGPR file: finish_stack_kernel took 13.9 us that way, 2 x 4.6 as two launches.)
+template <typename S>
+__device__ __forceinline__ const S& vg_karg_ref(size_t byte_offset) {
+  const __attribute__((address_space(4))) char* ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+  return *(const S*)(const char*)(ka + byte_offset);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // canonical element <- reference layouts (oracle/vmlmf_oracle.py: canonicalize)
 // ---------------------------------------------------------------------------------------------------

@@ -155,6 +155,10 @@ int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const
                       int nzero0, unsigned* zero1, int nzero1, hipStream_t s);
 int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
+// the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)
+int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
+int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
+int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, hipStream_t s);
 bool wf_bwd_built();   // (bring-up) the backward wavefront kernel exists
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated

@@ -287,17 +287,8 @@ struct PackStackArgs {
 };
 
 __global__ void __launch_bounds__(256) pack_stack_kernel(PackStackArgs a) {
-  typedef __attribute__((address_space(4))) int karg_i;
-  const karg_i* ka = (const karg_i*)__builtin_amdgcn_kernarg_segment_ptr();
   const int layer = blockIdx.y, bid = blockIdx.x;
-  PackStackLayer ly;   // this layer's block of the argument array, by scalar loads (a dynamic index into `a` would go through scratch)
-  {
-    const karg_i* w = ka + (size_t)layer * (sizeof(PackStackLayer) / 4);
-    int tmp[sizeof(PackStackLayer) / 4];
-#pragma unroll
-    for (unsigned i = 0; i < sizeof(PackStackLayer) / 4; ++i) tmp[i] = w[i];
-    __builtin_memcpy(&ly, tmp, sizeof(PackStackLayer));
-  }
+  const PackStackLayer& ly = vg_karg_ref<PackStackLayer>((size_t)layer * sizeof(PackStackLayer));
   if (layer == 0) {
     const int nthr = (int)gridDim.x * 256;
 #pragma unroll
@@ -511,8 +502,8 @@ __device__ __forceinline__ float* vx_dest(const VGeo& g, const RefG& o, long lon
   return o.v_x + e;
 }
 
-__global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o, HeadBwd hd,
-                                                     long long nbody) {
+__device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const float* __restrict__ cg, const RefG& o, const HeadBwd& hd,
+                                            const long long nbody) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
   {
     // classifier gradients (HeadBwd) ride at the end of the grid: dW[c][n] = sum_b dlogits[b][c] hT[b][n], db[c] = sum_b
@@ -701,11 +692,50 @@ __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float
   }
 }
 
-int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s) {
+__global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o, HeadBwd hd,
+                                                     long long nbody) {
+  finish_body(g, p, cg, o, hd, nbody);
+}
+struct FinishLayer {
+  VGeo g;
+  RefP p;
+  RefG o;
+  const float* cg;
+  long long nbody;
+};
+struct FinishStack {
+  FinishLayer l[WF_MAXL];
+};
+__global__ void __launch_bounds__(256) finish_stack_kernel(FinishStack S) {   // grid.y = layer (wavefront path; no classifier)
+  const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
+  if ((long long)blockIdx.x * 256 >= f.nbody) return;
+  HeadBwd hd;
+  memset(&hd, 0, sizeof(hd));
+  finish_body(f.g, f.p, f.cg, f.o, hd, f.nbody);
+}
+
+static long long finish_elements(const VGeo& g) {
   long long n = (long long)g.I * g.rw * (g.foldx ? 64 : 1) + 4LL * g.H * g.rw + g.I + g.H + 4LL * g.H;
   n += (long long)g.H * g.ru0 + 4LL * g.H * g.ru0;
   if (g.G == 2) n += (long long)g.H * g.ru1 + 4LL * g.H * g.ru1;
-  const long long nbody = (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
+  return (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
+}
+
+int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, hipStream_t s) {
+  static_assert(sizeof(FinishStack) <= 4096, "kernel-argument segment");
+  FinishStack S;
+  memset(&S, 0, sizeof(S));
+  long long nmax = 0;
+  for (int l = 0; l < L; ++l) {
+    S.l[l].g = g[l], S.l[l].p = p[l], S.l[l].o = out[l], S.l[l].cg = cgrad[l], S.l[l].nbody = finish_elements(g[l]);
+    nmax = S.l[l].nbody > nmax ? S.l[l].nbody : nmax;
+  }
+  hipLaunchKernelGGL(finish_stack_kernel, dim3((unsigned)(nmax / 256), L), dim3(256), 0, s, S);
+  return (int)hipGetLastError();
+}
+
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s) {
+  const long long nbody = finish_elements(g);
   const long long nhead = hd.C > 0 ? 16 * ((long long)hd.C * g.H + hd.C) : 0;   // sixteen lanes per classifier output
   hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((nbody + nhead + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out, hd, nbody);
   return (int)hipGetLastError();

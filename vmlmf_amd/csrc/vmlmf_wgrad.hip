@@ -7,6 +7,7 @@
 //   wgrad_mfma_kernel  every weight gradient as A^T B over the rows on fp32 MFMA (see below).
 //   reduce_cg_kernel   fixed-order sum of the per-chunk partial products (deterministic, no float atomics).
 #include "vmlmf_launch.h"
+#include <string.h>
 
 constexpr int RG = 8;  // rows per barrier group in dqx_dx_kernel
 
@@ -307,7 +308,7 @@ __device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const 
 // NS: 4 NS waves per workgroup, waves w, w + 4, ... share task w (a part of the rows each): the kernel is bound by
 // the load -> MFMA latency of each wave's row loop, so shortening the loop shortens the kernel.
 template <int NBT1, int NBT2, int NS>
-__global__ void __launch_bounds__(256 * NS) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
+__device__ __forceinline__ void wgrad_body(const VGeo& g, const AtbArgs& a) {
   extern __shared__ float4 smem4[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int slot = wave & 3, half = wave >> 2;
@@ -325,11 +326,25 @@ __global__ void __launch_bounds__(256 * NS) wgrad_mfma_kernel(VGeo g, AtbArgs a)
   else if (NS > 1)
     __syncthreads();
 }
+template <int NBT1, int NBT2, int NS>
+__global__ void __launch_bounds__(256 * NS) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
+  wgrad_body<NBT1, NBT2, NS>(g, a);
+}
+// the layers of a stack in one launch (grid.z = layer; wavefront path, vmlmf_wave.inc)
+struct AtbStack {
+  VGeo g[WF_MAXL];
+  AtbArgs a[WF_MAXL];
+};
+template <int NBT1, int NBT2, int NS>
+__global__ void __launch_bounds__(256 * NS) wgrad_mfma_stack_kernel(AtbStack S) {
+  const VGeo& g = vg_karg_ref<VGeo>(offsetof(AtbStack, g) + (size_t)blockIdx.z * sizeof(VGeo));
+  const AtbArgs& a = vg_karg_ref<AtbArgs>(offsetof(AtbStack, a) + (size_t)blockIdx.z * sizeof(AtbArgs));
+  wgrad_body<NBT1, NBT2, NS>(g, a);
+}
 
 // One thread per element of a chunk's partial block P (coalesced over chunks), fixed-order sum over the
 // chunks (deterministic), then scatter into cgrad[accumulator][slot] (layout finish_kernel reads).
-__global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __restrict__ Pall,
-                                                        float* __restrict__ cgrad) {
+__device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= g.PCH) return;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -383,6 +398,22 @@ __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __r
     const int acc = which == 0 ? va_eh(g, k) : (which == 1 ? va_ex(g, k) : va_b(g, k));
     cgrad[(size_t)acc * NT + slot] = total;
   }
+}
+
+__global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __restrict__ Pall,
+                                                        float* __restrict__ cgrad) {
+  reduce_cg_body(g, Pall, cgrad);
+}
+struct ReduceStack {
+  VGeo g[WF_MAXL];
+  const float* P[WF_MAXL];
+  float* cg[WF_MAXL];
+};
+__global__ void __launch_bounds__(256) reduce_cg_stack_kernel(ReduceStack S) {   // grid.y = layer
+  const VGeo& g = vg_karg_ref<VGeo>(offsetof(ReduceStack, g) + (size_t)blockIdx.y * sizeof(VGeo));
+  const float* P = vg_karg_ref<const float*>(offsetof(ReduceStack, P) + (size_t)blockIdx.y * sizeof(float*));
+  float* cg = vg_karg_ref<float*>(offsetof(ReduceStack, cg) + (size_t)blockIdx.y * sizeof(float*));
+  reduce_cg_body(g, P, cg);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -447,5 +478,44 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
 
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s) {
   hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad);
+  return (int)hipGetLastError();
+}
+
+// ---- the layers of a stack in one launch each (same ranks, rows and chunking in every layer; the input width may differ)
+int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s) {
+  static_assert(sizeof(AtbStack) <= 4096, "kernel-argument segment");
+  AtbStack S;
+  memset(&S, 0, sizeof(S));
+  int tasks = 0;
+  for (int l = 0; l < L; ++l) {
+    S.g[l] = g[l];
+    AtbArgs& a = S.a[l];
+    a.dpre = w[l].dpre, a.x = w[l].x, a.y = w[l].y, a.h0 = w[l].h0, a.qx = w[l].qx, a.dqx = w[l].dqx, a.Qs = w[l].Qs, a.dQs = w[l].dQs;
+    a.P = w[l].wpart;
+    const int t = g[l].NT / 8 + (g[l].H + 31) / 32 + (g[l].foldx ? 0 : (g[l].I + 31) / 32);
+    tasks = t > tasks ? t : tasks;
+    if (g[l].nchunk != g[0].nchunk || g[l].KX != g[0].KX || g[l].KH != g[0].KH || g[l].G != g[0].G || g[l].flat != g[0].flat) return -3;
+  }
+  const int GK = g[0].G * g[0].KH, n1 = (vg_nb1(g[0]) + 31) / 32, n2 = (GK + 31) / 32;
+  if (n1 > 2 || n2 > 2) return -3;   // (the stacks of the wavefront kernels: ranks <= 32, one group)
+  const dim3 grid((tasks + 3) / 4, g[0].nchunk, L);
+  const int nm = n1 > n2 ? n1 : n2;
+  const size_t lds = sizeof(float) * 4 * (16 * (size_t)nm + 3) * 64;
+  if (n1 == 1 && n2 == 1) hipLaunchKernelGGL((wgrad_mfma_stack_kernel<1, 1, 2>), grid, dim3(512), lds, s, S);
+  else if (n1 == 1) hipLaunchKernelGGL((wgrad_mfma_stack_kernel<1, 2, 2>), grid, dim3(512), lds, s, S);
+  else if (n2 == 1) hipLaunchKernelGGL((wgrad_mfma_stack_kernel<2, 1, 2>), grid, dim3(512), lds, s, S);
+  else hipLaunchKernelGGL((wgrad_mfma_stack_kernel<2, 2, 2>), grid, dim3(512), lds, s, S);
+  return (int)hipGetLastError();
+}
+
+int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s) {
+  ReduceStack S;
+  memset(&S, 0, sizeof(S));
+  long long pch = 0;
+  for (int l = 0; l < L; ++l) {
+    S.g[l] = g[l], S.P[l] = wpart[l], S.cg[l] = cgrad[l];
+    pch = g[l].PCH > pch ? g[l].PCH : pch;
+  }
+  hipLaunchKernelGGL(reduce_cg_stack_kernel, dim3((unsigned)((pch + 255) / 256), L), dim3(256), 0, s, S);
   return (int)hipGetLastError();
 }
