@@ -117,3 +117,38 @@ def test_comm_entry_points_validate_arguments_without_a_gpu():
     h = ctypes.c_void_p()
     rc = lib.vmlmf_comm_init(ctypes.byref(h), 2, 5, (ctypes.c_ubyte * 128)())
     assert rc in (_lib.E_BADARG, _lib.E_UNSUPPORTED) and not h
+
+
+def test_stack_query_host_logic():
+    """vmlmf_stack_query (ABI 7) is pure host logic: sizes for a covered stack, VMLMF_E_UNSUPPORTED / VMLMF_E_SHAPE for
+    stacks the wavefront kernels do not take (the caller then chains the per-layer calls).  No GPU call."""
+    import ctypes
+    from vmlmf_amd import _lib
+    lib = _lib.lib()
+
+    def query(L, B, T, I, H, rw, ru, variant=_lib.V1_CELL, g=1, H_upper=None, I_upper=None):
+        layers = (_lib.StackLayer * L)()
+        for l in range(L):
+            h = H if (l == 0 or H_upper is None) else H_upper
+            i = I if l == 0 else (H if I_upper is None else I_upper)
+            layers[l].desc = _lib.make_desc(variant, B, T, i, h, rw, [ru] * g, g=g, time_major=False, training=True)
+        rb = (ctypes.c_size_t * L)()
+        wb = ctypes.c_size_t()
+        rc = lib.vmlmf_stack_query(L, ctypes.addressof(layers), ctypes.addressof(rb), ctypes.addressof(wb))
+        return rc, [int(v) for v in rb], int(wb.value)
+
+    rc, rb, wb = query(2, 128, 24, 77, 256, 24, 24)            # BASELINE configs[2]
+    assert rc == 0 and all(v > 0 for v in rb) and wb > 0
+    single = _lib.query(_lib.make_desc(_lib.V1_CELL, 128, 24, 256, 256, 24, [24], training=True))
+    assert rb[1] > single.reserve_bytes                          # the stack's reserve also holds the rotated images
+    assert rb[0] - rb[1] != 0                                    # layer 0: other input width, plus the backward's progress words
+    assert query(1, 64, 128, 9, 180, 16, 16)[0] == 0
+    assert query(4, 8, 5, 20, 64, 8, 8)[0] == 0
+    assert query(5, 8, 5, 20, 64, 8, 8)[0] == _lib.E_UNSUPPORTED                      # more than four layers
+    assert query(2, 8, 5, 20, 64, 8, 16)[0] == _lib.E_UNSUPPORTED                     # padded w_rank != padded u_rank
+    assert query(2, 8, 5, 20, 320, 16, 16)[0] == _lib.E_UNSUPPORTED                   # more than four waves of units
+    assert query(2, 8, 5, 20, 256, 32, 32)[0] == _lib.E_UNSUPPORTED                   # rank 32 with four waves: register budget
+    assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == _lib.E_UNSUPPORTED   # group layers
+    assert query(2, 8, 5, 20, 64, 8, 8, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED            # unequal hidden sizes
+    assert query(2, 8, 5, 20, 64, 8, 8, I_upper=48)[0] == _lib.E_SHAPE                # layer 1 does not read layer 0's width
+    assert b"stack" in lib.vmlmf_last_error()

@@ -128,3 +128,35 @@ def test_stack_backward_twice_over_one_graph():
         os.environ.pop("VMLMF_STACK", None)
     for a, b in zip(g1, g2):
         assert torch.equal(a, b)
+
+
+def test_stack_through_both_bindings():
+    """vmlmf::stack of the C++ binding and VmlmfStackFn over ctypes call the same C ABI: same bits (fresh interpreters)."""
+    import subprocess
+    import sys
+    from vmlmf_amd import functional as F
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path[:0] = [%r]\n"
+        "import torch, vmlmf_amd\n"
+        "from vmlmf_amd import MyLSTM, MyVMLMFCell, functional as F\n"
+        "torch.manual_seed(3)\n"
+        "m = MyLSTM(20, hidden_layer_sizes=[72, 72, 72], batch_first=True, w_rank=16, u_ranks=16, cell=MyVMLMFCell).cuda()\n"
+        "x = torch.randn(6, 7, 20, device='cuda', requires_grad=True)\n"
+        "y, h = m(x); (y.square().sum() + h.sum()).backward()\n"
+        "print('binding', 'cpp' if F.torch_ops() is not None else 'ctypes')\n"
+        "print('vals', repr(float(y.double().sum())), repr(float(x.grad.double().sum())), repr(sum(float(p.grad.double().sum()) for p in m.parameters())))\n"
+    ) % (os.path.dirname(here),)
+    outs = {}
+    for mode in ("cpp", "ctypes"):
+        env = dict(os.environ)
+        env["VMLMF_STACK"] = "1"
+        if mode == "ctypes":
+            env["VMLMF_PYBIND"] = "ctypes"
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[mode] = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines() if " " in l)
+    assert outs["ctypes"]["binding"] == "ctypes"
+    if F.torch_ops() is not None:
+        assert outs["cpp"]["binding"] == "cpp"
+        assert outs["cpp"]["vals"] == outs["ctypes"]["vals"]

@@ -36,7 +36,14 @@ def graph_of(fn):
     return g
 
 
+ONLY = os.environ.get("BENCH_ONLY", "")   # substring filter on the config names (A/B runs of single configs)
+
+
 def har(name, cellcls, B, T, I, layers, rw, ru, variant, cpu=True):
+    if ONLY and ONLY not in name:
+        return
+    if os.environ.get("BENCH_NOCPU"):
+        cpu = False
     torch.manual_seed(0)
     rnn = MyLSTM(I, hidden_layer_sizes=layers, batch_first=True, w_rank=rw, u_ranks=ru, cell=cellcls).to(DEV)
     x = torch.randn(B, T, I, device=DEV)
@@ -72,6 +79,8 @@ def har(name, cellcls, B, T, I, layers, rw, ru, variant, cpu=True):
 
 
 def lm(name, cls, variant, B, T, H, rw, ru, nlayers, cpu_B=None):
+    if ONLY and ONLY not in name:
+        return
     torch.manual_seed(0)
     layers = [cls(H, H, w_rank=rw, u_ranks=ru).to(DEV) for _ in range(nlayers)]
     for l in layers:

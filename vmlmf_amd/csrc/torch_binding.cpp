@@ -1,6 +1,7 @@
 // PyTorch-ROCm binding of the C ABI (include/vmlmf_hip.h) as a TORCH_LIBRARY with C++ autograd functions:
 //   vmlmf::sequence        one VMLMF layer over a whole sequence          (replaces the Python time loops vmlmf.py:300-314,
 //                                                                          vmlmf_lm.py:272-280 / 166-174 and the cells under them)
+//   vmlmf::stack           every layer of a stack in one wavefront launch per direction (the layer loop vmlmf.py:300-314)
 //   vmlmf::head_linear     Net.lin on the last timestep                    (vmlmf.py:345,353-355)
 //   vmlmf::cross_entropy   the criterion of the reference's training loop  (train.py:58-65)
 // PyTorch supplies memory (caching allocator), the current HIP stream and autograd bookkeeping; every float of arithmetic
@@ -240,6 +241,115 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::
   return {out[0], out[1], out[2], out[3]};
 }
 
+// ---- stacked layers: one wavefront launch per direction (C ABI 7: vmlmf_stack_*) ------------------------------------
+// outputs: y of the top layer, then hT and cT as (L, B, H) tensors.  Initial states are zero (MyLSTM.forward).
+struct StackFn : public torch::autograd::Function<StackFn> {
+  static variable_list forward(AutogradContext* ctx, Tensor x, at::TensorList params_in, int64_t L, int64_t variant, int64_t w_rank,
+                               int64_t u_rank, bool time_major, bool training) {
+    ctx->set_materialize_grads(false);
+    require_hip_f32(x, "input");
+    x = x.contiguous();
+    std::vector<Tensor> params;
+    for (const auto& p : params_in) {
+      require_hip_f32(p, "parameter");
+      params.push_back(p.contiguous());
+    }
+    TORCH_CHECK(L >= 1 && L <= VMLMF_STACK_MAX && params.size() % L == 0, "vmlmf_amd: bad stack");
+    const size_t nper = params.size() / L;
+    const int64_t B = time_major ? x.size(1) : x.size(0), T = time_major ? x.size(0) : x.size(1), I = x.size(2);
+    std::vector<Tensor> p0(params.begin(), params.begin() + nper);
+    const int64_t H = hidden_size((int)variant, p0);
+    std::vector<vmlmf_stack_layer> ly(L);
+    std::vector<vmlmf_params> ps(L);
+    std::vector<size_t> rbytes(L);
+    size_t wbytes = 0;
+    memset(ly.data(), 0, sizeof(vmlmf_stack_layer) * L);
+    for (int64_t l = 0; l < L; ++l)
+      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, {u_rank}, 1, time_major, training, VMLMF_DT_F32);
+    check(vmlmf_stack_query((int)L, ly.data(), rbytes.data(), &wbytes));
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    std::vector<Tensor> ys, reserves;
+    Tensor hT = at::empty({L, B, H}, x.options()), cT = at::empty({L, B, H}, x.options());
+    Tensor ws = workspace(x, wbytes);
+    for (int64_t l = 0; l < L; ++l) {
+      ys.push_back(at::empty(time_major ? at::IntArrayRef({T, B, H}) : at::IntArrayRef({B, T, H}), x.options()));
+      reserves.push_back(training ? at::empty({(int64_t)rbytes[l]}, x.options().dtype(at::kByte)) : Tensor());
+      std::vector<Tensor> pl(params.begin() + l * nper, params.begin() + (l + 1) * nper);
+      fill_params(ps[l], pl, (int)variant, 1);
+      ly[l].params = &ps[l];
+      ly[l].y = ys[l].data_ptr<float>(), ly[l].hT = hT.data_ptr<float>() + l * B * H, ly[l].cT = cT.data_ptr<float>() + l * B * H;
+      ly[l].reserve = training ? reserves[l].data_ptr() : nullptr;
+    }
+    check(vmlmf_stack_forward((int)L, ly.data(), x.data_ptr<float>(), ws.data_ptr(), wbytes, stream_of(x)));
+    if (training) {
+      variable_list saved = {x};
+      for (auto& t : ys) saved.push_back(t);
+      for (auto& t : reserves) saved.push_back(t);
+      for (auto& t : params) saved.push_back(t);
+      ctx->save_for_backward(saved);
+      ctx->saved_data["cfg"] = std::vector<int64_t>{L, variant, w_rank, u_rank, time_major ? 1 : 0, B, T, I, H, (int64_t)nper};
+    }
+    return {ys[L - 1], hT, cT};
+  }
+
+  static variable_list backward(AutogradContext* ctx, variable_list gout) {
+    const auto saved = ctx->get_saved_variables();
+    const auto cfg = ctx->saved_data["cfg"].toIntVector();
+    const int64_t L = cfg[0], variant = cfg[1], w_rank = cfg[2], u_rank = cfg[3], B = cfg[5], T = cfg[6], I = cfg[7], H = cfg[8], nper = cfg[9];
+    const bool time_major = cfg[4] != 0;
+    const Tensor& x = saved[0];
+    std::vector<Tensor> params(saved.begin() + 1 + 2 * L, saved.end());
+    Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
+    Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
+    Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    Tensor dx = ctx->needs_input_grad(0) ? at::empty_like(x) : Tensor();
+    int64_t total = 0;
+    for (const auto& p : params) total += p.numel();
+    Tensor flat = at::empty({total}, x.options());   // the parameter gradients of the whole stack in one allocation (views are returned)
+    std::vector<Tensor> grads;
+    int64_t o = 0;
+    for (const auto& p : params) {
+      grads.push_back(flat.narrow(0, o, p.numel()).view(p.sizes()));
+      o += p.numel();
+    }
+    std::vector<vmlmf_stack_layer> ly(L);
+    std::vector<vmlmf_params> ps(L);
+    std::vector<vmlmf_grads> gs(L);
+    std::vector<size_t> rbytes(L);
+    size_t wbytes = 0;
+    memset(ly.data(), 0, sizeof(vmlmf_stack_layer) * L);
+    for (int64_t l = 0; l < L; ++l) {
+      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, {u_rank}, 1, time_major, true, VMLMF_DT_F32);
+      std::vector<Tensor> pl(params.begin() + l * nper, params.begin() + (l + 1) * nper);
+      std::vector<Tensor> gl(grads.begin() + l * nper, grads.begin() + (l + 1) * nper);
+      fill_params(ps[l], pl, (int)variant, 1);
+      fill_params(gs[l], gl, (int)variant, 1);
+      ly[l].params = &ps[l], ly[l].grads = &gs[l];
+      ly[l].y = const_cast<float*>(saved[1 + l].data_ptr<float>());
+      ly[l].reserve = saved[1 + L + l].data_ptr();
+      ly[l].dhT = dhT.defined() ? dhT.data_ptr<float>() + l * B * H : nullptr;
+      ly[l].dcT = dcT.defined() ? dcT.data_ptr<float>() + l * B * H : nullptr;
+    }
+    check(vmlmf_stack_query((int)L, ly.data(), rbytes.data(), &wbytes));
+    Tensor ws = workspace(x, wbytes);
+    check(vmlmf_stack_backward((int)L, ly.data(), x.data_ptr<float>(), cptr(dy), mptr(dx), ws.data_ptr(), wbytes, stream_of(x)));
+    variable_list out = {dx};
+    for (auto& gt : grads) out.push_back(gt);
+    for (int i = 0; i < 6; ++i) out.push_back(Tensor());   // the integer configuration
+    return out;
+  }
+};
+
+std::tuple<Tensor, Tensor, Tensor> stack(const Tensor& x, at::TensorList params, int64_t L, int64_t variant, int64_t w_rank,
+                                         int64_t u_rank, bool time_major) {
+  bool training = x.requires_grad();
+  for (const auto& p : params) training = training || p.requires_grad();
+  training = training && at::GradMode::is_enabled();
+  auto out = StackFn::apply(x, params, L, variant, w_rank, u_rank, time_major, training);
+  return {out[0], out[1], out[2]};
+}
+
 // ---- classifier head ---------------------------------------------------------------------------------------------
 struct HeadFn : public torch::autograd::Function<HeadFn> {
   static Tensor forward(AutogradContext* ctx, Tensor h, Tensor weight, c10::optional<Tensor> bias) {
@@ -332,6 +442,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 
 TORCH_LIBRARY(vmlmf, m) {
   m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int u_rank, bool time_major) -> (Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }
@@ -339,6 +450,7 @@ TORCH_LIBRARY(vmlmf, m) {
 // registered for every dispatch key that reaches them: the functions build their own autograd nodes
 TORCH_LIBRARY_IMPL(vmlmf, CompositeImplicitAutograd, m) {
   m.impl("sequence", sequence);
+  m.impl("stack", stack);
   m.impl("head_linear", head_linear);
   m.impl("cross_entropy", cross_entropy);
 }

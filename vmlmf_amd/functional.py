@@ -414,8 +414,9 @@ class VmlmfStackFn(torch.autograd.Function):
 
 
 def stack_mode():
-    """VMLMF_STACK: "auto" (default: stacks of two or more covered layers whose layers x rows fit the chip's 256 CUs at once),
-    "0" (never: chain the per-layer calls), "1" (whenever the wavefront kernels cover the stack, single layers included)."""
+    """VMLMF_STACK: "auto" (default: covered stacks whose layers x rows fit the chip's 256 CUs at once; a single layer only
+    when its input is wider than 16, i.e. when its x-projection would otherwise be a launch of its own), "0" (never: chain
+    the per-layer calls), "1" (whenever the wavefront kernels cover the stack)."""
     import os
     return os.environ.get("VMLMF_STACK", "auto")
 
@@ -432,13 +433,17 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
-    if mode != "1" and (L < 2 or L * B > 256):
-        return None
+    if mode != "1" and (L * B > 256 or (L == 1 and x.shape[2] <= 16)):
+        return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel)
     H = _hidden_size(variant, layer_params[0])
     training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
         return None
     flat = [p for ps in layer_params for p in ps]
+    ops = torch_ops()
+    if ops is not None:
+        y, hT, cT = ops.stack(x, flat, L, variant, int(w_rank), ur[0], bool(time_major))
+        return y, list(hT.unbind(0)), list(cT.unbind(0))
     out = VmlmfStackFn.apply(cfg, L, x, *flat)
     return out[0], list(out[1:1 + L]), list(out[1 + L:])
 
