@@ -128,6 +128,14 @@ if __name__ == "__main__":
             _lib.tune("rb_cluster", S)
             run(f"E-shape: PTB V3 H=650 r=32 B=256 T=35 x2 layers, cluster of {S}", *lm(256, False), 1, 10)
         _lib.tune("rb_cluster", 0)
+    if which == "e_rows":  # configs[4]: fewer live rows per workgroup with a smaller cluster (the same 256 workgroups)
+        for S, rows in ((16, 16), (8, 8), (4, 4), (8, 16)):
+            _lib.tune("rb_cluster", S)
+            _lib.tune("rb_rows", rows)
+            run(f"E: PTB V4 group B=256 T=35 x2 layers, cluster of {S}, {rows} live rows", *lm(256, True), 1, 10)
+            run(f"E-shape: PTB V3 B=256 T=35 x2 layers, cluster of {S}, {rows} live rows", *lm(256, False), 1, 10)
+        _lib.tune("rb_cluster", 0)
+        _lib.tune("rb_rows", 0)
     if which == "e32":     # configs[4] per GPU on an 8-GPU node: 32 rows
         for S in (4, 8, 16):
             _lib.tune("rb_cluster", S)
