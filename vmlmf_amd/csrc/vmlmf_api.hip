@@ -219,7 +219,7 @@ struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
   long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
   // forward workspace  : PACK (inference only) | gx
-  long long f_pack, f_gx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
+  long long f_pack, f_gx, f_qx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
   long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_headdh, b_total;
 };
@@ -238,6 +238,7 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   o = 0;
   L.f_pack = o, o += align64(P.total);
   L.f_gx = o, o += align64(TS * 4);
+  L.f_qx = o, o += align64(g.generic ? TB * g.KX : 0);   // qx of an inference call on a large layer (the MFMA x-side expansion reads it)
   L.f_trash = o, o += 64;
   {
     const long long gen = (g.generic && !g.rb) ? 1 : 0, BN = (long long)g.B * g.NT;
@@ -465,7 +466,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   const bool xwave = g_xwave && vg_xwave_ok(g);
   if (!xwave) {
     Scope sc(1, s);
-    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : nullptr, s), "xproj")) != 0)
+    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : (g.generic ? ws + L.f_qx : nullptr), s), "xproj")) != 0)
       return rc;
   }
   if (g.rb) {

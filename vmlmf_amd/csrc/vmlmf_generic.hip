@@ -873,3 +873,9 @@ int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s) {
   }
   return 0;
 }
+
+// qx = x U_x over all rows of a large time-major layer (rows of x contiguous in (t, b) order): a skinny product with K = the
+// input width, on the 16 x 16 MFMA tiles of gemm_skinny_kernel.  (xproj_kernel's own form of it took 50 us at H = 650.)
+int generic_qx(const VGeo& g, const float* x, const float* UXP, float* qx, hipStream_t s) {
+  return gemm(x, g.I, UXP, g.KX, qx, g.KX, g.T * g.B, g.KX, g.I, nullptr, 0, nullptr, 0, s);
+}

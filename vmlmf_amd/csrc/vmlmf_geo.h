@@ -55,6 +55,7 @@ struct VPack {
   long long VE, UR, VR, UE, EH, VRX, UXO, EXI, UXP, VXT, EXT, BBT;
   long long UD, VD, UDT, VDT, VXTT;   // dense group factors + V_x^T, step-wise path only
   long long TKT;                      // split-K tickets of the step-wise GEMMs (ints; pack_kernel zeroes them)
+  long long VXD;                      // V_x as a (rank x 4*slots) matrix: B operand of the MFMA x-side expansion (large layers)
   long long WXD;                      // dense x-side matrix W_x[m][k][slot] of the x-projection wave (I <= 16 only)
   long long RB;                       // A-operand images of the row-block kernels (RbGeo offsets are relative to RB)
   long long WF, total;                // rotated images of the wavefront kernels (WfPack offsets are relative to WF)
@@ -101,6 +102,7 @@ VG_HD VPack vg_pack_layout(const VGeo& g, long long rb_floats = 0, long long wf_
   p.VDT = take(dense ? N4 * GK : 0);
   p.VXTT = take(g.generic ? N4 * g.KX : 0);
   p.TKT = take(g.generic ? VG_GEMM_TICKETS : 0);
+  p.VXD = take(g.generic ? N4 * g.KX : 0);
   p.WXD = take(vg_xwave_ok(g) ? 4LL * g.I * g.NT : 0);
   p.RB = take(g.rb ? rb_floats : 0);
   p.WF = take(wf_floats);

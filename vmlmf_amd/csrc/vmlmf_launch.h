@@ -64,6 +64,8 @@ int generic_forward(const VGeo& g, const GenericBuf& w, hipStream_t s);
 int generic_backward(const VGeo& g, const GenericBuf& w, hipStream_t s);
 // the non-recurrent tail of generic_backward on its own: dqx = dpre V_x over all rows, then dx (row-block kernels on large layers)
 int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s);
+// qx = x U_x over all rows of a large time-major layer
+int generic_qx(const VGeo& g, const float* x, const float* UXP, float* qx, hipStream_t s);
 
 // row-block MFMA recurrent kernels (vmlmf_rb.hip)
 struct RbIo {

@@ -189,6 +189,14 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
         }
       } else if (e >= L.WXD) {  // WXD: dot workgroups
         if (e - (int)L.WXD < D.nWXD) continue;
+      } else if (e >= L.VXD) {  // VXD[r][slot*4+k]
+        const int le = e - (int)L.VXD;
+        if (le < g.KX * N4) {
+          rr = le / N4;
+          const int i = le - rr * N4;
+          k = i & 3;
+          if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
+        }
       }                         // else TKT: the split-K tickets start at zero
       if (mode == 1) {          // unit n feeds destination (grp - s) mod G through block s
         const int sblk = (g.G == 2 && rr >= g.off1) ? 1 : 0;
@@ -399,6 +407,7 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
       }
     }
   }
+  if (gx == nullptr) return;   // qx only: the expansion runs on the matrix cores (xexp_mfma_kernel, large layers)
   __syncthreads();
   for (int slot = tid; slot < NT; slot += 256) {
     int n;
@@ -446,6 +455,87 @@ __global__ void __launch_bounds__(256) xproj_kernel(VGeo g, const float* __restr
   }
 }
 
+// The expansion of the x side for LARGE layers (step-wise / clustered families: H = 650 ...) on fp32 MFMA:
+//   gx[row][slot][k] = sum_r qx[row][r] VXD[r][slot*4+k] + x[row][n] ex[k][n] + bb[k][n]
+// 64 x 64 tiles of the (T*B) x (4*slots) result, four waves with a 32 x 32 sub-tile each on v_mfma_f32_32x32x2_f32, K = the
+// padded x rank (<= 32) staged through LDS in one go, the tile then goes through LDS into (row, slot) elements whose four
+// gates are one 16-byte store.  As VALU FMAs in xproj_kernel (one thread per slot, 4 KX weights in registers, 8 rows per
+// workgroup) this expansion was 120 us per PTB layer (8960 rows x 2816 columns); it is bound by the 100 MB it writes.
+template <int KX>
+__global__ void __launch_bounds__(256) xexp_mfma_kernel(VGeo g, const float* __restrict__ x, const float* __restrict__ qx,
+                                                        const float* __restrict__ vxd, const float* __restrict__ ext,
+                                                        const float* __restrict__ bbt, float* __restrict__ gx) {
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
+  constexpr int PADM = 68;
+  __shared__ float As[KX][PADM];   // [k][row]
+  __shared__ float Bs[KX][PADM];   // [k][column]
+  __shared__ float Ct[64][PADM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lk = lane >> 5, wm = wave & 1, wn = wave >> 1;
+  const int NT = g.NT, N = 4 * NT, TB = g.T * g.B, B = g.B, H = g.H;
+  const int tiles_n = N / 64;   // NT is a multiple of 64
+  const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+  const int m0 = tm * 64, n0 = tn * 64;
+  {
+    const int ar = tid >> 2, aj = tid & 3;
+    const bool rok = m0 + ar < TB;
+    const float* ap = qx + (size_t)(rok ? m0 + ar : 0) * KX;
+    float ra[KX / 4];
+#pragma unroll
+    for (int i = 0; i < KX / 4; ++i) ra[i] = ap[aj + 4 * i];   // unconditional loads, masked values
+    const int bk = tid >> 4, bn = (tid & 15) * 4;
+    float4 rb[(KX + 15) / 16];
+#pragma unroll
+    for (int i = 0; i < (KX + 15) / 16; ++i) {
+      const int k = bk + 16 * i;
+      rb[i] = ld4(vxd + (size_t)(k < KX ? k : 0) * N + n0 + bn);
+    }
+#pragma unroll
+    for (int i = 0; i < KX / 4; ++i) As[aj + 4 * i][ar] = rok ? ra[i] : 0.f;
+#pragma unroll
+    for (int i = 0; i < (KX + 15) / 16; ++i)
+      if (bk + 16 * i < KX) *reinterpret_cast<float4*>(&Bs[bk + 16 * i][bn]) = rb[i];
+  }
+  __syncthreads();
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+  for (int s2 = 0; s2 < KX / 2; ++s2)
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[2 * s2 + lk][32 * wm + li], Bs[2 * s2 + lk][32 * wn + li], acc, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) Ct[32 * wm + (r & 3) + 8 * (r >> 2) + 4 * lk][32 * wn + li] = acc[r];
+  __syncthreads();
+  // thread -> slot (n0 / 4 + tid % 16) of rows tid / 16 + 16 i: every load of its four elements before the first store
+  const int sl = tid & 15, slot = (n0 >> 2) + sl;
+  int n;
+  const bool valid = vg_slot_unit(g, slot, n);
+  const int nc = valid ? n : 0;
+  const float e0 = ext[0 * H + nc], e1 = ext[1 * H + nc], e2 = ext[2 * H + nc], e3 = ext[3 * H + nc];
+  const float b0 = bbt[0 * H + nc], b1 = bbt[1 * H + nc], b2 = bbt[2 * H + nc], b3 = bbt[3 * H + nc];
+  const bool hasx = valid && n < g.I;
+  float xv[4];
+  int rg[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    rg[i] = m0 + (tid >> 4) + 16 * i;
+    const int rc = rg[i] < TB ? rg[i] : TB - 1;
+    const int t = rc / B, b = rc - t * B;
+    const float v = x[(size_t)t * g.sxT + (size_t)b * g.sxB + (hasx ? n : 0)];
+    xv[i] = hasx ? v : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (rg[i] < TB) {
+      const float4 c4 = *reinterpret_cast<const float4*>(&Ct[(tid >> 4) + 16 * i][4 * sl]);
+      const float4 out = valid ? make_float4(fmaf(xv[i], e0, c4.x + b0), fmaf(xv[i], e1, c4.y + b1), fmaf(xv[i], e2, c4.z + b2),
+                                             fmaf(xv[i], e3, c4.w + b3))
+                               : f4zero();
+      st4(gx + ((size_t)rg[i] * NT + slot) * 4, out);
+    }
+  }
+}
+
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
                  hipStream_t s) {
   const int TBp = g.T * g.Bp;
@@ -471,6 +561,15 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
       hipLaunchKernelGGL((xproj_kernel<K, 8>), grid, block, lds, s, g, x, uxp, vxt, ext, bbt, gx, qx);      \
     }                                                                                                       \
     break;
+  // large layers: qx by this kernel (gx = nullptr), the expansion on the matrix cores.  VMLMF_XEXP=0 keeps the VALU form (A/B)
+  static const bool xexp_on = []() { const char* e = getenv("VMLMF_XEXP"); return e == nullptr || e[0] != '0'; }();
+  const bool xexp = xexp_on && g.generic && !g.bf && g.Bp == g.B && qx != nullptr;
+  float* const gx_final = gx;
+  if (xexp) gx = nullptr;
+  if (xexp && g.time_major && g.I >= 256 && g.KX % 16 == 0) {   // qx as a skinny MFMA product (rows of x contiguous in (t, b) order)
+    const int rc = generic_qx(g, x, uxp, qx, s);
+    if (rc != 0) return rc;
+  } else
   switch (g.KX) {
     VX_CASE(8)
     VX_CASE(16)
@@ -480,6 +579,18 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
       return -3;
   }
 #undef VX_CASE
+  if (xexp) {
+    const hipError_t e0 = hipGetLastError();
+    if (e0 != hipSuccess) return (int)e0;
+    const dim3 grid2((unsigned)(((long long)g.T * g.B + 63) / 64 * (4 * g.NT / 64)));
+    const float* vxd = pack + L.VXD;
+    switch (g.KX) {
+      case 8: hipLaunchKernelGGL((xexp_mfma_kernel<8>), grid2, block, 0, s, g, x, qx, vxd, ext, bbt, gx_final); break;
+      case 16: hipLaunchKernelGGL((xexp_mfma_kernel<16>), grid2, block, 0, s, g, x, qx, vxd, ext, bbt, gx_final); break;
+      case 24: hipLaunchKernelGGL((xexp_mfma_kernel<24>), grid2, block, 0, s, g, x, qx, vxd, ext, bbt, gx_final); break;
+      case 32: hipLaunchKernelGGL((xexp_mfma_kernel<32>), grid2, block, 0, s, g, x, qx, vxd, ext, bbt, gx_final); break;
+    }
+  }
   return (int)hipGetLastError();
 }
 
