@@ -10,7 +10,9 @@ import sys
 
 OURS = ("pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel",
         "reduce_cg_kernel", "finish_kernel", "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel",
-        "adam_kernel")
+        "adam_kernel", "wf_fwd_kernel", "wf_bwd_kernel", "pack_stack_kernel", "wgrad_mfma_stack_kernel",
+        "reduce_cg_stack_kernel", "finish_stack_kernel", "rb_fwd_kernel", "rb_bwd_kernel", "rb_pack_kernel",
+        "xexp_mfma_kernel", "gemm_skinny_kernel")
 
 
 def per_kernel(db, counter):
