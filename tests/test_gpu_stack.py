@@ -160,3 +160,40 @@ def test_stack_through_both_bindings():
     if F.torch_ops() is not None:
         assert outs["cpp"]["binding"] == "cpp"
         assert outs["cpp"]["vals"] == outs["ctypes"]["vals"]
+
+
+def test_stack_time_major_lm_layers():
+    """Stacks of LM layers (MyVMLSTM, time-major, vmlmf_lm.py:437-439) through vmlmf_stack against the chained layer calls."""
+    import vmlmf_amd
+    from vmlmf_amd import _lib, functional as F
+    torch.manual_seed(21)
+    T, B, H, r, L = 11, 10, 96, 16, 3
+    layers = [vmlmf_amd.MyVMLSTM(H, H, w_rank=r, u_ranks=r).cuda() for _ in range(L)]
+    for l in layers:
+        for p in l.parameters():
+            torch.nn.init.uniform_(p, -0.3, 0.3)
+    x = (0.5 * torch.randn(T, B, H, device="cuda")).requires_grad_(True)
+    gy = torch.randn(T, B, H, device="cuda")
+    zeros = (torch.zeros(B, H, device="cuda"), torch.zeros(B, H, device="cuda"))
+    h = x
+    for l in layers:
+        h, _ = l(h, zeros)
+    (h * gy).sum().backward()
+    ref_y, ref_dx = h.detach().clone(), x.grad.clone()
+    ref_g = [p.grad.clone() for l in layers for p in l.parameters()]
+    x.grad = None
+    for l in layers:
+        l.zero_grad(set_to_none=True)
+    os.environ["VMLMF_STACK"] = "1"
+    try:
+        out = F.vmlmf_stack(_lib.V3_LM, x, [l.kernel_params() for l in layers], r, [r], g=1, time_major=True)
+    finally:
+        os.environ.pop("VMLMF_STACK", None)
+    assert out is not None
+    y = out[0]
+    (y * gy).sum().backward()
+    torch.cuda.synchronize()
+    assert float((y - ref_y).abs().max()) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert float((x.grad - ref_dx).abs().max()) <= 1e-4 * float(ref_dx.abs().max()) + 1e-6
+    for got, ref in zip([p.grad for l in layers for p in l.parameters()], ref_g):
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6
