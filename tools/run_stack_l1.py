@@ -1,0 +1,31 @@
+"""Single wide-input layer (H 180, I 77, r 16, B 64): wavefront launch (in-kernel x side) against the chained kernels
+(xproj + recurrence + dqx_dx) over the sequence length: where the x-team's per-step cost overtakes the launches it saves."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from vmlmf_amd import MyLSTM, MyVMLMFCell
+H, I, r, B = 180, 77, 16, 64
+for L in (1, 2):
+    for T in (16, 32, 64, 128, 256):
+        res = {}
+        for mode in ("0", "1"):
+            os.environ["VMLMF_STACK"] = mode
+            torch.manual_seed(0)
+            rnn = MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=r, u_ranks=r, cell=MyVMLMFCell).cuda()
+            x = torch.randn(B, T, I, device="cuda")
+            def step():
+                rnn.zero_grad(set_to_none=True)
+                y, _ = rnn(x)
+                y[:, -1].sum().backward()
+            side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3): step()
+            torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g): step()
+            for _ in range(20): g.replay()
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(100): g.replay()
+            torch.cuda.synchronize(); res[mode] = (time.perf_counter() - t0) / 100 * 1e3
+        print(f"L {L} T {T:4d}: chained {res['0']:.4f} ms  wavefront {res['1']:.4f} ms", flush=True)

@@ -415,7 +415,7 @@ class VmlmfStackFn(torch.autograd.Function):
 
 def stack_mode():
     """VMLMF_STACK: "auto" (default: covered stacks whose layers x rows fit the chip's 256 CUs at once; a single layer only
-    when its input is wider than 16, i.e. when its x-projection would otherwise be a launch of its own), "0" (never: chain
+    when its input is wider than 16, i.e. when its x-projection would otherwise be a launch of its own, and T <= 96), "0" (never: chain
     the per-layer calls), "1" (whenever the wavefront kernels cover the stack)."""
     import os
     return os.environ.get("VMLMF_STACK", "auto")
@@ -433,8 +433,10 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
-    if mode != "1" and (L * B > 256 or (L == 1 and x.shape[2] <= 16)):
-        return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel)
+    if mode != "1" and (L * B > 256 or (L == 1 and (x.shape[2] <= 16 or T > 96))):
+        return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel; with a wide
+                             #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
+                             #  profiles/r02_stack_vs_chained_over_T.txt)
     H = _hidden_size(variant, layer_params[0])
     training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
