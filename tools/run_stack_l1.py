@@ -6,8 +6,13 @@ sys.path.insert(0, ROOT)
 import torch
 from vmlmf_amd import MyLSTM, MyVMLMFCell
 H, I, r, B = 180, 77, 16, 64
-for L in (1, 2):
-    for T in (16, 32, 64, 128, 256):
+if len(sys.argv) > 4:
+    H, I, r = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+BS = [int(v) for v in sys.argv[4].split(',')] if len(sys.argv) > 4 else [B]
+TS = [int(v) for v in sys.argv[5].split(',')] if len(sys.argv) > 5 else [16, 32, 64, 128, 256]
+LS = [int(v) for v in sys.argv[6].split(',')] if len(sys.argv) > 6 else [1, 2]
+for L, B in [(l, b) for l in LS for b in BS]:
+    for T in TS:
         res = {}
         for mode in ("0", "1"):
             os.environ["VMLMF_STACK"] = mode
@@ -28,4 +33,4 @@ for L in (1, 2):
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(100): g.replay()
             torch.cuda.synchronize(); res[mode] = (time.perf_counter() - t0) / 100 * 1e3
-        print(f"L {L} T {T:4d}: chained {res['0']:.4f} ms  wavefront {res['1']:.4f} ms", flush=True)
+        print(f"L {L} B {B:4d} T {T:4d}: chained {res['0']:.4f} ms  wavefront {res['1']:.4f} ms", flush=True)

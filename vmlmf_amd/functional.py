@@ -414,9 +414,10 @@ class VmlmfStackFn(torch.autograd.Function):
 
 
 def stack_mode():
-    """VMLMF_STACK: "auto" (default: covered stacks whose layers x rows fit the chip's 256 CUs at once; a single layer only
-    when its input is wider than 16, i.e. when its x-projection would otherwise be a launch of its own, and T <= 96), "0" (never: chain
-    the per-layer calls), "1" (whenever the wavefront kernels cover the stack)."""
+    """VMLMF_STACK: "auto" (default: every covered stack of two or more layers - measured faster than the chained kernels
+    from B = 64 to 2048, profiles/r02_stack_vs_chained_over_batch.txt; a single layer only when its input is wider than 16,
+    i.e. when its x-projection would otherwise be a launch of its own, and T <= 96), "0" (never: chain the per-layer
+    calls), "1" (whenever the wavefront kernels cover the stack)."""
     import os
     return os.environ.get("VMLMF_STACK", "auto")
 
@@ -433,7 +434,7 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
-    if mode != "1" and (L * B > 256 or (L == 1 and (x.shape[2] <= 16 or T > 96))):
+    if mode != "1" and L == 1 and (x.shape[2] <= 16 or T > 96):
         return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel; with a wide
                              #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
                              #  profiles/r02_stack_vs_chained_over_T.txt)
