@@ -38,6 +38,9 @@ CASES = [
     (1, 9, 6, 77, 180, 8, "vm"),
     (2, 6, 5, 24, 72, 16, "lmf"),         # MyLSTMCell in low-rank mode (variant 5)
     (2, 300, 4, 10, 64, 8, "vm"),         # more workgroups than CUs
+    (3, 4, 1, 12, 40, 8, "vm"),           # one and two time steps: the pipelines of the x-team and of the hand-over barely start
+    (2, 6, 2, 30, 64, 16, "vm"),
+    (2, 520, 3, 16, 128, 16, "vm"),
 ]
 
 
@@ -193,7 +196,7 @@ def test_stack_time_major_lm_layers():
     y = out[0]
     (y * gy).sum().backward()
     torch.cuda.synchronize()
-    assert float((y - ref_y).abs().max()) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert float((y.detach() - ref_y).abs().max()) <= 2e-5 * max(1.0, float(ref_y.abs().max()))
     assert float((x.grad - ref_dx).abs().max()) <= 1e-4 * float(ref_dx.abs().max()) + 1e-6
     for got, ref in zip([p.grad for l in layers for p in l.parameters()], ref_g):
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6
