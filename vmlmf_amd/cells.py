@@ -18,7 +18,7 @@ import torch
 from torch import nn
 
 from . import _lib
-from .functional import head_linear, vmlmf_sequence, vmlmf_stack
+from .functional import head_linear, stack_mode, vmlmf_sequence, vmlmf_stack
 
 TIME_STEPS = 128
 RECURRENT_MAX = pow(2, 1 / TIME_STEPS)
@@ -288,7 +288,10 @@ class MyLSTM(nn.Module):
             cfg = cells[0].kernel_cfg()
             cfg.pop("pack_cache", None)
             if all({k: v for k, v in c.kernel_cfg().items() if k != "pack_cache"} == cfg for c in cells[1:]):
-                out = vmlmf_stack(x=x, layer_params=[c.kernel_params() for c in cells], time_major=not self.batch_first, **cfg)
+                # (a single layer whose kept parameter images were asked for stays on the per-layer call, which uses them)
+                kept = len(cells) == 1 and getattr(cells[0], "_pack_cache", None) is not None and stack_mode() != "1"
+                out = None if kept else vmlmf_stack(x=x, layer_params=[c.kernel_params() for c in cells],
+                                                    time_major=not self.batch_first, **cfg)
                 if out is not None:
                     return (out[0], out[1], None) if head is not None else (out[0], out[1])
         for i, cell in enumerate(self.rnncells):
