@@ -209,11 +209,14 @@ typedef struct vmlmf_stack_layer {
 } vmlmf_stack_layer;
 /* sizes for the stack: reserve_bytes[l] per layer, one workspace for either direction */
 int vmlmf_stack_query(int L, const vmlmf_stack_layer *layers, size_t *reserve_bytes, size_t *workspace_bytes);
-int vmlmf_stack_forward(int L, const vmlmf_stack_layer *layers, const float *x, void *workspace, size_t workspace_bytes,
-                        void *stream);
+/* head (or NULL): a classifier on the TOP layer's final hidden state (Net.lin, vmlmf.py:345,353-355), as in
+ * vmlmf_seq_forward_ex / _backward_ex: its logits come out of the forward launch's epilogue, d(hT) = dlogits W enters the
+ * backward launch's prologue, dW / db are outputs of the stack's finish launch. */
+int vmlmf_stack_forward(int L, const vmlmf_stack_layer *layers, const float *x, const vmlmf_head *head, void *workspace,
+                        size_t workspace_bytes, void *stream);
 /* dy: gradient of the top layer's y (or NULL); dx: gradient of x (or NULL when not wanted) */
 int vmlmf_stack_backward(int L, const vmlmf_stack_layer *layers, const float *x, const float *dy, float *dx,
-                         void *workspace, size_t workspace_bytes, void *stream);
+                         const vmlmf_head *head, void *workspace, size_t workspace_bytes, void *stream);
 
 int vmlmf_seq_backward(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
                        const float *c0, const float *y, const void *reserve, const float *dy,

@@ -200,3 +200,39 @@ def test_stack_time_major_lm_layers():
     assert float((x.grad - ref_dx).abs().max()) <= 1e-4 * float(ref_dx.abs().max()) + 1e-6
     for got, ref in zip([p.grad for l in layers for p in l.parameters()], ref_g):
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6
+
+
+@pytest.mark.parametrize("L,B,T,I,H,r", [(2, 128, 24, 77, 256, 24), (2, 9, 7, 12, 40, 8), (3, 5, 4, 30, 100, 16)])
+def test_net_classifier_rides_on_the_stack(L, B, T, I, H, r):
+    """Net (MyLSTM + Linear(H, 18) on the last time step, vmlmf.py:330-355) with the wavefront launches: the logits come out of
+    the forward launch, the classifier's backward is part of the stack's backward - against the chained per-layer form."""
+    import vmlmf_amd
+    from vmlmf_amd import Net, MyLSTM, MyVMLMFCell
+    torch.manual_seed(100 + L + B)
+    net = Net(I, layer_sizes=[H] * L, w_rank=r, u_rank=[r], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    with torch.no_grad():
+        for p in net.parameters():
+            p.mul_(1.5)
+        net.lin.weight.mul_(20.0)
+    x = torch.randn(B, T, I, device="cuda")
+    tgt = torch.randint(0, 18, (B,), device="cuda")
+    res = {}
+    for mode in ("0", "1"):
+        os.environ["VMLMF_STACK"] = mode
+        try:
+            net.zero_grad(set_to_none=True)
+            xx = x.clone().requires_grad_(True)
+            logits = net(xx)
+            loss = vmlmf_amd.cross_entropy(logits, tgt)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (logits.detach().clone(), xx.grad.clone(),
+                         {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None})
+        finally:
+            os.environ.pop("VMLMF_STACK", None)
+    a, b = res["1"], res["0"]
+    assert float((a[0] - b[0]).abs().max()) <= 2e-5 * max(1.0, float(b[0].abs().max()))
+    assert float((a[1] - b[1]).abs().max()) <= 1e-4 * float(b[1].abs().max()) + 1e-7
+    assert set(a[2]) == set(b[2])
+    for name, gref in b[2].items():
+        assert float((a[2][name] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-7, name

@@ -83,8 +83,8 @@ SYMBOLS = {
     "vmlmf_last_error": (ctypes.c_char_p, []),
     "vmlmf_tune": (_i, [ctypes.c_char_p, _i]),
     "vmlmf_stack_query": (_i, [_i, _vp, _vp, _vp]),
-    "vmlmf_stack_forward": (_i, [_i, _vp, _vp, _vp, _sz, _vp]),
-    "vmlmf_stack_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vmlmf_stack_forward": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vmlmf_stack_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),
     "vmlmf_seq_forward": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                _vp, _vp, _sz, _vp]),

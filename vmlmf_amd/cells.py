@@ -281,7 +281,7 @@ class MyLSTM(nn.Module):
         last layer's final hidden state also its logits (None when the last layer cannot carry it)."""
         hiddens, logits = [], None
         # every layer in one wavefront launch per direction when the stack is covered (same cell type and sizes above the
-        # first layer; include/vmlmf_hip.h: vmlmf_stack_*); a classifier then runs as its own (head) kernels
+        # first layer; include/vmlmf_hip.h: vmlmf_stack_*); a classifier rides on the top layer's workgroups
         cells = list(self.rnncells)
         if (x.is_cuda and all(type(c) is type(cells[0]) and hasattr(c, "kernel_cfg") for c in cells)
                 and len(set(self.hidden_layer_sizes)) == 1 and getattr(cells[0], "low_rank", True)):
@@ -291,9 +291,9 @@ class MyLSTM(nn.Module):
                 # (a single layer whose kept parameter images were asked for stays on the per-layer call, which uses them)
                 kept = len(cells) == 1 and getattr(cells[0], "_pack_cache", None) is not None and stack_mode() != "1"
                 out = None if kept else vmlmf_stack(x=x, layer_params=[c.kernel_params() for c in cells],
-                                                    time_major=not self.batch_first, **cfg)
+                                                    time_major=not self.batch_first, head=head, **cfg)
                 if out is not None:
-                    return (out[0], out[1], None) if head is not None else (out[0], out[1])
+                    return (out[0], out[1], out[3]) if head is not None else (out[0], out[1])
         for i, cell in enumerate(self.rnncells):
             fused = hasattr(cell, "sequence") and (not isinstance(cell, MyLSTMCell) or (cell.low_rank and x.is_cuda))
             if fused and head is not None and i == len(self.rnncells) - 1:

@@ -242,10 +242,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::
 }
 
 // ---- stacked layers: one wavefront launch per direction (C ABI 7: vmlmf_stack_*) ------------------------------------
-// outputs: y of the top layer, then hT and cT as (L, B, H) tensors.  Initial states are zero (MyLSTM.forward).
+// outputs: y of the top layer, hT and cT as (L, B, H) tensors, the logits of a classifier riding on the top layer (or an
+// empty tensor).  Initial states are zero (MyLSTM.forward).
 struct StackFn : public torch::autograd::Function<StackFn> {
   static variable_list forward(AutogradContext* ctx, Tensor x, at::TensorList params_in, int64_t L, int64_t variant, int64_t w_rank,
-                               int64_t u_rank, bool time_major, bool training) {
+                               int64_t u_rank, bool time_major, bool training, c10::optional<Tensor> head_w_o,
+                               c10::optional<Tensor> head_b_o) {
+    Tensor head_w = head_w_o.has_value() ? head_w_o->contiguous() : Tensor();
+    Tensor head_b = head_b_o.has_value() ? head_b_o->contiguous() : Tensor();
+    if (head_w.defined()) require_hip_f32(head_w, "head weight");
     ctx->set_materialize_grads(false);
     require_hip_f32(x, "input");
     x = x.contiguous();
@@ -280,16 +285,27 @@ struct StackFn : public torch::autograd::Function<StackFn> {
       ly[l].y = ys[l].data_ptr<float>(), ly[l].hT = hT.data_ptr<float>() + l * B * H, ly[l].cT = cT.data_ptr<float>() + l * B * H;
       ly[l].reserve = training ? reserves[l].data_ptr() : nullptr;
     }
-    check(vmlmf_stack_forward((int)L, ly.data(), x.data_ptr<float>(), ws.data_ptr(), wbytes, stream_of(x)));
+    Tensor logits = head_w.defined() ? at::empty({B, head_w.size(0)}, x.options()) : at::empty({0}, x.options());
+    vmlmf_head hd;
+    memset(&hd, 0, sizeof(hd));
+    if (head_w.defined()) {
+      TORCH_CHECK(head_w.dim() == 2 && head_w.size(1) == H, "vmlmf_amd: head weight must be (classes, hidden_size)");
+      hd.classes = (int)head_w.size(0), hd.weight = head_w.data_ptr<float>(), hd.bias = cptr(head_b), hd.logits = logits.data_ptr<float>();
+    }
+    check(vmlmf_stack_forward((int)L, ly.data(), x.data_ptr<float>(), head_w.defined() ? &hd : nullptr, ws.data_ptr(), wbytes,
+                              stream_of(x)));
     if (training) {
       variable_list saved = {x};
       for (auto& t : ys) saved.push_back(t);
       for (auto& t : reserves) saved.push_back(t);
       for (auto& t : params) saved.push_back(t);
+      if (head_w.defined()) saved.push_back(head_w);
       ctx->save_for_backward(saved);
       ctx->saved_data["cfg"] = std::vector<int64_t>{L, variant, w_rank, u_rank, time_major ? 1 : 0, B, T, I, H, (int64_t)nper};
+      ctx->saved_data["head"] = head_w.defined();
+      ctx->saved_data["head_b"] = head_b.defined();
     }
-    return {ys[L - 1], hT, cT};
+    return {ys[L - 1], hT, cT, logits};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list gout) {
@@ -298,7 +314,10 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     const int64_t L = cfg[0], variant = cfg[1], w_rank = cfg[2], u_rank = cfg[3], B = cfg[5], T = cfg[6], I = cfg[7], H = cfg[8], nper = cfg[9];
     const bool time_major = cfg[4] != 0;
     const Tensor& x = saved[0];
-    std::vector<Tensor> params(saved.begin() + 1 + 2 * L, saved.end());
+    const bool has_head = ctx->saved_data["head"].toBool(), has_head_b = ctx->saved_data["head_b"].toBool();
+    std::vector<Tensor> params(saved.begin() + 1 + 2 * L, saved.end() - (has_head ? 1 : 0));
+    Tensor head_w = has_head ? saved.back() : Tensor();
+    Tensor dlogits = (has_head && gout.size() > 3 && gout[3].defined()) ? gout[3].contiguous() : Tensor();
     Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
     Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
     Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
@@ -333,21 +352,37 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     }
     check(vmlmf_stack_query((int)L, ly.data(), rbytes.data(), &wbytes));
     Tensor ws = workspace(x, wbytes);
-    check(vmlmf_stack_backward((int)L, ly.data(), x.data_ptr<float>(), cptr(dy), mptr(dx), ws.data_ptr(), wbytes, stream_of(x)));
+    Tensor hflat, dW, db;
+    vmlmf_head hd;
+    memset(&hd, 0, sizeof(hd));
+    if (dlogits.defined()) {   // classifier gradients: weight and bias share one allocation
+      const int64_t C = head_w.size(0);
+      hflat = at::empty({C * H + C}, x.options());
+      dW = hflat.narrow(0, 0, C * H).view({C, H});
+      if (has_head_b) db = hflat.narrow(0, C * H, C);
+      hd.classes = (int)C, hd.weight = head_w.data_ptr<float>(), hd.dlogits = dlogits.data_ptr<float>();
+      hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
+    }
+    check(vmlmf_stack_backward((int)L, ly.data(), x.data_ptr<float>(), cptr(dy), mptr(dx), dlogits.defined() ? &hd : nullptr,
+                               ws.data_ptr(), wbytes, stream_of(x)));
     variable_list out = {dx};
     for (auto& gt : grads) out.push_back(gt);
     for (int i = 0; i < 6; ++i) out.push_back(Tensor());   // the integer configuration
+    out.push_back(dW);                                     // head weight, head bias
+    out.push_back(db);
     return out;
   }
 };
 
-std::tuple<Tensor, Tensor, Tensor> stack(const Tensor& x, at::TensorList params, int64_t L, int64_t variant, int64_t w_rank,
-                                         int64_t u_rank, bool time_major) {
+std::tuple<Tensor, Tensor, Tensor, Tensor> stack(const Tensor& x, at::TensorList params, int64_t L, int64_t variant, int64_t w_rank,
+                                                 int64_t u_rank, bool time_major, const c10::optional<Tensor>& head_w,
+                                                 const c10::optional<Tensor>& head_b) {
   bool training = x.requires_grad();
   for (const auto& p : params) training = training || p.requires_grad();
+  training = training || (head_w.has_value() && head_w->requires_grad()) || (head_b.has_value() && head_b->requires_grad());
   training = training && at::GradMode::is_enabled();
-  auto out = StackFn::apply(x, params, L, variant, w_rank, u_rank, time_major, training);
-  return {out[0], out[1], out[2]};
+  auto out = StackFn::apply(x, params, L, variant, w_rank, u_rank, time_major, training, head_w, head_b);
+  return {out[0], out[1], out[2], out[3]};
 }
 
 // ---- classifier head ---------------------------------------------------------------------------------------------
@@ -442,7 +477,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 
 TORCH_LIBRARY(vmlmf, m) {
   m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int u_rank, bool time_major) -> (Tensor, Tensor, Tensor)");
+  m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int u_rank, bool time_major, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }

@@ -724,12 +724,14 @@ int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_by
   return 0;
 }
 
-int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void* workspace, size_t workspace_bytes,
-                        void* stream) {
+int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, const vmlmf_head* head_in, void* workspace,
+                        size_t workspace_bytes, void* stream) {
   StackPlan S;
   int rc = stack_plan(L, ly, &S);
   if (rc != 0) return rc;
   if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
+  const vmlmf_head* head = (head_in != nullptr && head_in->classes != 0) ? head_in : nullptr;
+  if ((rc = check_head(S.g[L - 1], head, true)) != 0) return rc;
   if (workspace_bytes < (size_t)S.ws_total * sizeof(float)) return fail(VMLMF_E_WORKSPACE, "stack: workspace smaller than vmlmf_stack_query() reported");
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
@@ -737,6 +739,7 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+  if (head != nullptr) a.hd.W = head->weight, a.hd.bias = head->bias, a.hd.logits = head->logits, a.hd.C = head->classes;
   RefP rps[WF_MAXL];
   float* packs[WF_MAXL];
   for (int l = 0; l < L; ++l) {
@@ -771,12 +774,14 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, void
   return 0;
 }
 
-int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, const float* dy, float* dx, void* workspace,
-                         size_t workspace_bytes, void* stream) {
+int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, const float* dy, float* dx,
+                         const vmlmf_head* head_in, void* workspace, size_t workspace_bytes, void* stream) {
   StackPlan S;
   int rc = stack_plan(L, ly, &S);
   if (rc != 0) return rc;
   if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
+  const vmlmf_head* head = (head_in != nullptr && head_in->classes != 0) ? head_in : nullptr;
+  if ((rc = check_head(S.g[L - 1], head, false)) != 0) return rc;
   if (workspace_bytes < (size_t)S.ws_total * sizeof(float)) return fail(VMLMF_E_WORKSPACE, "stack: workspace smaller than vmlmf_stack_query() reported");
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
@@ -785,13 +790,22 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     if ((rc = check_pointers(S.g[l], ly[l].grads, "grads")) != 0) return rc;
     if (ly[l].y == nullptr || ly[l].reserve == nullptr) return fail(VMLMF_E_BADARG, "stack: null y / reserve");
   }
-  HeadBwd hb;
+  HeadBwd hb;      // per-layer kernels of the chained form: no classifier riding
   memset(&hb, 0, sizeof(hb));
+  HeadBwd hb_top;  // the classifier on the top layer
+  memset(&hb_top, 0, sizeof(hb_top));
+  if (head != nullptr) {
+    const VGeo& gt = S.g[L - 1];
+    hb_top.W = head->weight, hb_top.dl = head->dlogits, hb_top.hlast = ly[L - 1].y + (size_t)(gt.T - 1) * gt.syT, hb_top.ldh = gt.syB;
+    hb_top.dW = head->dweight, hb_top.db = head->dbias, hb_top.C = head->classes;
+  }
   const bool wave = g_wf_bwd && wf_bwd_built();
+  if (!wave && head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: the classifier rides on the wavefront backward only (VMLMF_WF_BWD=0 is an A/B switch)");
   if (wave) {
     WfBwdArgs a;
     memset(&a, 0, sizeof(a));
     a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L;   // cleared by the forward
+    a.hd = hb_top;
     for (int l = 0; l < L; ++l) {
       const VGeo& g = S.g[l];
       const Layout& Lr = S.lay[l];
@@ -846,7 +860,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     }
     {
       Scope sc(7, s);
-      if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, s), "finish")) != 0) return rc;
+      if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb_top, s), "finish")) != 0) return rc;
     }
     return 0;
   }

@@ -144,10 +144,12 @@ struct WfCommon {
 struct WfFwdArgs {
   WfCommon c;
   WfFwdLayer l[WF_MAXL];
+  HeadFwd hd;   // classifier on the top layer's final hidden state (C = 0: none)
 };
 struct WfBwdArgs {
   WfCommon c;
   WfBwdLayer l[WF_MAXL];
+  HeadBwd hd;
 };
 bool wf_supported(const VGeo& g);   // an instantiation exists for the layer's (rank, waves)
 WfPack wf_pack_layout(const VGeo& g);
@@ -160,7 +162,8 @@ int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 // the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)
 int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
 int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
-int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, hipStream_t s);
+int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
+                        hipStream_t s);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
 bool wf_bwd_built();   // (bring-up) the backward wavefront kernel exists
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated

@@ -813,16 +813,15 @@ struct FinishLayer {
   RefG o;
   const float* cg;
   long long nbody;
+  HeadBwd hd;   // classifier gradients ride with the top layer (C = 0 elsewhere)
 };
 struct FinishStack {
   FinishLayer l[WF_MAXL];
 };
 __global__ void __launch_bounds__(256) finish_stack_kernel(FinishStack S) {   // grid.y = layer (wavefront path; no classifier)
   const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
-  if ((long long)blockIdx.x * 256 >= f.nbody) return;
-  HeadBwd hd;
-  memset(&hd, 0, sizeof(hd));
-  finish_body(f.g, f.p, f.cg, f.o, hd, f.nbody);
+  if ((long long)blockIdx.x * 256 >= f.nbody && f.hd.C <= 0) return;
+  finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody);
 }
 
 static long long finish_elements(const VGeo& g) {
@@ -832,14 +831,20 @@ static long long finish_elements(const VGeo& g) {
   return (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
 }
 
-int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, hipStream_t s) {
+int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
+                        hipStream_t s) {
   static_assert(sizeof(FinishStack) <= 4096, "kernel-argument segment");
   FinishStack S;
   memset(&S, 0, sizeof(S));
   long long nmax = 0;
   for (int l = 0; l < L; ++l) {
     S.l[l].g = g[l], S.l[l].p = p[l], S.l[l].o = out[l], S.l[l].cg = cgrad[l], S.l[l].nbody = finish_elements(g[l]);
-    nmax = S.l[l].nbody > nmax ? S.l[l].nbody : nmax;
+    long long n = S.l[l].nbody;
+    if (l == L - 1 && hd_top.C > 0) {
+      S.l[l].hd = hd_top;
+      n += (16 * ((long long)hd_top.C * g[l].H + hd_top.C) + 255) / 256 * 256;   // sixteen lanes per classifier output
+    }
+    nmax = n > nmax ? n : nmax;
   }
   hipLaunchKernelGGL(finish_stack_kernel, dim3((unsigned)(nmax / 256), L), dim3(256), 0, s, S);
   return (int)hipGetLastError();

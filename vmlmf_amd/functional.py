@@ -337,7 +337,7 @@ class VmlmfStackFn(torch.autograd.Function):
     (MyLSTM.forward, vmlmf.py:296-298)."""
 
     @staticmethod
-    def forward(ctx, cfg, L, x, *params):
+    def forward(ctx, cfg, L, x, head_w, head_b, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -368,13 +368,24 @@ class VmlmfStackFn(torch.autograd.Function):
             ly.desc, ly.params = descs[l], ctypes.pointer(ps)
             ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[0, l].data_ptr(), hc[1, l].data_ptr()
             ly.reserve = None if reserves[l] is None else reserves[l].data_ptr()
+        # a classifier riding on the top layer's final hidden state (Net.lin): its logits are the last output
+        hw = None if head_w is None else head_w.contiguous()
+        hb = None if head_b is None else head_b.contiguous()
+        logits = torch.empty((B, hw.shape[0]) if hw is not None else (0,), device=dev, dtype=torch.float32)
+        hd = _lib.Head()
+        if hw is not None:
+            _require_hip(hw, "head weight")
+            hd.classes, hd.weight, hd.logits = hw.shape[0], hw.data_ptr(), logits.data_ptr()
+            hd.bias = None if hb is None else hb.data_ptr()
         with _lib.on_device(dev):
-            _lib.check(_lib.lib().vmlmf_stack_forward(L, ctypes.addressof(layers), x.data_ptr(), ws.data_ptr(), wbytes,
+            _lib.check(_lib.lib().vmlmf_stack_forward(L, ctypes.addressof(layers), x.data_ptr(),
+                                                      ctypes.addressof(hd) if hw is not None else None, ws.data_ptr(), wbytes,
                                                       _lib.raw_stream(dev)))
         if training:
             ctx.cfg, ctx.L, ctx.nper, ctx.plan = cfg, L, nper, plan
-            ctx.save_for_backward(x, *ys, *reserves, *params)
-        return (ys[-1],) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L))
+            ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
+            ctx.save_for_backward(x, *ys, *reserves, *params, *([hw] if hw is not None else []))
+        return (ys[-1],) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L)) + (logits,)
 
     @staticmethod
     def backward(ctx, dy, *dstates):
@@ -383,10 +394,14 @@ class VmlmfStackFn(torch.autograd.Function):
         descs, rbytes, wbytes = ctx.plan
         saved = ctx.saved_tensors
         x, ys, reserves, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
+        hw = None
+        if ctx.has_head:
+            params, hw = params[:-1], params[-1]
+        dlogits = dstates[2 * L]
         dev = x.device
         dy = None if dy is None else dy.contiguous()
         dhT = [None if d is None else d.contiguous() for d in dstates[:L]]
-        dcT = [None if d is None else d.contiguous() for d in dstates[L:]]
+        dcT = [None if d is None else d.contiguous() for d in dstates[L:2 * L]]
         need_dx = ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_dx else None
         # one flat buffer for the parameter gradients of the whole stack (views are returned)
@@ -407,10 +422,22 @@ class VmlmfStackFn(torch.autograd.Function):
             ly.y, ly.reserve = ys[l].data_ptr(), reserves[l].data_ptr()
             ly.dhT = None if dhT[l] is None else dhT[l].data_ptr()
             ly.dcT = None if dcT[l] is None else dcT[l].data_ptr()
+        dW = db = None
+        hd = _lib.Head()
+        use_head = hw is not None and dlogits is not None
+        if use_head:
+            dl = dlogits.contiguous()
+            C, H = hw.shape
+            hflat = torch.empty(C * H + C, device=dev, dtype=torch.float32)   # weight + bias gradients in one allocation
+            dW = hflat[:C * H].view(C, H)
+            db = hflat[C * H:] if ctx.has_head_b else None
+            hd.classes, hd.weight, hd.dlogits, hd.dweight = C, hw.data_ptr(), dl.data_ptr(), dW.data_ptr()
+            hd.dbias = None if db is None else db.data_ptr()
         with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_stack_backward(L, ctypes.addressof(layers), x.data_ptr(), _ptr(dy), _ptr(dx),
-                                                       ws.data_ptr(), wbytes, _lib.raw_stream(dev)))
-        return (None, None, dx) + tuple(grads)
+                                                       ctypes.addressof(hd) if use_head else None, ws.data_ptr(), wbytes,
+                                                       _lib.raw_stream(dev)))
+        return (None, None, dx, dW, db) + tuple(grads)
 
 
 def stack_mode():
@@ -422,10 +449,11 @@ def stack_mode():
     return os.environ.get("VMLMF_STACK", "auto")
 
 
-def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32"):
+def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", head=None):
     """Run a stack of VMLMF layers (zero initial states) in one wavefront launch per direction.  layer_params: one parameter
     tuple per layer, in vmlmf_sequence's order.  Returns (y of the top layer, [hT per layer], [cT per layer]) or None when
-    the stack is not covered / not worth it (the caller then chains vmlmf_sequence calls)."""
+    the stack is not covered / not worth it (the caller then chains vmlmf_sequence calls).  head: (weight (C, H), bias or
+    None) of a classifier on the top layer's final hidden state (<= 32 classes): a fourth element, its logits, is returned."""
     mode = stack_mode()
     L = len(layer_params)
     if mode == "0" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3:
@@ -443,12 +471,15 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
         return None
     flat = [p for ps in layer_params for p in ps]
+    hw, hb = (None, None) if head is None else head
     ops = torch_ops()
     if ops is not None:
-        y, hT, cT = ops.stack(x, flat, L, variant, int(w_rank), ur[0], bool(time_major))
-        return y, list(hT.unbind(0)), list(cT.unbind(0))
-    out = VmlmfStackFn.apply(cfg, L, x, *flat)
-    return out[0], list(out[1:1 + L]), list(out[1 + L:])
+        y, hT, cT, logits = ops.stack(x, flat, L, variant, int(w_rank), ur[0], bool(time_major), hw, hb)
+        out = (y, list(hT.unbind(0)), list(cT.unbind(0)))
+        return out + (logits,) if head is not None else out
+    res = VmlmfStackFn.apply(cfg, L, x, hw, hb, *flat)
+    out = (res[0], list(res[1:1 + L]), list(res[1 + L:1 + 2 * L]))
+    return out + (res[1 + 2 * L],) if head is not None else out
 
 
 class HeadLinearFn(torch.autograd.Function):
