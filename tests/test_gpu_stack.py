@@ -236,3 +236,38 @@ def test_net_classifier_rides_on_the_stack(L, B, T, I, H, r):
     assert set(a[2]) == set(b[2])
     for name, gref in b[2].items():
         assert float((a[2][name] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-7, name
+
+
+def test_stack_random_shapes_sweep():
+    """Thirty seeded random stacks (layers, batch, length, input width, hidden size, rank) through the wavefront launches
+    against the chained per-layer kernels: outputs, input gradient and every parameter gradient."""
+    import random
+    import vmlmf_amd
+    rng = random.Random(20261002)
+    for trial in range(30):
+        L = rng.choice([1, 2, 2, 3, 4])
+        r = rng.choice([8, 16, 24, 32])
+        hmax = 192 if r == 32 else 256
+        H = rng.randint(max(r, 12), hmax)
+        I = rng.randint(1, H)
+        B = rng.choice([1, 2, 3, 7, 8, 9, 17, 33, 70])
+        T = rng.randint(1, 20)
+        ru = rng.randint(max(1, r - 7), r)          # true ranks anywhere inside the padded width
+        rw = rng.randint(max(1, r - 7), r)
+        torch.manual_seed(trial)
+        model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=rw, u_ranks=ru,
+                                 cell=vmlmf_amd.MyVMLMFCell).cuda()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.3)
+        x = torch.randn(B, T, I, device="cuda")
+        gy = torch.randn(B, T, H, device="cuda")
+        gh = torch.randn(B, L * H, device="cuda")
+        ref = _run(model, x, "0", (gy, gh))
+        got = _run(model, x, "1", (gy, gh))
+        what = f"trial {trial}: L={L} B={B} T={T} I={I} H={H} rw={rw} ru={ru}"
+        for a, b in ((got[0], ref[0]), (got[1], ref[1])):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), what
+        assert float((got[2] - ref[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max()) + 1e-6, what
+        for name, gref in ref[3].items():
+            assert float((got[3][name] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-6, (what, name)
