@@ -271,3 +271,31 @@ def test_stack_random_shapes_sweep():
         assert float((got[2] - ref[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max()) + 1e-6, what
         for name, gref in ref[3].items():
             assert float((got[3][name] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-6, (what, name)
+
+
+def test_stack_backward_switch_chains_the_per_layer_kernels():
+    """VMLMF_WF_BWD=0 (read when the library loads): the stack's backward as the chained per-layer kernels behind the same
+    vmlmf_stack_backward call - same gradients as the wavefront backward, in a fresh interpreter each."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path[:0] = [%r]\n"
+        "import torch, vmlmf_amd\n"
+        "torch.manual_seed(11)\n"
+        "m = vmlmf_amd.MyLSTM(33, hidden_layer_sizes=[130, 130], batch_first=True, w_rank=24, u_ranks=24, cell=vmlmf_amd.MyVMLMFCell).cuda()\n"
+        "x = torch.randn(10, 9, 33, device='cuda', requires_grad=True)\n"
+        "y, h = m(x); (y.square().sum() + h.sum()).backward()\n"
+        "print('vals', ' '.join(repr(float(v)) for v in [y.double().sum(), x.grad.double().abs().sum()] + [p.grad.double().abs().sum() for p in m.parameters()]))\n"
+    ) % (os.path.dirname(here),)
+    vals = {}
+    for sw in ("1", "0"):
+        env = dict(os.environ)
+        env["VMLMF_STACK"] = "1"
+        env["VMLMF_WF_BWD"] = sw
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("vals ")][-1]
+        vals[sw] = [float(v) for v in line.split()[1:]]
+    for a, b in zip(vals["1"], vals["0"]):
+        assert abs(a - b) <= 1e-4 * abs(b) + 1e-6
