@@ -53,6 +53,51 @@ __device__ __forceinline__ void fmac_ror(float& acc, float src, float w) {
 }
 __device__ __forceinline__ void dpp_fence(float& src) { asm volatile("s_nop 1" : "+v"(src)); }
 
+// Whole rotation chains as ONE asm statement.  Between two single-instruction asm statements that write and then use the
+// same accumulator hipcc inserts an s_nop (it cannot know that the accumulator is not the DPP operand): one per pair of
+// instructions in the forward reduce, one per group of four in the backward one - 8 to 16 issue slots of a step.
+#define VG_DPP1(acc, src, w, k) "v_fmac_f32_dpp %" #acc ", %" #src ", %" #w " row_ror:" #k " row_mask:0xf bank_mask:0xf\n\t"
+// 16 rotations of `src` against w[0..15], even rotations into a0, odd ones into a1
+__device__ __forceinline__ void fmac_ror_x16(float& a0, float& a1, float src, const float* w) {
+  asm("v_fmac_f32 %0, %2, %3\n\t" VG_DPP1(1, 2, 4, 1) VG_DPP1(0, 2, 5, 2) VG_DPP1(1, 2, 6, 3) VG_DPP1(0, 2, 7, 4) VG_DPP1(1, 2, 8, 5)
+      VG_DPP1(0, 2, 9, 6) VG_DPP1(1, 2, 10, 7) VG_DPP1(0, 2, 11, 8) VG_DPP1(1, 2, 12, 9) VG_DPP1(0, 2, 13, 10) VG_DPP1(1, 2, 14, 11)
+      VG_DPP1(0, 2, 15, 12) VG_DPP1(1, 2, 16, 13) VG_DPP1(0, 2, 17, 14) VG_DPP1(1, 2, 18, 15)
+      : "+v"(a0), "+v"(a1)
+      : "v"(src), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "v"(w[9]),
+        "v"(w[10]), "v"(w[11]), "v"(w[12]), "v"(w[13]), "v"(w[14]), "v"(w[15]));
+}
+// 8 rotations (0..7) against w[0..7] (the half pass of vmlmf_wave.inc)
+__device__ __forceinline__ void fmac_ror_x8(float& a0, float& a1, float src, const float* w) {
+  asm("v_fmac_f32 %0, %2, %3\n\t" VG_DPP1(1, 2, 4, 1) VG_DPP1(0, 2, 5, 2) VG_DPP1(1, 2, 6, 3) VG_DPP1(0, 2, 7, 4) VG_DPP1(1, 2, 8, 5)
+      VG_DPP1(0, 2, 9, 6) VG_DPP1(1, 2, 10, 7)
+      : "+v"(a0), "+v"(a1)
+      : "v"(src), "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]));
+}
+// four rotations K0 .. K0+3 of the four gate derivatives d[0..3] against w_g[K0 .. K0+3], gate g into acc[g] (interleaved:
+// four independent chains)
+#define VG_STEP4(k, w0, w1, w2, w3) VG_DPP1(0, 4, w0, k) VG_DPP1(1, 5, w1, k) VG_DPP1(2, 6, w2, k) VG_DPP1(3, 7, w3, k)
+#define VG_STEP4_PLAIN(w0, w1, w2, w3) \
+  "v_fmac_f32 %0, %4, %" #w0 "\n\tv_fmac_f32 %1, %5, %" #w1 "\n\tv_fmac_f32 %2, %6, %" #w2 "\n\tv_fmac_f32 %3, %7, %" #w3 "\n\t"
+#define VG_BLOCK4_OPERANDS                                                                                                  \
+  : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])                                                                   \
+  : "v"(d[0]), "v"(d[1]), "v"(d[2]), "v"(d[3]), "v"(w0[K0]), "v"(w1[K0]), "v"(w2[K0]), "v"(w3[K0]), "v"(w0[K0 + 1]), "v"(w1[K0 + 1]), \
+    "v"(w2[K0 + 1]), "v"(w3[K0 + 1]), "v"(w0[K0 + 2]), "v"(w1[K0 + 2]), "v"(w2[K0 + 2]), "v"(w3[K0 + 2]), "v"(w0[K0 + 3]),  \
+    "v"(w1[K0 + 3]), "v"(w2[K0 + 3]), "v"(w3[K0 + 3])
+template <int K0>
+__device__ __forceinline__ void fmac_ror_4x4(float (&acc)[4], const float (&d)[4], const float* w0, const float* w1, const float* w2,
+                                             const float* w3) {
+  static_assert(K0 == 0 || K0 == 4 || K0 == 8 || K0 == 12, "blocks of four rotations");
+  if constexpr (K0 == 0) {
+    asm(VG_STEP4_PLAIN(8, 9, 10, 11) VG_STEP4(1, 12, 13, 14, 15) VG_STEP4(2, 16, 17, 18, 19) VG_STEP4(3, 20, 21, 22, 23) VG_BLOCK4_OPERANDS);
+  } else if constexpr (K0 == 4) {
+    asm(VG_STEP4(4, 8, 9, 10, 11) VG_STEP4(5, 12, 13, 14, 15) VG_STEP4(6, 16, 17, 18, 19) VG_STEP4(7, 20, 21, 22, 23) VG_BLOCK4_OPERANDS);
+  } else if constexpr (K0 == 8) {
+    asm(VG_STEP4(8, 8, 9, 10, 11) VG_STEP4(9, 12, 13, 14, 15) VG_STEP4(10, 16, 17, 18, 19) VG_STEP4(11, 20, 21, 22, 23) VG_BLOCK4_OPERANDS);
+  } else {
+    asm(VG_STEP4(12, 8, 9, 10, 11) VG_STEP4(13, 12, 13, 14, 15) VG_STEP4(14, 16, 17, 18, 19) VG_STEP4(15, 20, 21, 22, 23) VG_BLOCK4_OPERANDS);
+  }
+}
+
 // x + (x rotated by K lanes inside the 16-lane row), one instruction (v_add_f32 with a DPP operand)
 template <int K>
 __device__ __forceinline__ float add_ror16(float x) {
