@@ -799,7 +799,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     hb_top.W = head->weight, hb_top.dl = head->dlogits, hb_top.hlast = ly[L - 1].y + (size_t)(gt.T - 1) * gt.syT, hb_top.ldh = gt.syB;
     hb_top.dW = head->dweight, hb_top.db = head->dbias, hb_top.C = head->classes;
   }
-  const bool wave = g_wf_bwd && wf_bwd_built();
+  const bool wave = g_wf_bwd;
   if (!wave && head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: the classifier rides on the wavefront backward only (VMLMF_WF_BWD=0 is an A/B switch)");
   if (wave) {
     WfBwdArgs a;

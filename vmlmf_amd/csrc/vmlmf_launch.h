@@ -164,7 +164,6 @@ int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
 int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
                         hipStream_t s);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
-bool wf_bwd_built();   // (bring-up) the backward wavefront kernel exists
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

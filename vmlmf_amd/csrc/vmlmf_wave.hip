@@ -49,5 +49,3 @@ int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s) {
   }
   return -3;
 }
-
-bool wf_bwd_built() { return true; }
