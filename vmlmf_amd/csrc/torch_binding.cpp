@@ -192,7 +192,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     std::vector<Tensor> grads;
     int64_t o = 0;
     for (const auto& p : params) {
-      grads.push_back(flat.narrow(0, o, p.numel()).view(p.sizes()));
+      grads.push_back(flat.as_strided(p.sizes(), p.strides(), o));   // one op per view (narrow + view were two)
       o += p.numel();
     }
     Tensor ws = workspace(x, sz.workspace_bytes);
@@ -329,7 +329,7 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     std::vector<Tensor> grads;
     int64_t o = 0;
     for (const auto& p : params) {
-      grads.push_back(flat.narrow(0, o, p.numel()).view(p.sizes()));
+      grads.push_back(flat.as_strided(p.sizes(), p.strides(), o));   // one op per view (narrow + view were two)
       o += p.numel();
     }
     std::vector<vmlmf_stack_layer> ly(L);
