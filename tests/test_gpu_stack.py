@@ -299,3 +299,68 @@ def test_stack_backward_switch_chains_the_per_layer_kernels():
         vals[sw] = [float(v) for v in line.split()[1:]]
     for a, b in zip(vals["1"], vals["0"]):
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6
+
+
+@pytest.mark.parametrize("variant_name,time_major", [("V1", False), ("V3", True), ("V5", False)])
+def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_major):
+    """The stack entry points with everything the per-layer calls take - initial states of every layer, gradients into
+    every layer's final states, gradients of the initial states - against the literal fp64 restatement of the reference
+    chained layer by layer (vmlmf.py:300-314 / vmlmf_lm.py:437-439)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "oracle"), here]
+    import vmlmf_oracle as O
+    from hip_util import ORDER, assert_grad, assert_out
+    from vmlmf_amd import functional as F
+    variant = getattr(O, variant_name)
+    L, B, T, I, H, rw, ru = 3, 6, 7, (48 if variant_name == "V3" else 20), 48, 13, 10
+    rng = np.random.Generator(np.random.PCG64(77))
+    Ps = [O.make_params(variant, I if l == 0 else H, H, rw, ru, seed=3 + l) for l in range(L)]
+    shp = (T, B, I) if time_major else (B, T, I)
+    x = rng.standard_normal(shp).astype(np.float32)
+    h0 = (0.5 * rng.standard_normal((L, B, H))).astype(np.float32)
+    c0 = (0.5 * rng.standard_normal((L, B, H))).astype(np.float32)
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((L, B, H)).astype(np.float32)
+    dcT = rng.standard_normal((L, B, H)).astype(np.float32)
+    # ---- oracle, fp64
+    Pt = [O.to_torch(P, dtype=torch.float64, requires_grad=True) for P in Ps]
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    h0t = torch.tensor(h0, dtype=torch.float64, requires_grad=True)
+    c0t = torch.tensor(c0, dtype=torch.float64, requires_grad=True)
+    cur, loss = xt, 0.0
+    hTs, cTs = [], []
+    for l in range(L):
+        cur, hT, cT = O.literal_sequence(variant, Pt[l], cur, h0t[l], c0t[l], time_major=time_major)
+        hTs.append(hT), cTs.append(cT)
+        loss = loss + (hT * torch.tensor(dhT[l], dtype=torch.float64)).sum() + (cT * torch.tensor(dcT[l], dtype=torch.float64)).sum()
+    loss = loss + (cur * torch.tensor(dy, dtype=torch.float64)).sum()
+    loss.backward()
+    # ---- HIP, through vmlmf_stack
+    names = ORDER[variant]
+    params = [[torch.tensor(np.asarray(P[k]), dtype=torch.float32, device="cuda").requires_grad_(True) for k in names] for P in Ps]
+    xg = torch.tensor(x, device="cuda").requires_grad_(True)
+    h0g = torch.tensor(h0, device="cuda").requires_grad_(True)
+    c0g = torch.tensor(c0, device="cuda").requires_grad_(True)
+    os.environ["VMLMF_STACK"] = "1"
+    try:
+        out = F.vmlmf_stack(variant, xg, params, rw, [ru], g=1, time_major=time_major, h0=h0g, c0=c0g)
+    finally:
+        os.environ.pop("VMLMF_STACK", None)
+    assert out is not None
+    y, hs, cs = out
+    lossg = (y * torch.tensor(dy, device="cuda")).sum()
+    for l in range(L):
+        lossg = lossg + (hs[l] * torch.tensor(dhT[l], device="cuda")).sum() + (cs[l] * torch.tensor(dcT[l], device="cuda")).sum()
+    lossg.backward()
+    torch.cuda.synchronize()
+    assert_out(y.detach().cpu().numpy(), cur.detach().numpy(), "y")
+    for l in range(L):
+        assert_out(hs[l].detach().cpu().numpy(), hTs[l].detach().numpy(), f"hT[{l}]")
+        assert_out(cs[l].detach().cpu().numpy(), cTs[l].detach().numpy(), f"cT[{l}]")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "dx")
+    assert_grad(h0g.grad.cpu().numpy(), h0t.grad.numpy(), "dh0")
+    assert_grad(c0g.grad.cpu().numpy(), c0t.grad.numpy(), "dc0")
+    for l in range(L):
+        for k, p in zip(names, params[l]):
+            assert_grad(p.grad.cpu().numpy(), Pt[l][k].grad.numpy(), f"layer {l} {k}")

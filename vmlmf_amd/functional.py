@@ -337,7 +337,7 @@ class VmlmfStackFn(torch.autograd.Function):
     (MyLSTM.forward, vmlmf.py:296-298)."""
 
     @staticmethod
-    def forward(ctx, cfg, L, x, head_w, head_b, *params):
+    def forward(ctx, cfg, L, x, head_w, head_b, h0, c0, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -359,6 +359,8 @@ class VmlmfStackFn(torch.autograd.Function):
         hc = torch.empty((2, L, B, H), device=dev, dtype=torch.float32)
         reserves = [torch.empty(rbytes[l], device=dev, dtype=torch.uint8) if training else None for l in range(L)]
         ws = _workspace(dev, wbytes)
+        h0c = None if h0 is None else h0.contiguous()      # initial states of every layer, (L, B, H), or None = zeros
+        c0c = None if c0 is None else c0.contiguous()
         layers = (_lib.StackLayer * L)()
         keep = []
         for l in range(L):
@@ -368,6 +370,8 @@ class VmlmfStackFn(torch.autograd.Function):
             ly.desc, ly.params = descs[l], ctypes.pointer(ps)
             ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[0, l].data_ptr(), hc[1, l].data_ptr()
             ly.reserve = None if reserves[l] is None else reserves[l].data_ptr()
+            ly.h0 = None if h0c is None else h0c[l].data_ptr()
+            ly.c0 = None if c0c is None else c0c[l].data_ptr()
         # a classifier riding on the top layer's final hidden state (Net.lin): its logits are the last output
         hw = None if head_w is None else head_w.contiguous()
         hb = None if head_b is None else head_b.contiguous()
@@ -384,7 +388,9 @@ class VmlmfStackFn(torch.autograd.Function):
         if training:
             ctx.cfg, ctx.L, ctx.nper, ctx.plan = cfg, L, nper, plan
             ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
-            ctx.save_for_backward(x, *ys, *reserves, *params, *([hw] if hw is not None else []))
+            ctx.has_h0, ctx.has_c0 = h0c is not None, c0c is not None
+            ctx.save_for_backward(x, *ys, *reserves, *params, *([hw] if hw is not None else []),
+                                  *([h0c] if h0c is not None else []), *([c0c] if c0c is not None else []))
         return (ys[-1],) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L)) + (logits,)
 
     @staticmethod
@@ -393,10 +399,10 @@ class VmlmfStackFn(torch.autograd.Function):
         L, nper = ctx.L, ctx.nper
         descs, rbytes, wbytes = ctx.plan
         saved = ctx.saved_tensors
-        x, ys, reserves, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], saved[1 + 2 * L:]
-        hw = None
-        if ctx.has_head:
-            params, hw = params[:-1], params[-1]
+        x, ys, reserves, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], list(saved[1 + 2 * L:])
+        c0 = params.pop() if ctx.has_c0 else None
+        h0 = params.pop() if ctx.has_h0 else None
+        hw = params.pop() if ctx.has_head else None
         dlogits = dstates[2 * L]
         dev = x.device
         dy = None if dy is None else dy.contiguous()
@@ -411,6 +417,9 @@ class VmlmfStackFn(torch.autograd.Function):
             grads.append(flat[o:o + p.numel()].view(p.shape))
             o += p.numel()
         ws = _workspace(dev, wbytes)
+        B, H = ys[0].shape[1 if time_major else 0], ys[0].shape[2]
+        dh0 = torch.empty((L, B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
+        dc0 = torch.empty((L, B, H), device=dev, dtype=torch.float32) if ctx.has_c0 else None
         layers = (_lib.StackLayer * L)()
         keep = []
         for l in range(L):
@@ -420,6 +429,10 @@ class VmlmfStackFn(torch.autograd.Function):
             ly = layers[l]
             ly.desc, ly.params, ly.grads = descs[l], ctypes.pointer(ps), ctypes.pointer(gs)
             ly.y, ly.reserve = ys[l].data_ptr(), reserves[l].data_ptr()
+            ly.h0 = None if h0 is None else h0[l].data_ptr()
+            ly.c0 = None if c0 is None else c0[l].data_ptr()
+            ly.dh0 = None if dh0 is None else dh0[l].data_ptr()
+            ly.dc0 = None if dc0 is None else dc0[l].data_ptr()
             ly.dhT = None if dhT[l] is None else dhT[l].data_ptr()
             ly.dcT = None if dcT[l] is None else dcT[l].data_ptr()
         dW = db = None
@@ -437,7 +450,7 @@ class VmlmfStackFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmlmf_stack_backward(L, ctypes.addressof(layers), x.data_ptr(), _ptr(dy), _ptr(dx),
                                                        ctypes.addressof(hd) if use_head else None, ws.data_ptr(), wbytes,
                                                        _lib.raw_stream(dev)))
-        return (None, None, dx, dW, db) + tuple(grads)
+        return (None, None, dx, dW, db, dh0, dc0) + tuple(grads)
 
 
 def stack_mode():
@@ -449,11 +462,13 @@ def stack_mode():
     return os.environ.get("VMLMF_STACK", "auto")
 
 
-def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", head=None):
+def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", head=None, h0=None, c0=None):
     """Run a stack of VMLMF layers (zero initial states) in one wavefront launch per direction.  layer_params: one parameter
     tuple per layer, in vmlmf_sequence's order.  Returns (y of the top layer, [hT per layer], [cT per layer]) or None when
     the stack is not covered / not worth it (the caller then chains vmlmf_sequence calls).  head: (weight (C, H), bias or
-    None) of a classifier on the top layer's final hidden state (<= 32 classes): a fourth element, its logits, is returned."""
+    None) of a classifier on the top layer's final hidden state (<= 32 classes): a fourth element, its logits, is returned.
+    h0 / c0: initial states of every layer as (L, B, H) tensors (None = zeros, MyLSTM.forward; the LM network carries them
+    from batch to batch, vmlmf_lm.py:421-439)."""
     mode = stack_mode()
     L = len(layer_params)
     if mode == "0" or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3:
@@ -467,17 +482,18 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
                              #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
                              #  profiles/r02_stack_vs_chained_over_T.txt)
     H = _hidden_size(variant, layer_params[0])
-    training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps))
+    training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps)
+                                            or (h0 is not None and h0.requires_grad) or (c0 is not None and c0.requires_grad))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
         return None
     flat = [p for ps in layer_params for p in ps]
     hw, hb = (None, None) if head is None else head
     ops = torch_ops()
-    if ops is not None:
+    if ops is not None and h0 is None and c0 is None:      # (initial states: the ctypes form below)
         y, hT, cT, logits = ops.stack(x, flat, L, variant, int(w_rank), ur[0], bool(time_major), hw, hb)
         out = (y, list(hT.unbind(0)), list(cT.unbind(0)))
         return out + (logits,) if head is not None else out
-    res = VmlmfStackFn.apply(cfg, L, x, hw, hb, *flat)
+    res = VmlmfStackFn.apply(cfg, L, x, hw, hb, h0, c0, *flat)
     out = (res[0], list(res[1:1 + L]), list(res[1 + L:1 + 2 * L]))
     return out + (res[1 + 2 * L],) if head is not None else out
 
