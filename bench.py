@@ -5,7 +5,7 @@ Metric: RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16 (UCI-HAR shape, M
 A "step" is one pass of the hot path over one synthetic batch:
     zero_grad -> Net.forward (MyLSTM over T=128 + Linear) -> cross-entropy -> backward
     (+ ONE flat RCCL all-reduce of the gradients when N > 1).  The optimizer is outside the timed region and
-reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step_ms` everything in one graph).  Inputs are resident in HBM before the timed region starts.
+reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step_ms` everything in one graph).  `other_configs` (single GPU, outside the metric, `--no-extra` skips it): BASELINE configs[2] in fp32 as the wavefront launches and as the chained per-layer kernels.  Inputs are resident in HBM before the timed region starts.
 value = (N ranks x T timesteps per step) / step time: weak scaling, per-GPU batch fixed at 64
 (N = 8 is BASELINE config D: global batch 512).
 
@@ -153,12 +153,61 @@ def cpu_baseline(budget_s=30.0):
             "s_per_step": results[best]}
 
 
+def other_configs(iters=100):
+    """Outside the metric: BASELINE configs[2] in fp32 (two VMLMF layers of 256, rank 24, B 128, T 24, I 77), forward +
+    backward of the RNN stack replayed from a hipGraph - as the wavefront launches (all layers in one launch per direction,
+    DESIGN.md section 4f) and as the chained per-layer kernels (VMLMF_STACK=0)."""
+    import torch
+    from vmlmf_amd import MyLSTM, MyVMLMFCell
+    out = {}
+    prev = os.environ.get("VMLMF_STACK")
+    try:
+        for key, mode in (("ms_per_step", "auto"), ("chained_ms_per_step", "0")):
+            os.environ["VMLMF_STACK"] = mode
+            torch.manual_seed(0)
+            rnn = MyLSTM(77, hidden_layer_sizes=[256, 256], batch_first=True, w_rank=24, u_ranks=[24], cell=MyVMLMFCell).cuda()
+            x = torch.randn(128, 24, 77, device="cuda")
+
+            def fb():
+                rnn.zero_grad(set_to_none=True)
+                y, _ = rnn(x)
+                y[:, -1].sum().backward()
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    fb()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fb()
+            for _ in range(10):
+                g.replay()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(iters):
+                g.replay()
+            torch.cuda.synchronize()
+            out[key] = round((time.perf_counter() - t0) / iters * 1e3, 4)
+    finally:
+        if prev is None:
+            os.environ.pop("VMLMF_STACK", None)
+        else:
+            os.environ["VMLMF_STACK"] = prev
+    out["timesteps_per_s"] = round(24 / (out["ms_per_step"] * 1e-3), 1)
+    out["workload"] = "BASELINE configs[2] in fp32: 2 x MyVMLMFCell(256), rank 24, B 128, T 24, I 77; RNN stack forward + backward, hipGraph replay"
+    return {"C_fp32": out}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the measurements outside the metric (other_configs)")
     ap.add_argument("--no-graph", action="store_true", help="time eager launches only")
     ap.add_argument("--graph-collective", action="store_true", help="capture the gradient all-reduce inside the hipGraph too")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
@@ -483,6 +532,11 @@ def main():
             "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
             "loss": round(float(loss.item()), 6),
         }
+        if world == 1 and not strong and not args.no_extra:
+            try:
+                out["other_configs"] = other_configs()
+            except Exception as e:   # never at the expense of the line itself
+                log(f"other_configs failed ({type(e).__name__}: {e})")
         if world == 1 and not strong and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
             out["speedup_vs_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
