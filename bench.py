@@ -5,7 +5,7 @@ Metric: RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16 (UCI-HAR shape, M
 A "step" is one pass of the hot path over one synthetic batch:
     zero_grad -> Net.forward (MyLSTM over T=128 + Linear) -> cross-entropy -> backward
     (+ ONE flat RCCL all-reduce of the gradients when N > 1).  The optimizer is outside the timed region and
-reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step_ms` everything in one graph).  `other_configs` (single GPU, outside the metric, `--no-extra` skips it): BASELINE configs[2] in fp32 as the wavefront launches and as the chained per-layer kernels.  Inputs are resident in HBM before the timed region starts.
+reported separately (`adam_ms` stock, `fused_adam_ms` the package's, `train_step_ms` everything in one graph).  `other_configs` (single GPU, outside the metric, `--no-extra` skips it): BASELINE configs[2] in fp32 as the wavefront launches and as the chained per-layer kernels, and configs[4]'s two group layers on one GPU.  Inputs are resident in HBM before the timed region starts.
 value = (N ranks x T timesteps per step) / step time: weak scaling, per-GPU batch fixed at 64
 (N = 8 is BASELINE config D: global batch 512).
 
@@ -198,7 +198,36 @@ def other_configs(iters=100):
             os.environ["VMLMF_STACK"] = prev
     out["timesteps_per_s"] = round(24 / (out["ms_per_step"] * 1e-3), 1)
     out["workload"] = "BASELINE configs[2] in fp32: 2 x MyVMLMFCell(256), rank 24, B 128, T 24, I 77; RNN stack forward + backward, hipGraph replay"
-    return {"C_fp32": out}
+    res = {"C_fp32": out}
+    # BASELINE configs[4] on one GPU: two PTB group layers (H 650, ranks 32 / [32, 32]), B 256, T 35 (clustered row-block kernels)
+    from vmlmf_amd import MyVMLSTMGroup
+    torch.manual_seed(0)
+    layers = [MyVMLSTMGroup(650, 650, w_rank=32, u_ranks=[32, 32]).cuda() for _ in range(2)]
+    for l in layers:
+        for p in l.parameters():
+            torch.nn.init.uniform_(p, -0.05, 0.05)
+    xe = 0.05 * torch.randn(35, 256, 650, device="cuda")
+    states = [(torch.zeros(256, 650, device="cuda"), torch.zeros(256, 650, device="cuda")) for _ in layers]
+
+    def fbe():
+        for l in layers:
+            l.zero_grad(set_to_none=True)
+        h = xe
+        for l, st in zip(layers, states):
+            h, _ = l(h, st)
+        h.sum().backward()
+
+    for _ in range(3):
+        fbe()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        fbe()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 20 * 1e3
+    res["E_1gpu"] = {"ms_per_step": round(ms, 4), "timesteps_per_s": round(35 / (ms * 1e-3), 1),
+                     "workload": "BASELINE configs[4] on one GPU: 2 x MyVMLSTMGroup(650), ranks 32 / [32, 32], B 256, T 35; layers forward + backward, eager launches"}
+    return res
 
 
 def main():
