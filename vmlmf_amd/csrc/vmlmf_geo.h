@@ -46,6 +46,7 @@ struct RbGeo {
   int S, MT, TPGV, WSG, NMT, nmu, nrb;
   int rbl;                      // live batch rows of a 16-column MFMA tile (16; 8 or 4 for clusters at small batches)
   int mlist[2][5];              // per group: the M-tiles of the padded rank space its units couple to
+  unsigned tgcode;              // four bits per M-tile m: 1 + the one group whose units feed it in the forward reduce, 0: several / all
   long long UA, VA, VB, UB, total;   // float offsets of the A-operand images inside the RB region of PACK
   long long xq_floats, flag_words;   // cluster exchange scratch (S > 1)
 };

@@ -179,6 +179,18 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
     if (n != nmu) return false;
   }
   q.nmu = nmu;
+  // forward reduce: which group's units feed M-tile m.  With two groups every tile has exactly one feeding group, so only
+  // that group's members of a cluster hold a non-zero partial of it (the cluster sum then moves half the bytes)
+  q.tgcode = 0;
+  if (g.G == 2 && q.NMT <= 8) {
+    for (int m = 0; m < q.NMT; ++m) {
+      int owner = -1, cnt = 0;
+      for (int grp = 0; grp < g.G; ++grp)
+        for (int u = 0; u < nmu; ++u)
+          if (q.mlist[grp][u] == m) owner = grp, ++cnt;
+      if (cnt == 1) q.tgcode |= (unsigned)(owner + 1) << (4 * m);
+    }
+  }
   const long long NTV = (long long)g.G * q.TPGV, KS = g.KH / 4;
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
