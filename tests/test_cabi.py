@@ -145,7 +145,8 @@ def test_stack_query_host_logic():
     assert query(1, 64, 128, 9, 180, 16, 16)[0] == 0
     assert query(4, 8, 5, 20, 64, 8, 8)[0] == 0
     assert query(5, 8, 5, 20, 64, 8, 8)[0] == _lib.E_UNSUPPORTED                      # more than four layers
-    assert query(2, 8, 5, 20, 64, 8, 16)[0] == _lib.E_UNSUPPORTED                     # padded w_rank != padded u_rank
+    assert query(2, 8, 5, 20, 64, 8, 16)[0] == 0                                      # padded w_rank != padded u_rank: the wider of the two
+    assert query(2, 8, 5, 20, 256, 8, 32)[0] == _lib.E_UNSUPPORTED                    # ... which must still fit
     assert query(2, 8, 5, 20, 320, 16, 16)[0] == _lib.E_UNSUPPORTED                   # more than four waves of units
     assert query(2, 8, 5, 20, 256, 32, 32)[0] == _lib.E_UNSUPPORTED                   # rank 32 with four waves: register budget
     assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == _lib.E_UNSUPPORTED   # group layers

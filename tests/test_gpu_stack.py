@@ -38,6 +38,9 @@ CASES = [
     (1, 9, 6, 77, 180, 8, "vm"),
     (2, 6, 5, 24, 72, 16, "lmf"),         # MyLSTMCell in low-rank mode (variant 5)
     (2, 300, 4, 10, 64, 8, "vm"),         # more workgroups than CUs
+    (2, 6, 7, 20, 64, (8, 16), "vm"),     # padded w_rank != padded u_rank: both sides at the wider one
+    (3, 9, 5, 33, 130, (24, 5), "vm"),
+    (2, 128, 24, 77, 256, (16, 24), "vm"),
     (3, 4, 1, 12, 40, 8, "vm"),           # one and two time steps: the pipelines of the x-team and of the hand-over barely start
     (2, 6, 2, 30, 64, 16, "vm"),
     (2, 520, 3, 16, 128, 16, "vm"),
@@ -49,8 +52,9 @@ def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
     import vmlmf_amd
     from vmlmf_amd import functional as F
     torch.manual_seed(1234 + L * 7 + B)
+    rw, ru = r if isinstance(r, tuple) else (r, r)
     cell = vmlmf_amd.MyVMLMFCell if kind == "vm" else vmlmf_amd.MyLSTMCell
-    model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=r, u_ranks=r, cell=cell).cuda()
+    model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=rw, u_ranks=ru, cell=cell).cuda()
     with torch.no_grad():
         for p in model.parameters():
             p.mul_(1.5)       # livelier gates than the reference's init
@@ -61,7 +65,7 @@ def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
     got = _run(model, x, "1", (gy, gh))
     # the stack really ran on the wavefront launch
     cfg = model.rnncells[0].kernel_cfg()
-    assert F._stack_plan((cfg["variant"], 1, r, (r,), False, 0), L, B, T, I, H, True) is not None
+    assert F._stack_plan((cfg["variant"], 1, rw, (ru,), False, 0), L, B, T, I, H, True) is not None
     for a, b, what in ((got[0], ref[0], "y"), (got[1], ref[1], "hidden"), (got[2], ref[2], "dx")):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, scale), what
@@ -252,8 +256,13 @@ def test_stack_random_shapes_sweep():
         I = rng.randint(1, H)
         B = rng.choice([1, 2, 3, 7, 8, 9, 17, 33, 70])
         T = rng.randint(1, 20)
-        ru = rng.randint(max(1, r - 7), r)          # true ranks anywhere inside the padded width
+        ru = rng.randint(max(1, r - 7), r)          # true ranks anywhere inside the padded width ...
         rw = rng.randint(max(1, r - 7), r)
+        if trial % 3 == 2:                          # ... and every third stack with a narrower x or h side
+            if trial % 2:
+                rw = rng.randint(1, r)
+            else:
+                ru = rng.randint(1, r)
         torch.manual_seed(trial)
         model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=rw, u_ranks=ru,
                                  cell=vmlmf_amd.MyVMLMFCell).cuda()

@@ -686,11 +686,10 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
     if (rc != 0) return rc;
     const VGeo& g = S.g[l];
     if (!wf_supported(g))
-      return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (one group, padded w_rank == padded u_rank, "
-                                       "hidden_size <= 256, fp32)");
+      return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (one group, hidden_size <= 256 - 192 at padded rank 32 -, fp32)");
     if (l > 0) {
       const VGeo& g0 = S.g[0];
-      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.ru0 != g0.ru0 || g.rw != g0.rw ||
+      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.rw != g0.rw ||
           g.time_major != g0.time_major || g.training != g0.training)
         return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, H, ranks, layout and training flag");
       if (g.I != g.H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: input_size must equal hidden_size");
@@ -754,8 +753,11 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
     WfFwdLayer& w = a.l[l];
     w.x = l == 0 ? x : ly[l - 1].y;
     w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
-    w.VE = pack + S.P[l].VE, w.EH = pack + S.P[l].EH, w.VXT = pack + S.P[l].VXT, w.EXT = pack + S.P[l].EXT, w.BBT = pack + S.P[l].BBT;
-    w.UR = pack + S.P[l].WF + S.W.UR, w.URX = pack + S.P[l].WF + S.W.URX;
+    const bool mixed = g.KH != g.KX;   // both sides at the wider padded rank: re-laid images in the WF region
+    const float* wf = pack + S.P[l].WF;
+    w.VE = mixed ? wf + S.W.VE : pack + S.P[l].VE, w.VXT = mixed ? wf + S.W.VXK : pack + S.P[l].VXT;
+    w.EH = pack + S.P[l].EH, w.EXT = pack + S.P[l].EXT, w.BBT = pack + S.P[l].BBT;
+    w.UR = wf + S.W.UR, w.URX = wf + S.W.URX;
     w.h0 = ly[l].h0, w.c0 = ly[l].c0, w.y = ly[l].y, w.hT = ly[l].hT, w.cT = ly[l].cT;
     w.gates = training ? rs + Lr.r_gates : nullptr, w.cs = training ? rs + Lr.r_cs : nullptr;
     w.Qs = training ? rs + Lr.r_Qs : nullptr, w.qx = training ? rs + Lr.r_qx : nullptr;
@@ -816,8 +818,11 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       w.gates = rs + Lr.r_gates, w.cs = rs + Lr.r_cs;
       w.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
       w.dhT = ly[l].dhT, w.dcT = ly[l].dcT, w.dh0 = ly[l].dh0, w.dc0 = ly[l].dc0;
-      w.UE = pack + S.P[l].UE, w.EH = pack + S.P[l].EH, w.UXO = pack + S.P[l].UXO, w.EXI = pack + S.P[l].EXI;
-      w.VR = pack + S.P[l].WF + S.W.VR, w.VRX = pack + S.P[l].WF + S.W.VRX;
+      const bool mixed = g.KH != g.KX;
+      const float* wf = pack + S.P[l].WF;
+      w.UE = mixed ? wf + S.W.UE : pack + S.P[l].UE, w.UXO = mixed ? wf + S.W.UXK : pack + S.P[l].UXO;
+      w.EH = pack + S.P[l].EH, w.EXI = pack + S.P[l].EXI;
+      w.VR = wf + S.W.VR, w.VRX = wf + S.W.VRX;
       w.dpre = wl + Lr.b_dpre, w.dQs = wl + Lr.b_dQs, w.dqx = wl + Lr.b_dqx;
       w.dx = l == 0 ? dx : ws + S.ws_dx[l];
       w.want_dx = w.dx != nullptr ? 1 : 0;

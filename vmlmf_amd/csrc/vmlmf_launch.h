@@ -118,8 +118,12 @@ hipError_t launch_nll_bwd(int R, int V, const float* scores, const long long* y,
 constexpr int WF_MAXL = 4;          // layers per launch
 constexpr int WF_FLAG_STRIDE = 32;  // unsigned words between two progress words (one 128-byte line each)
 struct WfPack {                     // float offsets inside the WF region of PACK (images with the half-pass layout)
-  long long UR, VR, URX, VRX, total;
+  long long UR, VR, URX, VRX;
+  long long VE, UE, VXK, UXK;       // only when padded w_rank != padded u_rank: pack_kernel's VE / UE / VXT / UXO re-laid to
+                                    // the common width K = max of the two (zero ranks behind the narrower side)
+  long long total;
 };
+__host__ __device__ inline int wf_width(const VGeo& g) { return g.KH > g.KX ? g.KH : g.KX; }   // rank width the wavefront kernels are instantiated for
 struct WfFwdLayer {
   const float* x;                   // input rows of the layer (above the first: the y of the layer below)
   const float *VE, *EH, *VXT, *EXT, *BBT;   // pack_kernel images

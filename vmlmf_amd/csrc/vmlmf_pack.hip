@@ -248,13 +248,45 @@ int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipSt
 // Four images: UR (U_h), VR[4] (V_h per gate), URX (U_x, inputs by slot), VRX[4] (V_x per gate).
 __device__ __forceinline__ void wf_pack_body(const VGeo& g, const RefP& p, const WfPack& W, float* __restrict__ out, const int bid,
                                              const int nblk) {
-  const int NT = g.NT, K = g.KH, NPF = K / 16;
+  const int NT = g.NT, K = wf_width(g), NPF = K / 16;
   const int lane = threadIdx.x & 63;
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
   const int total = (int)W.total;
   for (int e = bid * 256 + threadIdx.x; e < total; e += nblk * 256) {
     float v = 0.f;
+    if (e >= W.VE) {   // (mixed widths only) plain re-layouts at the common width K: VE, UE by slot; VXK by unit; UXK by slot
+      if (e < W.UE) {
+        const int le = e - (int)W.VE;
+        if (le < 4 * K * NT) {
+          const int jj = le / NT, slot = le - jj * NT, k = jj / K, rr = jj - k * K;
+          int n;
+          if (vg_slot_unit(g, slot, n)) v = ref_vc(g, p, n, k, rr);
+        }
+      } else if (e < W.VXK) {
+        const int le = e - (int)W.UE;
+        if (le < K * NT) {
+          const int rr = le / NT, slot = le - rr * NT;
+          int n;
+          if (vg_slot_unit(g, slot, n)) v = ref_uc(g, p, n, rr);
+        }
+      } else if (e < W.UXK) {
+        const int le = e - (int)W.VXK;
+        if (le < 4 * K * g.H) {
+          const int jj = le / g.H, n = le - jj * g.H, k = jj / K;
+          v = ref_vx(g, p, n, k, jj - k * K);
+        }
+      } else {
+        const int le = e - (int)W.UXK;
+        if (le < K * NT) {
+          const int r = le / NT, slot = le - r * NT;
+          int n;
+          if (vg_slot_unit(g, slot, n) && n < g.I) v = ref_ux(g, p, n, r);
+        }
+      }
+      out[e] = v;
+      continue;
+    }
     int le, kind;   // kind 0: UR, 1: VR, 2: URX, 3: VRX
     if (e < W.VR) le = e - (int)W.UR, kind = 0;
     else if (e < W.URX) le = e - (int)W.VR, kind = 1;

@@ -6,22 +6,28 @@ WfPack wf_pack_layout(const VGeo& g) {
   WfPack W;
   long long o = 0;
   auto take = [&](long long n) { long long r = o; o += (n + 63) / 64 * 64; return r; };
-  const long long K = g.KH;
+  const long long K = wf_width(g);
+  const long long mixed = g.KH != g.KX ? 1 : 0;
   W.UR = take(K * g.NT);
   W.VR = take(4 * K * g.NT);
   W.URX = take(K * g.NT);
   W.VRX = take(4 * K * g.NT);
+  W.VE = take(mixed * 4 * K * g.NT);
+  W.UE = take(mixed * K * g.NT);
+  W.VXK = take(mixed * 4 * K * g.H);
+  W.UXK = take(mixed * K * g.NT);
   W.total = o;
   return W;
 }
 
-// one group, x rank padded like the h rank, at most four waves of units; rank 32 with four waves would need more than the
+// one group, at most four waves of units; rank 32 with four waves would need more than the
 // 168 VGPRs a 10-wave workgroup leaves per lane
 bool wf_supported(const VGeo& g) {
   if (g.generic || g.rb || g.bf || g.flat || g.G != 1 || g.R != 1) return false;
-  if (g.KX != g.KH || g.I > g.H || g.NW > 4) return false;
-  if (g.KH != 8 && g.KH != 16 && g.KH != 24 && g.KH != 32) return false;
-  if (g.KH == 32 && g.NW == 4) return false;
+  if (g.I > g.H || g.NW > 4) return false;
+  const int K = wf_width(g);   // padded w_rank != padded u_rank: both sides run at the wider one (zero ranks behind the narrower)
+  if (K != 8 && K != 16 && K != 24 && K != 32) return false;
+  if (K == 32 && g.NW == 4) return false;
   return true;
 }
 
@@ -32,7 +38,7 @@ DECL(8) DECL(16) DECL(24) DECL(32)
 #undef DECL
 
 int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s) {
-  switch (g.KH) {
+  switch (wf_width(g)) {
     case 8: return launch_wf_fwd_k8(g, a, s);
     case 16: return launch_wf_fwd_k16(g, a, s);
     case 24: return launch_wf_fwd_k24(g, a, s);
@@ -41,7 +47,7 @@ int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s) {
   return -3;
 }
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s) {
-  switch (g.KH) {
+  switch (wf_width(g)) {
     case 8: return launch_wf_bwd_k8(g, a, s);
     case 16: return launch_wf_bwd_k16(g, a, s);
     case 24: return launch_wf_bwd_k24(g, a, s);
