@@ -190,8 +190,9 @@ int vmlmf_seq_backward_ex(const vmlmf_desc *d, const vmlmf_params *p, const floa
  * that launch (no x-projection / input-gradient launches, no (T,B,4H) pre-activation round trip).  Results are those of
  * L calls of vmlmf_seq_forward / vmlmf_seq_backward chained through y (same arithmetic per element; the order of the
  * rank-space sums differs in the last bits).
- * Covered: 1..4 layers of one-group variants (V1, V3, V5) with equal B, T, H, ranks and layout, hidden_size <= 256 (<= 192
- * when the wider of the padded w_rank / u_rank is 32), layer l > 0 with input_size == hidden_size.  Anything else: VMLMF_E_UNSUPPORTED from
+ * Covered: 1..4 layers of V1, V2, V3, V5 or V6 (not the flat V4 layout) with equal B, T, H, ranks and layout, at most four
+ * waves of hidden units (hidden_size <= 256; two groups: hidden_size / 2 <= 128), the wider of padded w_rank and (summed)
+ * padded u_rank <= 24, or <= 32 with at most three waves of units, layer l > 0 with input_size == hidden_size.  Anything else: VMLMF_E_UNSUPPORTED from
  * vmlmf_stack_query() - the caller then chains the per-layer calls.
  * Per layer: desc (training flag and shapes must agree across the stack), params, optional initial / final states, the
  * layer's output y (B,T,H or T,B,H; layer l's y is layer l+1's x) and its reserve (training).  Backward additionally:

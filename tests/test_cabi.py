@@ -149,7 +149,9 @@ def test_stack_query_host_logic():
     assert query(2, 8, 5, 20, 256, 8, 32)[0] == _lib.E_UNSUPPORTED                    # ... which must still fit
     assert query(2, 8, 5, 20, 320, 16, 16)[0] == _lib.E_UNSUPPORTED                   # more than four waves of units
     assert query(2, 8, 5, 20, 256, 32, 32)[0] == _lib.E_UNSUPPORTED                   # rank 32 with four waves: register budget
-    assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == _lib.E_UNSUPPORTED   # group layers
+    assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == 0                    # group cells: two rank blocks
+    assert query(2, 8, 5, 20, 360, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == _lib.E_UNSUPPORTED   # ... within four waves of units
+    assert query(2, 8, 5, 64, 64, 8, 8, variant=_lib.V4_LM_GROUP, g=2)[0] in (_lib.E_UNSUPPORTED, _lib.E_SHAPE)   # the flat LM layout: not covered
     assert query(2, 8, 5, 20, 64, 8, 8, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED            # unequal hidden sizes
     assert query(2, 8, 5, 20, 64, 8, 8, I_upper=48)[0] == _lib.E_SHAPE                # layer 1 does not read layer 0's width
     assert b"stack" in lib.vmlmf_last_error()

@@ -41,6 +41,11 @@ CASES = [
     (2, 6, 7, 20, 64, (8, 16), "vm"),     # padded w_rank != padded u_rank: both sides at the wider one
     (3, 9, 5, 33, 130, (24, 5), "vm"),
     (2, 128, 24, 77, 256, (16, 24), "vm"),
+    (1, 81, 24, 77, 180, (8, [2, 4]), "g2"),      # the reference's vmlmf_group2 demo (script/demo.sh): two groups, ranks 2 and 4
+    (2, 7, 6, 12, 64, (8, [4, 6]), "g2"),
+    (3, 5, 9, 40, 128, (16, [8, 9]), "g2"),
+    (2, 9, 5, 30, 200, (12, [8, 8]), "g2"),       # two waves per group
+    (2, 6, 7, 20, 96, (8, [5, 3]), "g2novm"),     # the group cell without the vector multiplication (variant 6)
     (3, 4, 1, 12, 40, 8, "vm"),           # one and two time steps: the pipelines of the x-team and of the hand-over barely start
     (2, 6, 2, 30, 64, 16, "vm"),
     (2, 520, 3, 16, 128, 16, "vm"),
@@ -53,7 +58,8 @@ def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
     from vmlmf_amd import functional as F
     torch.manual_seed(1234 + L * 7 + B)
     rw, ru = r if isinstance(r, tuple) else (r, r)
-    cell = vmlmf_amd.MyVMLMFCell if kind == "vm" else vmlmf_amd.MyLSTMCell
+    cell = {"vm": vmlmf_amd.MyVMLMFCell, "lmf": vmlmf_amd.MyLSTMCell, "g2": vmlmf_amd.MyVMLMFCellg2,
+            "g2novm": vmlmf_amd.MyVMLMFgCellg2}[kind]
     model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=rw, u_ranks=ru, cell=cell).cuda()
     with torch.no_grad():
         for p in model.parameters():
@@ -65,7 +71,8 @@ def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
     got = _run(model, x, "1", (gy, gh))
     # the stack really ran on the wavefront launch
     cfg = model.rnncells[0].kernel_cfg()
-    assert F._stack_plan((cfg["variant"], 1, rw, (ru,), False, 0), L, B, T, I, H, True) is not None
+    ur = tuple(ru) if isinstance(ru, list) else (ru,)
+    assert F._stack_plan((cfg["variant"], cfg["g"], rw, ur, False, 0), L, B, T, I, H, True) is not None
     for a, b, what in ((got[0], ref[0], "y"), (got[1], ref[1], "hidden"), (got[2], ref[2], "dx")):
         scale = float(b.abs().max()) + 1e-12
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, scale), what

@@ -246,8 +246,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::
 // empty tensor).  Initial states are zero (MyLSTM.forward).
 struct StackFn : public torch::autograd::Function<StackFn> {
   static variable_list forward(AutogradContext* ctx, Tensor x, at::TensorList params_in, int64_t L, int64_t variant, int64_t w_rank,
-                               int64_t u_rank, bool time_major, bool training, c10::optional<Tensor> head_w_o,
-                               c10::optional<Tensor> head_b_o) {
+                               std::vector<int64_t> u_ranks, int64_t g, bool time_major, bool training,
+                               c10::optional<Tensor> head_w_o, c10::optional<Tensor> head_b_o) {
     Tensor head_w = head_w_o.has_value() ? head_w_o->contiguous() : Tensor();
     Tensor head_b = head_b_o.has_value() ? head_b_o->contiguous() : Tensor();
     if (head_w.defined()) require_hip_f32(head_w, "head weight");
@@ -270,7 +270,7 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     size_t wbytes = 0;
     memset(ly.data(), 0, sizeof(vmlmf_stack_layer) * L);
     for (int64_t l = 0; l < L; ++l)
-      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, {u_rank}, 1, time_major, training, VMLMF_DT_F32);
+      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, u_ranks, g, time_major, training, VMLMF_DT_F32);
     check(vmlmf_stack_query((int)L, ly.data(), rbytes.data(), &wbytes));
     c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     std::vector<Tensor> ys, reserves;
@@ -280,7 +280,7 @@ struct StackFn : public torch::autograd::Function<StackFn> {
       ys.push_back(at::empty(time_major ? at::IntArrayRef({T, B, H}) : at::IntArrayRef({B, T, H}), x.options()));
       reserves.push_back(training ? at::empty({(int64_t)rbytes[l]}, x.options().dtype(at::kByte)) : Tensor());
       std::vector<Tensor> pl(params.begin() + l * nper, params.begin() + (l + 1) * nper);
-      fill_params(ps[l], pl, (int)variant, 1);
+      fill_params(ps[l], pl, (int)variant, (int)g);
       ly[l].params = &ps[l];
       ly[l].y = ys[l].data_ptr<float>(), ly[l].hT = hT.data_ptr<float>() + l * B * H, ly[l].cT = cT.data_ptr<float>() + l * B * H;
       ly[l].reserve = training ? reserves[l].data_ptr() : nullptr;
@@ -301,7 +301,8 @@ struct StackFn : public torch::autograd::Function<StackFn> {
       for (auto& t : params) saved.push_back(t);
       if (head_w.defined()) saved.push_back(head_w);
       ctx->save_for_backward(saved);
-      ctx->saved_data["cfg"] = std::vector<int64_t>{L, variant, w_rank, u_rank, time_major ? 1 : 0, B, T, I, H, (int64_t)nper};
+      ctx->saved_data["cfg"] = std::vector<int64_t>{L, variant, w_rank, g, time_major ? 1 : 0, B, T, I, H, (int64_t)nper};
+      ctx->saved_data["ur"] = u_ranks;
       ctx->saved_data["head"] = head_w.defined();
       ctx->saved_data["head_b"] = head_b.defined();
     }
@@ -311,7 +312,8 @@ struct StackFn : public torch::autograd::Function<StackFn> {
   static variable_list backward(AutogradContext* ctx, variable_list gout) {
     const auto saved = ctx->get_saved_variables();
     const auto cfg = ctx->saved_data["cfg"].toIntVector();
-    const int64_t L = cfg[0], variant = cfg[1], w_rank = cfg[2], u_rank = cfg[3], B = cfg[5], T = cfg[6], I = cfg[7], H = cfg[8], nper = cfg[9];
+    const int64_t L = cfg[0], variant = cfg[1], w_rank = cfg[2], g = cfg[3], B = cfg[5], T = cfg[6], I = cfg[7], H = cfg[8], nper = cfg[9];
+    const auto u_ranks = ctx->saved_data["ur"].toIntVector();
     const bool time_major = cfg[4] != 0;
     const Tensor& x = saved[0];
     const bool has_head = ctx->saved_data["head"].toBool(), has_head_b = ctx->saved_data["head_b"].toBool();
@@ -339,11 +341,11 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     size_t wbytes = 0;
     memset(ly.data(), 0, sizeof(vmlmf_stack_layer) * L);
     for (int64_t l = 0; l < L; ++l) {
-      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, {u_rank}, 1, time_major, true, VMLMF_DT_F32);
+      ly[l].desc = make_desc((int)variant, B, T, l == 0 ? I : H, H, w_rank, u_ranks, g, time_major, true, VMLMF_DT_F32);
       std::vector<Tensor> pl(params.begin() + l * nper, params.begin() + (l + 1) * nper);
       std::vector<Tensor> gl(grads.begin() + l * nper, grads.begin() + (l + 1) * nper);
-      fill_params(ps[l], pl, (int)variant, 1);
-      fill_params(gs[l], gl, (int)variant, 1);
+      fill_params(ps[l], pl, (int)variant, (int)g);
+      fill_params(gs[l], gl, (int)variant, (int)g);
       ly[l].params = &ps[l], ly[l].grads = &gs[l];
       ly[l].y = const_cast<float*>(saved[1 + l].data_ptr<float>());
       ly[l].reserve = saved[1 + L + l].data_ptr();
@@ -367,7 +369,7 @@ struct StackFn : public torch::autograd::Function<StackFn> {
                                ws.data_ptr(), wbytes, stream_of(x)));
     variable_list out = {dx};
     for (auto& gt : grads) out.push_back(gt);
-    for (int i = 0; i < 6; ++i) out.push_back(Tensor());   // the integer configuration
+    for (int i = 0; i < 7; ++i) out.push_back(Tensor());   // the integer configuration
     out.push_back(dW);                                     // head weight, head bias
     out.push_back(db);
     return out;
@@ -375,13 +377,13 @@ struct StackFn : public torch::autograd::Function<StackFn> {
 };
 
 std::tuple<Tensor, Tensor, Tensor, Tensor> stack(const Tensor& x, at::TensorList params, int64_t L, int64_t variant, int64_t w_rank,
-                                                 int64_t u_rank, bool time_major, const c10::optional<Tensor>& head_w,
-                                                 const c10::optional<Tensor>& head_b) {
+                                                 at::IntArrayRef u_ranks, int64_t g, bool time_major,
+                                                 const c10::optional<Tensor>& head_w, const c10::optional<Tensor>& head_b) {
   bool training = x.requires_grad();
   for (const auto& p : params) training = training || p.requires_grad();
   training = training || (head_w.has_value() && head_w->requires_grad()) || (head_b.has_value() && head_b->requires_grad());
   training = training && at::GradMode::is_enabled();
-  auto out = StackFn::apply(x, params, L, variant, w_rank, u_rank, time_major, training, head_w, head_b);
+  auto out = StackFn::apply(x, params, L, variant, w_rank, u_ranks.vec(), g, time_major, training, head_w, head_b);
   return {out[0], out[1], out[2], out[3]};
 }
 
@@ -477,7 +479,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 
 TORCH_LIBRARY(vmlmf, m) {
   m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
-  m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int u_rank, bool time_major, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int[] u_ranks, int g, bool time_major, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
 }

@@ -686,10 +686,11 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
     if (rc != 0) return rc;
     const VGeo& g = S.g[l];
     if (!wf_supported(g))
-      return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (one group, hidden_size <= 256 - 192 at padded rank 32 -, fp32)");
+      return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (V1-V3, V5, V6; at most four waves of hidden units; padded ranks "
+                                       "<= 24, or 32 with at most three waves; fp32)");
     if (l > 0) {
       const VGeo& g0 = S.g[0];
-      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.rw != g0.rw ||
+      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G || g.rw != g0.rw ||
           g.time_major != g0.time_major || g.training != g0.training)
         return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, H, ranks, layout and training flag");
       if (g.I != g.H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: input_size must equal hidden_size");

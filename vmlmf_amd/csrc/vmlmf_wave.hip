@@ -20,10 +20,10 @@ WfPack wf_pack_layout(const VGeo& g) {
   return W;
 }
 
-// one group, at most four waves of units; rank 32 with four waves would need more than the
+// one or two (wave-aligned) groups, at most four waves of units; rank 32 with four waves would need more than the
 // 168 VGPRs a 10-wave workgroup leaves per lane
 bool wf_supported(const VGeo& g) {
-  if (g.generic || g.rb || g.bf || g.flat || g.G != 1 || g.R != 1) return false;
+  if (g.generic || g.rb || g.bf || g.flat || g.G > 2 || g.R != 1) return false;   // (V4's flat layout: not covered)
   if (g.I > g.H || g.NW > 4) return false;
   const int K = wf_width(g);   // padded w_rank != padded u_rank: both sides run at the wider one (zero ranks behind the narrower)
   if (K != 8 && K != 16 && K != 24 && K != 32) return false;
