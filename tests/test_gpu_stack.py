@@ -213,14 +213,18 @@ def test_stack_time_major_lm_layers():
         assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-6
 
 
-@pytest.mark.parametrize("L,B,T,I,H,r", [(2, 128, 24, 77, 256, 24), (2, 9, 7, 12, 40, 8), (3, 5, 4, 30, 100, 16)])
+@pytest.mark.parametrize("L,B,T,I,H,r", [(2, 128, 24, 77, 256, 24), (2, 9, 7, 12, 40, 8), (3, 5, 4, 30, 100, 16),
+                                         (2, 11, 6, 20, 180, (8, [4, 6]))])
 def test_net_classifier_rides_on_the_stack(L, B, T, I, H, r):
     """Net (MyLSTM + Linear(H, 18) on the last time step, vmlmf.py:330-355) with the wavefront launches: the logits come out of
     the forward launch, the classifier's backward is part of the stack's backward - against the chained per-layer form."""
     import vmlmf_amd
     from vmlmf_amd import Net, MyLSTM, MyVMLMFCell
     torch.manual_seed(100 + L + B)
-    net = Net(I, layer_sizes=[H] * L, w_rank=r, u_rank=[r], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    if isinstance(r, tuple):    # group cell: (w_rank, [u_rank of shift 0, of shift 1])
+        net = Net(I, layer_sizes=[H] * L, w_rank=r[0], u_rank=r[1], model=MyLSTM, cell=vmlmf_amd.MyVMLMFCellg2).cuda()
+    else:
+        net = Net(I, layer_sizes=[H] * L, w_rank=r, u_rank=[r], model=MyLSTM, cell=MyVMLMFCell).cuda()
     with torch.no_grad():
         for p in net.parameters():
             p.mul_(1.5)
@@ -282,6 +286,38 @@ def test_stack_random_shapes_sweep():
         ref = _run(model, x, "0", (gy, gh))
         got = _run(model, x, "1", (gy, gh))
         what = f"trial {trial}: L={L} B={B} T={T} I={I} H={H} rw={rw} ru={ru}"
+        for a, b in ((got[0], ref[0]), (got[1], ref[1])):
+            assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), what
+        assert float((got[2] - ref[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max()) + 1e-6, what
+        for name, gref in ref[3].items():
+            assert float((got[3][name] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-6, (what, name)
+
+
+def test_stack_random_group_cells_sweep():
+    """Twenty seeded random stacks of the group cells (MyVMLMFCellg2 / MyVMLMFgCellg2): wavefront against chained kernels."""
+    import random
+    import vmlmf_amd
+    rng = random.Random(777)
+    for trial in range(20):
+        L = rng.choice([1, 2, 2, 3])
+        H = 2 * rng.randint(6, 128)
+        rw = rng.randint(1, 16)
+        ru = [rng.randint(1, 8), rng.randint(1, 8)] if H > 128 else [rng.randint(1, 16), rng.randint(1, 8)]
+        I = rng.randint(1, H)
+        B = rng.choice([1, 3, 8, 9, 20, 41])
+        T = rng.randint(1, 14)
+        cell = vmlmf_amd.MyVMLMFCellg2 if trial % 3 else vmlmf_amd.MyVMLMFgCellg2
+        torch.manual_seed(trial)
+        model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H] * L, batch_first=True, w_rank=rw, u_ranks=ru, cell=cell).cuda()
+        with torch.no_grad():
+            for p in model.parameters():
+                p.mul_(1.3)
+        x = torch.randn(B, T, I, device="cuda")
+        gy = torch.randn(B, T, H, device="cuda")
+        gh = torch.randn(B, L * H, device="cuda")
+        ref = _run(model, x, "0", (gy, gh))
+        got = _run(model, x, "1", (gy, gh))
+        what = f"trial {trial}: {cell.__name__} L={L} B={B} T={T} I={I} H={H} rw={rw} ru={ru}"
         for a, b in ((got[0], ref[0]), (got[1], ref[1])):
             assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max())), what
         assert float((got[2] - ref[2]).abs().max()) <= 1e-4 * float(ref[2].abs().max()) + 1e-6, what
