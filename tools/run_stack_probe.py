@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("VMLMF_STACK", "1")
+os.environ["VMLMF_PYBIND"] = "ctypes"      # the probe reads the ctypes binding's workspace (the C++ binding keeps its own)
 import torch
 from vmlmf_amd import MyLSTM, MyVMLMFCell, functional as F
 torch.manual_seed(0)
