@@ -477,11 +477,12 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
-    if mode != "1" and L == 1 and (x.shape[2] <= 16 or T > 96):
+    H = _hidden_size(variant, layer_params[0])
+    xwave = x.shape[2] <= 16 and H <= 192 and g == 1       # (vg_xwave_ok of the C side: <= 3 waves of units, one group)
+    if mode != "1" and L == 1 and (xwave or T > 96):
         return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel; with a wide
                              #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
                              #  profiles/r02_stack_vs_chained_over_T.txt)
-    H = _hidden_size(variant, layer_params[0])
     training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps)
                                             or (h0 is not None and h0.requires_grad) or (c0 is not None and c0.requires_grad))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
