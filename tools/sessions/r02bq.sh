@@ -1,0 +1,20 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r02bq; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+db() { find $O/$1 -name "*.db" | head -1; }
+prof() { tag=$1; shift
+  ( cd /tmp && env "$@" timeout -k 5 300 rocprofv3 --kernel-trace --stats -d $R/$O/$tag -o k -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extra ) > $O/$tag.log 2>&1 < /dev/null
+  python tools/rocprof_summary.py $(db $tag) $O/$tag.csv "$tag" > /dev/null 2>&1
+  rm -rf $O/$tag
+  echo "== $tag bwd $(grep rec_bwd $O/$tag.csv | cut -d, -f8-11) fwd $(grep rec_fwd $O/$tag.csv | cut -d, -f9-11) $(grep ms_per_step $O/$tag.log | grep -o '"ms_per_step": [0-9.]*')"
+}
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|FAILED|Error" | head
+prof dry VMLMF_WRIDE_DRY=1
+prof dry_pub1 VMLMF_WRIDE_DRY=3
+prof dry_lag4 VMLMF_WRIDE_DRY=1 VMLMF_WRIDE_LAG=4
+prof ride
+prof ride_k8 VMLMF_WRIDE_K=8
+prof ride_k24 VMLMF_WRIDE_K=24
+prof off VMLMF_WRIDE=0

@@ -1,0 +1,21 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT
+export TMPDIR=/tmp
+O=gpurun_out/r02bw; mkdir -p $O
+R=$GRAFT_REPO_ROOT
+db() { find $O/$1 -name "*.db" | head -1; }
+prof() { tag=$1; shift
+  ( cd /tmp && env "$@" timeout -k 5 90 rocprofv3 --kernel-trace --stats -d $R/$O/$tag -o k -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extra ) > $O/$tag.log 2>&1 < /dev/null
+  python tools/rocprof_summary.py $(db $tag) $O/$tag.csv "$tag" > /dev/null 2>&1
+  rm -rf $O/$tag
+  echo "== $tag bwd $(grep rec_bwd $O/$tag.csv | cut -d, -f8-11) $(grep ms_per_step $O/$tag.log | grep -o '"ms_per_step": [0-9.]*')"
+}
+timeout 60 python tools/sessions/r02br.py 2>&1 | grep "^it\|fault" | cut -c1-200 | tee $O/diag.txt
+grep -q fault $O/diag.txt && exit 1
+
+prof ride
+prof ride_rc32 VMLMF_WRIDE_RC=32
+prof ride_rc64 VMLMF_WRIDE_RC=64
+prof ride_rc32_k24 VMLMF_WRIDE_RC=32 VMLMF_WRIDE_K=24
+prof ride_rc32_lag3 VMLMF_WRIDE_RC=32 VMLMF_WRIDE_LAG=3
+prof ride_rc32_pub1 VMLMF_WRIDE_RC=32 VMLMF_WRIDE_DRY=2

@@ -76,7 +76,18 @@ int env_pos(const char* name, int dflt) {
 }
 const int g_wchunks = env_pos("VMLMF_WCHUNKS", 64);
 const int g_rc = env_pos("VMLMF_RC", 0);   // dqx_dx rows per workgroup (A/B); 0 = derived from the row count
-const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
+const int g_wmin = env_pos("VMLMF_WMIN", 64);
+// weight-gradient workers riding on rec_bwd_kernel's launch (vmlmf_atb.inc): VMLMF_WRIDE=0 off; VMLMF_WRIDE_K = workers per
+// task, VMLMF_WRIDE_MAXB = largest batch that rides (beyond it the rows fill the chip and the workers only compete with them)
+const bool g_wride = []() {
+  const char* e = getenv("VMLMF_WRIDE");
+  return e == nullptr || e[0] != '0';
+}();
+const int g_wride_k = env_pos("VMLMF_WRIDE_K", 32);
+const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 128);
+const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
+const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
+const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
 
 // Row-block MFMA kernels (vmlmf_rb.hip): -1 = automatic (large batches, and layers beyond the register-resident VALU kernels),
 // 0 = never, 1 = wherever an instantiation exists.  VMLMF_RB in the environment, or vmlmf_tune("rb", v) at run time.
@@ -217,7 +228,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
 // ---- buffer layouts (float offsets) ----
 struct Layout {
   // reserve (training) : PACK | qx | gates | cs | Qs
-  long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_total;
+  long long r_pack, r_qx, r_gates, r_cs, r_Qs, r_prog, r_total;
   // forward workspace  : PACK (inference only) | gx
   long long f_pack, f_gx, f_qx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
@@ -234,6 +245,7 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   L.r_gates = o, o += align64(TS * 4);
   L.r_cs = o, o += align64(TS + (long long)g.Bp * g.NT);   // slice 0 = c0, slice t+1 = c_t
   L.r_Qs = o, o += align64(TB * g.G * g.KH);
+  L.r_prog = o, o += align64((long long)g.B * WR_PROG_STRIDE);   // progress words of the backward rows (zero between launches: cleared by the forward kernel)
   L.r_total = o;
   o = 0;
   L.f_pack = o, o += align64(P.total);
@@ -308,19 +320,59 @@ int hip_fail(int rc, const char* what) {
 
 // the batched half of a layer's backward: every weight gradient (MFMA products over all rows), their fixed-order sum, and
 // the reference-layout gradients
-static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
-                         const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s) {
-  int rc;
+static WghArgs wgrad_args(const Layout& L, const float* x, const float* y, const float* h0, const float* rs, float* ws) {
   WghArgs wh;
   wh.dpre = ws + L.b_dpre, wh.x = x, wh.y = y, wh.h0 = h0, wh.qx = rs + L.r_qx, wh.dqx = ws + L.b_dqx;
   wh.Qs = rs + L.r_Qs, wh.dQs = ws + L.b_dQs, wh.wpart = ws + L.b_wpart;
-  {
+  return wh;
+}
+
+// Do the weight-gradient products ride on the recurrent backward launch?  Layers of the persistent VALU kernels whose x-side
+// gradient folds into the dpre product (no dqx operand, which only exists after that launch), with few enough batch rows that
+// most of the chip is idle during the recurrence.  Fills w (K = 0: no).
+static void plan_wride(const VGeo& g, const Layout& L, const float* x, const float* y, const float* h0, const float* rs, float* ws,
+                       WRide* w) {
+  memset(w, 0, sizeof(*w));
+  const int n1 = (vg_nb1(g) + 31) / 32, n2 = (g.G * g.KH + 31) / 32;
+  if (!g_wride || g.rb || g.generic || g.bf || !g.foldx || g.R != 1 || g.NT > 256 || g.B > g_wride_maxb || n1 > 2 || n2 > 2) return;
+  const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
+  w->a.dpre = wh.dpre, w->a.x = wh.x, w->a.y = wh.y, w->a.h0 = wh.h0, w->a.qx = wh.qx, w->a.dqx = wh.dqx, w->a.Qs = wh.Qs;
+  w->a.dQs = wh.dQs, w->a.P = wh.wpart;
+  w->prog = reinterpret_cast<unsigned*>(const_cast<float*>(rs + L.r_prog));
+  // rows per chunk: a part of a step's batch rows when they divide evenly (one batch of loads per chunk: the last chunk's
+  // latency is the tail of the launch), else whole steps of at least 64 rows
+  if (g.B % g_wride_rc == 0 && g_wride_rc % 2 == 0) w->S = g_wride_rc;
+  else w->S = g.B * (g.B >= 64 ? 1 : (64 + g.B - 1) / g.B);
+  const int nck = (g.T * g.B + w->S - 1) / w->S;
+  int K = g_wride_k < g.nchunk ? g_wride_k : g.nchunk;         // partial blocks: the workspace holds nchunk of them
+  K = K < nck ? K : nck;
+  w->tasks = g.NT / 8 + (g.H + 31) / 32;
+  const int wpw = (g.NT + 128) / 64;
+  w->ntg = (w->tasks + wpw - 1) / wpw;
+  // every workgroup of the launch has a CU of its own (the launch asks for more than half a CU's LDS): rows + workers must
+  // fit the chip at once, or the workers behind the last CU would only start when the others have finished
+  const int room = (248 - g.nwg) / w->ntg;
+  K = K < room ? K : room;
+  if (K < 4) return;
+  w->K = K;
+  w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
+  w->dry = g_wride_dry;
+}
+
+static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
+                         const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s, const WRide* ride = nullptr) {
+  int rc;
+  const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
+  const bool rode = ride != nullptr && ride->K > 0;
+  if (!rode) {
     Scope sc(5, s);
     if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
   }
   {
     Scope sc(6, s);
-    if ((rc = hip_fail(launch_reduce(g, ws + L.b_wpart, ws + L.b_cgrad, s), "reduce")) != 0) return rc;
+    VGeo gr_ = g;
+    if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
+    if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s), "reduce")) != 0) return rc;
   }
   RefG og;
   og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
@@ -527,6 +579,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   memset(&xw.hd, 0, sizeof(xw.hd));
   if (head_inside) xw.hd.W = head->weight, xw.hd.bias = head->bias, xw.hd.logits = head->logits, xw.hd.C = head->classes;
   a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
+  a.prog = g.training ? reinterpret_cast<unsigned*>(rs + L.r_prog) : nullptr;
   {
     Scope sc(2, s);
     if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
@@ -593,6 +646,8 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     hb.W = head->weight, hb.dl = head->dlogits, hb.hlast = hlast, hb.ldh = g.syB, hb.dW = head->dweight, hb.db = head->dbias;
     hb.C = head->classes;
   }
+  WRide ride;
+  memset(&ride, 0, sizeof(ride));
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -643,6 +698,8 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
   a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
   a.hd = hb;
+  plan_wride(g, L, x, y, h0, rs, ws, &ride);
+  a.wr = ride;
   {
     Scope sc(3, s);
     if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
@@ -655,7 +712,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  return backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s);
+  return backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride);
 }
 
 
@@ -885,6 +942,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       b.VR = pack + P.VR, b.UE = pack + P.UE, b.EH = pack + P.EH;
       b.dpre = wl + Lr.b_dpre, b.dQs = wl + Lr.b_dQs, b.dh0 = ly[l].dh0, b.dc0 = ly[l].dc0, b.trash = wl + Lr.b_trash;
       b.hd = hb;
+      memset(&b.wr, 0, sizeof(b.wr));   // (the tape of a stack launch: its progress words are not this path's)
       {
         Scope sc(3, s);
         if ((rc = hip_fail(launch_rec_bwd(g, b, s), "rec_bwd")) != 0) return rc;

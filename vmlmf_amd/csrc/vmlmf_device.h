@@ -157,12 +157,15 @@ __device__ __forceinline__ const gf32* sel_g(bool c, const float* a, const float
 __device__ __forceinline__ void st4g(gf32* p, float4 v) {
   *reinterpret_cast<gf32x4*>(p) = f32x4{v.x, v.y, v.z, v.w};
 }
+// (Every inline-asm store of more than 8 bytes is followed by `s_nop 1`: gfx940+ needs two wait states between such a store
+// and a VALU write of its data registers; the compiler inserts them for stores it emits itself, but it cannot see into an asm
+// block, and did schedule an address computation into a data register right behind one: a wrong first element in a few rows.)
 // Store written through to agent scope (sc1): visible to workgroups on every XCD once vmcnt has counted it,
 // without the whole-L2 write-back of a release fence (split-K partials of the step-wise GEMMs).  Inline asm: the
 // compiler's waitcnt pass does not see it, the caller waits on vmcnt itself.
 __device__ __forceinline__ void st4g_agent(gf32* p, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(t) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
 }
 __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
   asm volatile("global_store_dword %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
@@ -173,10 +176,21 @@ __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
 // Inline asm: invisible to the compiler's waitcnt pass, which is fine for waves that never wait on stores.
 __device__ __forceinline__ void st4_sv(const void* sbase, unsigned voff, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, %2" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void st1_sv(const void* sbase, unsigned voff, float v) {
   asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+// system-scope write-through variants (sc0 sc1): rows another workgroup, possibly on another XCD, consumes during the launch
+__device__ __forceinline__ void st4_sv_sys(const void* sbase, unsigned voff, float4 v) {
+  const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
+asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void st1_sv_sys(const void* sbase, unsigned voff, float v) {
+  asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void st1u_sv_sys(const void* sbase, unsigned voff, unsigned v) {
+  asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base + lane*SIZE).
 typedef __attribute__((address_space(3))) void lds_void_t;

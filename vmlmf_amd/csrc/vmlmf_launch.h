@@ -24,6 +24,7 @@ struct FwdArgs {
   float* trash;  // >= 64 floats: target of the redirected stores of inactive lanes (keeps stores unconditional)
   float* qxw;    // x-projection wave: qx rows for the weight-gradient kernels (written by the storer wave)
   int xwave;     // 1: wave NW computes the x-projection itself (XwArgs), no gx buffer is read
+  unsigned* prog;  // training: the rows' progress words of the backward launch (WRide), cleared here
 };
 // second argument block of rec_fwd_kernel: what its x-projection wave needs (only that wave reads it, straight
 // from the kernel-argument segment, so it costs the recurrent waves no registers)
@@ -31,11 +32,28 @@ struct XwArgs {
   const float *x, *UXP, *WXD, *BBT;
   HeadFwd hd;   // read from the kernel-argument segment by the epilogue only
 };
+// operands of the weight-gradient products (vmlmf_atb.inc)
+struct AtbArgs {
+  const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
+  float* P;
+};
+// weight-gradient workers riding on rec_bwd_kernel's launch (vmlmf_atb.inc): K workers per task, chunks of S rows (t,b),
+// ntg workgroups per worker index; prog = one progress word per batch row (zero between launches)
+constexpr int WR_PROG_STRIDE = 32;   // unsigned words between two rows' progress words: one 128-byte line each (written through
+                                     // every other step by 64+ workgroups: words sharing a line serialise at the memory side)
+struct WRide {
+  AtbArgs a;
+  unsigned* prog;
+  int K, S, ntg, tasks;
+  int lag, dry;   // lag: segments a progress word trails the stores it covers; dry: the workers leave at once (timing experiments)
+                  // dry bit 1: a progress word every segment instead of every other one
+};
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
   float *dpre, *dQs, *dh0, *dc0;
   float* trash;
   HeadBwd hd;   // read from the kernel-argument segment by the prologue only
+  WRide wr;     // K = 0: no riding workers
 };
 struct WgxArgs {
   const float *dpre, *VRX, *UXO, *EXI;
@@ -89,7 +107,7 @@ int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
-int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s);
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s);
 
 // classifier head (vmlmf_head.hip)

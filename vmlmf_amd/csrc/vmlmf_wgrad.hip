@@ -112,197 +112,7 @@ __global__ void __launch_bounds__(MAXT) dqx_dx_kernel(VGeo g, WgxArgs a) {
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// wgrad_mfma_kernel: every weight gradient is a product  C = A^T B  contracted over the (t,b) rows, with a
-// skinny B (the rank-space vectors).  One wave owns a 32-wide tile of A's columns and up to three 32-wide
-// tiles of B's columns for one chunk of rows, on v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain; each
-// instruction contracts 2 rows).  Three products share the kernel (wave task -> mode):
-//   mode 1  A = dpre  [rows x (slot,k)]   B = [qx | Q_0 | Q_1]  -> dV_x, dV_h   (+ column sums d(eh), d(ex), db)
-//   mode 2  A = h_{t-1} [rows x unit]     B = [dQ_0 | dQ_1]      -> dU_h
-//   mode 3  A = x     [rows x input]      B = dqx                -> dU_x
-// Operand layout of the instruction (cdna_hip_programming.md section 3): lane l supplies A[i = l&31][k = l>>5]
-// and B[k = l>>5][j = l&31]; result register r of lane l is C[i = (r&3) + 8*(r>>2) + 4*(l>>5)][j = l&31].
-// Partials per chunk go to P (summed in fixed order by reduce_kernel: deterministic, no float atomics).
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct AtbArgs {
-  const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
-  float* P;
-};
-
-// NS (1, 2, 4): that many waves share the task, each takes a part of the chunk's rows; parts 1.. hand their
-// accumulators to part 0 through `comb` (LDS, [task slot][part - 1][value][lane]) and part 0 writes the sum
-// (parts added in index order: deterministic).
-template <int MODE, int NBT, int NS>
-__device__ __forceinline__ void atb_task(const VGeo& g, const AtbArgs& a, const int mt, const int chunk,
-                                         const int lane, const int half, float* comb) {
-  const int B = g.B, H = g.H, NT = g.NT, KX = g.KX, GK = g.G * g.KH;
-  const int TB = g.T * B;
-  const int MT2 = (H + 31) / 32, MT3 = (g.I + 31) / 32;   // (partial layout: the C3 block stays in place with the x-fold)
-  const int crow0 = chunk * g.RC2;
-  const int crow1 = crow0 + g.RC2 < TB ? crow0 + g.RC2 : TB;
-  // parts are cut at even rows so that each MFMA still contracts a (row, row + 1) pair of one part
-  const int plen = ((crow1 - crow0 + NS - 1) / NS + 1) / 2 * 2;
-  const int row0 = crow0 + half * plen < crow1 ? crow0 + half * plen : crow1;
-  const int row1 = row0 + plen < crow1 && half != NS - 1 ? row0 + plen : crow1;
-  const int li = lane & 31, lk = lane >> 5;
-  const int NB = MODE == 1 ? vg_nb1(g) : (MODE == 2 ? GK : KX);   // B columns
-  const int qoff = (MODE == 1 && !g.flat) ? ((mt * 8) / (64 * g.W)) * g.KH : 0;   // mode 1: this task's group's vector
-  constexpr int nbt = NBT;
-  const int col = mt * 32 + li;                                     // A column of this lane
-  int n1 = 0;
-  bool v1 = false;
-  if (MODE == 1) v1 = vg_slot_unit(g, col >> 2, n1);                // unit of this (slot,k) column
-  const int an = MODE == 1 ? (v1 ? n1 : 0) : (MODE == 2 ? (col < H ? col : 0) : (col < g.I ? col : 0));
-  const float amask = MODE == 1 ? 1.f : ((MODE == 2 ? col < H : col < g.I) ? 1.f : 0.f);
-  const float hmask = (MODE == 1 && v1) ? 1.f : 0.f;
-  const bool xm = MODE == 1 && v1 && n1 < g.I;
-  const int xn = xm ? n1 : 0;
-  // B column sources (per lane, fixed): pointer + row stride, masked when out of range
-  const float* bsrc[NBT];
-  unsigned bstr[NBT];
-  float bmask[NBT];
-  bool bisx[NBT];   // x-fold: the column is a column of x, addressed by (t, b) strides
-#pragma unroll
-  for (int j = 0; j < NBT; ++j) {
-    const int c = j * 32 + li;
-    const bool okc = j < nbt && c < NB;
-    bmask[j] = okc ? 1.f : 0.f;
-    const int cc = okc ? c : 0;
-    bisx[j] = false;
-    if (MODE == 1) {
-      if (g.foldx && cc < KX) {   // G = dpre^T x in the columns qx had (I <= KX; the rest of them stay zero)
-        bisx[j] = true;
-        if (cc >= g.I) bmask[j] = 0.f;
-        bsrc[j] = a.x + (cc < g.I ? cc : 0);
-        bstr[j] = 0;
-      } else {
-        bsrc[j] = cc < KX ? a.qx + cc : a.Qs + qoff + (cc - KX);
-        bstr[j] = cc < KX ? KX : GK;
-      }
-    } else if (MODE == 2) {
-      bsrc[j] = a.dQs + cc;
-      bstr[j] = GK;
-    } else {
-      bsrc[j] = a.dqx + cc;
-      bstr[j] = KX;
-    }
-  }
-  const bool has_h0 = a.h0 != nullptr;
-
-  f32x16 acc[NBT];
-#pragma unroll
-  for (int j = 0; j < NBT; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  float e_h = 0.f, e_x = 0.f, e_b = 0.f;
-  // element offsets fit 32 bits (checked by the host: T*B*H and T*Bp*NT*4 < 2^31)
-  const unsigned usyT = (unsigned)g.syT, usyB = (unsigned)g.syB, usxT = (unsigned)g.sxT, usxB = (unsigned)g.sxB;
-
-  constexpr int U = 8;   // row pairs per batch: every load of a batch is issued (branch-free) before its MFMAs
-  // (t, b) of this lane's first row; advanced incrementally (one integer division per task, not per row)
-  unsigned tt = (unsigned)(row0 + lk) / (unsigned)B, bb = (unsigned)(row0 + lk) - tt * (unsigned)B;
-  for (int rb = row0; rb < row1; rb += 2 * U) {
-    float av[U], bv[U][NBT], hv[U], xv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int r = rb + 2 * u + lk;
-      const bool ok = r < row1;
-      // clamp to the last valid row of the chunk (values are masked by okf)
-      const unsigned t = ok ? tt : (unsigned)(row1 - 1) / (unsigned)B;
-      const unsigned b = ok ? bb : (unsigned)(row1 - 1) - t * (unsigned)B;
-      const unsigned rc = t * (unsigned)B + b;
-      bb += 2;
-      if (bb >= (unsigned)B) {   // B >= 1; two rows ahead wraps at most... (B == 1: twice)
-        bb -= (unsigned)B;
-        ++tt;
-        if (bb >= (unsigned)B) {
-          bb -= (unsigned)B;
-          ++tt;
-        }
-      }
-      // h_{t-1}: y[t-1] for t > 0, else h0 (or 0): address select + mask, no branch
-      const float* hp = t > 0 ? a.y + ((t - 1) * usyT + b * usyB) : (has_h0 ? a.h0 + b * (unsigned)H : a.y + b * usyB);
-      const float hm = (t > 0 || has_h0) ? 1.f : 0.f;
-      const float okf = ok ? 1.f : 0.f;
-      if (MODE == 1) {
-        av[u] = okf * tape_elem(a.dpre, (t * (unsigned)g.Bp + b) * (unsigned)(NT * 4) + col, g.bf);
-        hv[u] = hmask * hm * hp[an];
-        xv[u] = xm ? a.x[t * usxT + b * usxB + xn] : 0.f;
-      } else if (MODE == 2) {
-        av[u] = okf * amask * hm * hp[an];
-        hv[u] = 0.f, xv[u] = 0.f;
-      } else {
-        av[u] = okf * amask * a.x[t * usxT + b * usxB + an];
-        hv[u] = 0.f, xv[u] = 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < NBT; ++j)
-        bv[u][j] = bmask[j] * bsrc[j][(MODE == 1 && bisx[j]) ? t * usxT + b * usxB : rc * bstr[j]];
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-#pragma unroll
-      for (int j = 0; j < NBT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
-      if (MODE == 1) {
-        e_h = fmaf(av[u], hv[u], e_h);
-        e_x = fmaf(av[u], xv[u], e_x);
-        e_b += av[u];
-      }
-    }
-  }
-
-  if constexpr (NS > 1) {
-    constexpr int NV = 16 * NBT + 3;
-    if (half > 0) {
-      float* mine = comb + (size_t)(half - 1) * NV * 64;
-#pragma unroll
-      for (int j = 0; j < NBT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64 + lane] = acc[j][r];
-      mine[(NV - 3) * 64 + lane] = e_h;
-      mine[(NV - 2) * 64 + lane] = e_x;
-      mine[(NV - 1) * 64 + lane] = e_b;
-    }
-    __syncthreads();
-    if (half > 0) return;
-#pragma unroll
-    for (int hp = 0; hp < NS - 1; ++hp) {
-      const float* other = comb + (size_t)hp * NV * 64;
-#pragma unroll
-      for (int j = 0; j < NBT; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] += other[(j * 16 + r) * 64 + lane];
-      e_h += other[(NV - 3) * 64 + lane];
-      e_x += other[(NV - 2) * 64 + lane];
-      e_b += other[(NV - 1) * 64 + lane];
-    }
-  }
-  // partial layout per chunk: C1 [NT*4][NB1p] | C2 [M2p][NB2p] | C3 [M3p][NB3p] | E [3][NT*4]
-  const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
-  const size_t o2 = (size_t)NT * 4 * NB1p, o3 = o2 + (size_t)MT2 * 32 * NB2p, oe = o3 + (size_t)MT3 * 32 * NB3p;
-  float* P = a.P + (size_t)chunk * g.PCH;
-  float* C = MODE == 1 ? P : (MODE == 2 ? P + o2 : P + o3);
-  const int ldc = MODE == 1 ? NB1p : (MODE == 2 ? NB2p : NB3p);
-#pragma unroll
-  for (int j = 0; j < NBT; ++j) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int i = (r & 3) + 8 * (r >> 2) + 4 * lk;
-      C[(size_t)(mt * 32 + i) * ldc + j * 32 + li] = acc[j][r];
-    }
-  }
-  if (MODE == 1) {   // column sums: the two half-waves hold the even / odd rows
-    e_h += __shfl_xor(e_h, 32);
-    e_x += __shfl_xor(e_x, 32);
-    e_b += __shfl_xor(e_b, 32);
-    if (lk == 0) {
-      P[oe + 0 * (size_t)NT * 4 + col] = e_h;
-      P[oe + 1 * (size_t)NT * 4 + col] = e_x;
-      P[oe + 2 * (size_t)NT * 4 + col] = e_b;
-    }
-  }
-}
+#include "vmlmf_atb.inc"
 
 // NBT1 / NBT2: 32-wide tiles of B for mode 1 (KX + G*KH columns) and mode 2 (G*KH columns); mode 3 has one.
 // NS: 4 NS waves per workgroup, waves w, w + 4, ... share task w (a part of the rows each): the kernel is bound by
@@ -401,7 +211,10 @@ __device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __res
 }
 
 __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __restrict__ Pall,
-                                                        float* __restrict__ cgrad) {
+                                                        float* __restrict__ cgrad, unsigned* __restrict__ prog) {
+  // after a launch with riding workers: the rows' progress words back to zero (nothing reads them any more)
+  if (prog != nullptr && blockIdx.x == 0)
+    for (int b = threadIdx.x; b < g.B; b += 256) prog[(size_t)b * WR_PROG_STRIDE] = 0u;
   reduce_cg_body(g, Pall, cgrad);
 }
 struct ReduceStack {
@@ -476,8 +289,8 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, hipStream_t s) {
-  hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad);
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s) {
+  hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad, prog);
   return (int)hipGetLastError();
 }
 
