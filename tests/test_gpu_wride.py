@@ -1,0 +1,128 @@
+"""GPU parity of the weight-gradient workers that ride on the recurrent backward launch (vmlmf_rec_bwd.inc RIDE,
+vmlmf_atb.inc): layers whose input is not wider than the padded w_rank (the x-fold), batch <= 128, fp32, on the persistent
+VALU kernels.  The workers read rows that other workgroups write during the same launch, so besides the oracle comparison
+the tests look for what such a protocol gets wrong: stale progress words or stale rows when the same buffers are used again
+with other data, the last steps of a sequence (published at the end of the launch), very short sequences (shorter than the
+lag of the progress words), odd batches, a second backward over the same tape."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import vmlmf_oracle as O
+from hip_util import run_hip, run_literal, compare_all, assert_grad, ORDER, ranks_of
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _case(variant, B, T, I, H, rw, ru, seed, states=True):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    P = O.make_params(variant, I, H, rw, ru if variant in (O.V2, O.V4, O.V6) else ru[0], seed=seed + 1)
+    x = rng.standard_normal((B, T, I)).astype(np.float32)
+    h0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if states else None
+    c0 = (0.4 * rng.standard_normal((B, H))).astype(np.float32) if states else None
+    dy = rng.standard_normal((B, T, H)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    dcT = rng.standard_normal((B, H)).astype(np.float32)
+    return P, x, h0, c0, dy, dhT, dcT
+
+
+# (variant, B, T, I, H, w_rank, u_ranks): every one has I <= padded w_rank and B <= 128, i.e. rides
+RIDING = [
+    (O.V1, 64, 40, 9, 180, 16, [16]),       # the headline layer (its full length: test_gpu_parity, golden vectors)
+    (O.V1, 128, 24, 8, 100, 8, [16]),       # largest riding batch
+    (O.V1, 37, 9, 5, 70, 6, [12]),          # odd batch: whole-step chunks, row pairs straddle steps
+    (O.V1, 3, 1, 4, 40, 4, [8]),            # one step: the only progress word is the final one
+    (O.V1, 16, 2, 9, 64, 8, [8]),           # shorter than the lag of the progress words
+    (O.V1, 16, 5, 9, 64, 8, [8]),
+    (O.V2, 32, 12, 9, 180, 16, [16, 16]),   # group cell: two 32-wide tiles of B columns
+    (O.V1, 8, 7, 30, 130, 32, [32]),        # rank 32 on both sides
+    (O.V3, 24, 6, 24, 24, 24, [8]),         # PTB cell (input size = hidden size), small enough to fold
+    (O.V6, 20, 6, 10, 80, 12, [12, 12]),    # group cell without vm
+    (O.V5, 20, 6, 10, 80, 12, [12]),        # MyLSTMCell low-rank (no vm)
+]
+
+
+@pytest.mark.parametrize("case", RIDING, ids=lambda c: "v%d_B%d_T%d_I%d_H%d_r%d_%s" % (c[0], c[1], c[2], c[3], c[4], c[5], "_".join(map(str, c[6]))))
+def test_riding_workers_vs_oracle(case):
+    variant, B, T, I, H, rw, ru = case
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=11 * B + T)
+    got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT)
+    compare_all(got, ref, "ride")
+
+
+def test_same_buffers_other_data_every_launch():
+    """One module, the same shapes (so the caching allocator hands back the same tape and workspace), new inputs and new
+    upstream gradients every iteration: a stale progress word or a stale row of an earlier launch would show up in the
+    weight gradients, which are compared with the oracle each time."""
+    variant, B, T, I, H, rw, ru = O.V1, 64, 48, 9, 180, 16, [16]
+    for it in range(6):
+        P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=100 + it, states=(it % 2 == 0))
+        got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+        ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT)
+        compare_all(got, ref, "it%d" % it)
+
+
+def test_second_backward_over_the_same_tape():
+    """retain_graph: the progress words go back to zero after a launch (reduce_cg_kernel), so a second backward over the
+    same tape waits for its own rows instead of finding the words of the first one."""
+    from vmlmf_amd import vmlmf_sequence
+    variant, B, T, I, H, rw, ru = O.V1, 48, 20, 9, 120, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=5, states=False)
+    names = ORDER[variant]
+    params = [torch.tensor(np.asarray(P[k]), dtype=torch.float32, device="cuda").requires_grad_(True) for k in names]
+    xt = torch.tensor(x, device="cuda")
+    r_w, r_u, g = ranks_of(variant, P)
+    y, hT, cT = vmlmf_sequence(variant, xt, None, None, params, r_w, r_u, g=g)
+    dy1 = torch.tensor(dy, device="cuda")
+    dy2 = torch.tensor(dy[::-1].copy(), device="cuda")
+    g1 = torch.autograd.grad((y * dy1).sum(), params, retain_graph=True)
+    g2 = torch.autograd.grad((y * dy2).sum(), params)
+    ref1 = run_literal(variant, P, x, None, None, dy, None, None)
+    ref2 = run_literal(variant, P, x, None, None, dy[::-1].copy(), None, None)
+    for k, a, b in zip(names, g1, g2):
+        assert_grad(a.cpu().numpy(), ref1["G"][k], "first." + k)
+        assert_grad(b.cpu().numpy(), ref2["G"][k], "second." + k)
+
+
+def test_results_repeat_bit_for_bit():
+    """Fixed chunk -> worker assignment and a fixed-order sum of the partial blocks: the same inputs give the same bits,
+    however the workers were scheduled."""
+    variant, B, T, I, H, rw, ru = O.V1, 64, 64, 9, 180, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=77)
+    first = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    for _ in range(4):
+        again = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+        for k in first["G"]:
+            assert np.array_equal(first["G"][k], again["G"][k]), k
+        assert np.array_equal(first["dx"], again["dx"])
+
+
+@pytest.mark.parametrize("env", [{"VMLMF_WRIDE": "0"}, {"VMLMF_WRIDE_K": "5"}, {"VMLMF_WRIDE_RC": "16"}, {"VMLMF_WRIDE_RC": "64"},
+                                 {"VMLMF_WRIDE_LAG": "1"}, {"VMLMF_WRIDE_LAG": "6"}, {"VMLMF_WRIDE_MAXB": "8"}],
+                         ids=lambda e: "_".join(f"{k[6:]}{v}" for k, v in e.items()))
+def test_switches_of_the_riding_workers(env):
+    """VMLMF_WRIDE* (read once when the library loads): off, few workers, other chunk sizes, other lags of the progress words,
+    a batch limit below the test's batch - in a fresh interpreter each, against the oracle."""
+    code = (
+        "import sys; sys.path[:0] = [%r, %r, %r]\n"
+        "import numpy as np, vmlmf_oracle as O\n"
+        "from hip_util import run_hip, run_literal, compare_all\n"
+        "for variant, B, T, I, H, rw, ru in [(O.V1, 64, 40, 9, 180, 16, [16]), (O.V1, 10, 3, 12, 40, 12, [40]), (O.V2, 32, 9, 9, 96, 16, [16, 16])]:\n"
+        "    rng = np.random.Generator(np.random.PCG64(5))\n"
+        "    P = O.make_params(variant, I, H, rw, ru if variant == O.V2 else ru[0], seed=7)\n"
+        "    x = rng.standard_normal((B, T, I)).astype(np.float32)\n"
+        "    dy = rng.standard_normal((B, T, H)).astype(np.float32)\n"
+        "    dhT = rng.standard_normal((B, H)).astype(np.float32)\n"
+        "    for it in range(2):\n"
+        "        compare_all(run_hip(variant, P, x, None, None, dy, dhT, None), run_literal(variant, P, x, None, None, dy, dhT, None), 'switch')\n"
+        "print('ok')\n") % (ROOT, os.path.join(ROOT, "oracle"), HERE)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
