@@ -173,24 +173,43 @@ __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
 // Stores in the scalar-base + 32-bit vector byte-offset form (global_store ... v_off, v_data, s[base:base+1]).
 // hipcc turns `uniform_ptr[per_lane_index]` into 64-bit per-lane pointers and updates them with vector adds; in
 // the storer waves of the recurrent kernels that arithmetic was most of their ~200 vector instructions per step.
-// Inline asm: invisible to the compiler's waitcnt pass, which is fine for waves that never wait on stores.
+// Inline asm: invisible to the compiler's waitcnt pass, which is fine for waves that never wait on stores - and invisible to
+// its hazard recognizer, which matters twice on gfx940+:
+//  (1) a store of more than 8 bytes needs two wait states before a VALU instruction overwrites its data registers.  The
+//      compiler scheduled an address computation into the first data register right behind such a store (a wrong first
+//      element of dpre[0] in ~20 % of the rows of a new kernel, timing-dependent): every wide store carries `s_nop 1` behind it.
+//  (2) a scalar register written by a VALU instruction (v_readlane: a spilled scalar register coming back from its vector
+//      lane) needs five wait states before a vector memory instruction uses it as an address.  In the large kernels the
+//      reload sat right in front of the store, which then went to a garbage address (memory access faults that came and went
+//      with unrelated changes of a kernel; the faults of the wavefront kernels with a noinline function were the same thing).
+//      SAFE = true puts `s_nop 4` in front of the store.  It is not the default: the storer waves are on the critical path of
+//      the recurrent kernels and 20 clocks a store cost 14 us of the headline step (a copy of the base through s_mov_b64
+//      cost 20, the same stores as raw-buffer builtins - which the compiler does guard by itself - 16: four scalar registers
+//      a base, more spills).  The instantiations whose scalar registers do spill around the stores set SAFE (see the
+//      SAFE_ST constants of the kernels), and tools/check_asm_hazards.py, run by the CPU tests on the built library,
+//      disassembles every kernel and fails on either hazard at any store with a scalar base.
+template <bool SAFE = false>
 __device__ __forceinline__ void st4_sv(const void* sbase, unsigned voff, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
 }
+template <bool SAFE = false>
 __device__ __forceinline__ void st1_sv(const void* sbase, unsigned voff, float v) {
-  asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  else asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // system-scope write-through variants (sc0 sc1): rows another workgroup, possibly on another XCD, consumes during the launch
+template <bool SAFE = false>
 __device__ __forceinline__ void st4_sv_sys(const void* sbase, unsigned voff, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
-asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  else asm volatile("global_store_dwordx4 %0, %1, %2 sc0 sc1\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
 }
-__device__ __forceinline__ void st1_sv_sys(const void* sbase, unsigned voff, float v) {
-  asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void st1u_sv_sys(const void* sbase, unsigned voff, unsigned v) {
-  asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+template <bool SAFE = false, class V>
+__device__ __forceinline__ void st1_sv_sys(const void* sbase, unsigned voff, V v) {   // V: float or unsigned
+  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  else asm volatile("global_store_dword %0, %1, %2 sc0 sc1" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // LDS-DMA: 64 lanes x SIZE bytes from per-lane global addresses to LDS at (wave-uniform base + lane*SIZE).
 typedef __attribute__((address_space(3))) void lds_void_t;
