@@ -498,7 +498,7 @@ def main():
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; they were collected
         # with rocprofv3 in separate passes on this same command and committed under profiles/
         traffic, traffic_note, util, util_note = None, None, None, None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
@@ -507,14 +507,19 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
-            u = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_util.json")))["kernels"][dom]["derived"]
+            util_file = "r02_zz4_pmc_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_zz4_pmc_util.json")) else "r02_pmc_util.json"
+            u = json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"][dom]["derived"]
             util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
                                           "lds_conflict_frac", "valu_insts_per_wave", "mfma_insts_per_wave")}
-            util_note = "profiles/r02_pmc_util.json (rocprofv3 --pmc SQ_*; fractions of SQ_WAVE_CYCLES resp. of busy-CU cycles)"
+            util_note = f"profiles/{util_file} (rocprofv3 --pmc SQ_*; fractions of SQ_WAVE_CYCLES resp. of busy-CU cycles)"
         except (OSError, KeyError, ValueError):
             pass
         rows = rows_gpu * T                              # sample-timesteps one launch processes
-        flops = rows * F_H * (1 if dom == "rec_fwd_kernel" else 1)   # 10 H ru per sample-step either way
+        # 10 H ru per sample-step in either recurrent kernel; a backward launch that carries the weight-gradient workers
+        # (no wgrad_mfma_kernel launch in the breakdown pass) also does their products: dpre^T x, dpre^T Q, h^T dQ
+        riding = dom == "rec_bwd_kernel" and kern.get("wgrad_mfma_kernel", 0.0) == 0.0
+        F_WG = 2 * 4 * H * I + 2 * 4 * H * RU + 2 * H * RU
+        flops = rows * (F_H + (F_WG if riding else 0))
         achieved = flops / (rec[dom] * 1e-6) / 1e12
         out = {
             "metric": "RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16; 1/2/4/8 GPU",
@@ -545,10 +550,13 @@ def main():
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                          "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
                          # one batch row per CU: rows_gpu of 256 CUs are busy; the same rate against THEIR share of the peak
-                         "active_cus": min(rows_gpu, 256),
-                         "frac_of_active_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * min(rows_gpu, 256) / 256.0), 5),
+                         "active_cus": min(rows_gpu, 256) if not riding else min(rows_gpu + 180, 256),
+                         "frac_of_active_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * (min(rows_gpu, 256) if not riding else min(rows_gpu + 180, 256)) / 256.0), 5),
                          "utilisation": util, "utilisation_source": util_note,
                          "flops_per_launch": flops,
+                         "contains": ("recurrence (10 H ru per sample-step) + the weight-gradient products riding on the launch "
+                                      "(8 H I + 8 H ru + 2 H ru per sample-step, on otherwise idle CUs)") if riding else
+                                     "recurrence (10 H ru per sample-step)",
                          "measured": "HIP event pairs on the launch stream over the eager timed region of the same K "
                                      "steps (events cannot be read inside a replayed hipGraph)",
                          "note": "fp32: MFMA peak == vector peak on gfx950; the kernel is a 2T-long dependent "

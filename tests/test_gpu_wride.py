@@ -1,5 +1,5 @@
 """GPU parity of the weight-gradient workers that ride on the recurrent backward launch (vmlmf_rec_bwd.inc RIDE,
-vmlmf_atb.inc): layers whose input is not wider than the padded w_rank (the x-fold), batch <= 128, fp32, on the persistent
+vmlmf_atb.inc): layers whose input is not wider than the padded w_rank (the x-fold), batch <= 96, fp32, on the persistent
 VALU kernels.  The workers read rows that other workgroups write during the same launch, so besides the oracle comparison
 the tests look for what such a protocol gets wrong: stale progress words or stale rows when the same buffers are used again
 with other data, the last steps of a sequence (published at the end of the launch), very short sequences (shorter than the
@@ -36,7 +36,8 @@ def _case(variant, B, T, I, H, rw, ru, seed, states=True):
 # (variant, B, T, I, H, w_rank, u_ranks): every one has I <= padded w_rank and B <= 128, i.e. rides
 RIDING = [
     (O.V1, 64, 40, 9, 180, 16, [16]),       # the headline layer (its full length: test_gpu_parity, golden vectors)
-    (O.V1, 128, 24, 8, 100, 8, [16]),       # largest riding batch
+    (O.V1, 96, 24, 8, 100, 8, [16]),        # largest riding batch
+    (O.V1, 128, 10, 8, 100, 8, [16]),       # just above it: the stand-alone kernel
     (O.V1, 37, 9, 5, 70, 6, [12]),          # odd batch: whole-step chunks, row pairs straddle steps
     (O.V1, 3, 1, 4, 40, 4, [8]),            # one step: the only progress word is the final one
     (O.V1, 16, 2, 9, 64, 8, [8]),           # shorter than the lag of the progress words

@@ -84,7 +84,7 @@ const bool g_wride = []() {
   return e == nullptr || e[0] != '0';
 }();
 const int g_wride_k = env_pos("VMLMF_WRIDE_K", 32);
-const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 128);
+const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 96);   // measured at H = 180, T = 128: B 32 +3 %, 64 +10 %, 80 and 96 +1 %, 112 -17 % (too few free CUs for the workers to keep up)
 const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
 const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
 const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
