@@ -106,6 +106,39 @@ def test_results_repeat_bit_for_bit():
         assert np.array_equal(first["dx"], again["dx"])
 
 
+def test_backward_under_load_from_another_stream():
+    """A second stream keeps the chip busy with large products while the backward launch with its workers runs: the rows'
+    workgroups are dispatched before the workers' (lower block ids), so the workers can be late but never wait for rows that
+    have no CU; the gradients are the same bits as in the quiet run."""
+    from vmlmf_amd import vmlmf_sequence
+    variant, B, T, I, H, rw, ru = O.V1, 64, 96, 9, 180, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=21, states=False)
+    names = ORDER[variant]
+    params = [torch.tensor(np.asarray(P[k]), dtype=torch.float32, device="cuda").requires_grad_(True) for k in names]
+    xt = torch.tensor(x, device="cuda")
+    dyt = torch.tensor(dy, device="cuda")
+    r_w, r_u, g = ranks_of(variant, P)
+
+    def grads():
+        y, hT, cT = vmlmf_sequence(variant, xt, None, None, params, r_w, r_u, g=g)
+        return [t.clone() for t in torch.autograd.grad((y * dyt).sum(), params)]
+
+    quiet = grads()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 4096, device="cuda")
+    for i in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                a = (a @ a).clamp_(-1, 1)
+        busy = grads()
+        for k, q, b in zip(names, quiet, busy):
+            assert torch.equal(q, b), (i, k)
+    torch.cuda.synchronize()
+    ref = run_literal(variant, P, x, None, None, dy, None, None)
+    for k, q in zip(names, quiet):
+        assert_grad(q.cpu().numpy(), ref["G"][k], k)
+
+
 @pytest.mark.parametrize("env", [{"VMLMF_WRIDE": "0"}, {"VMLMF_WRIDE_K": "5"}, {"VMLMF_WRIDE_RC": "16"}, {"VMLMF_WRIDE_RC": "64"},
                                  {"VMLMF_WRIDE_LAG": "1"}, {"VMLMF_WRIDE_LAG": "6"}, {"VMLMF_WRIDE_MAXB": "8"}],
                          ids=lambda e: "_".join(f"{k[6:]}{v}" for k, v in e.items()))
