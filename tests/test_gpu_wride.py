@@ -59,6 +59,31 @@ def test_riding_workers_vs_oracle(case):
     compare_all(got, ref, "ride")
 
 
+def test_random_riding_shapes_vs_oracle():
+    """Seeded random layers that ride (I <= padded w_rank, B <= 96): hidden sizes across the wave counts, every padded rank
+    of the instantiations (8 / 16 / 24 / 32), one and two groups, cells with and without vm, odd batches, with and without
+    initial states and upstream gradients of the final states."""
+    rng = np.random.Generator(np.random.PCG64(2024))
+    for it in range(24):
+        variant = [O.V1, O.V2, O.V5, O.V6][it % 4]
+        two = variant in (O.V2, O.V6)
+        H = int(rng.choice([24, 40, 64, 90, 128, 180, 200, 256]))
+        if two and H % 2:
+            H += 1
+        rw = int(rng.choice([3, 8, 12, 16, 24, 30]))
+        I = int(rng.integers(1, ((rw + 7) // 8) * 8 + 1))           # <= padded w_rank
+        I = max(2, min(I, H))                                       # (the reference's group cells squeeze() a 1-wide input away)
+        ru = [int(rng.choice([4, 8, 13, 16])) for _ in range(2)] if two else [int(rng.choice([4, 8, 16, 21, 32]))]
+        B = int(rng.integers(2, 97))
+        T = int(rng.integers(1, 30))
+        P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=300 + it, states=bool(it & 1))
+        if it % 3 == 0:
+            dhT, dcT = None, None
+        got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+        ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT)
+        compare_all(got, ref, "it%d v%d B%d T%d I%d H%d rw%d ru%s" % (it, variant, B, T, I, H, rw, ru))
+
+
 def test_same_buffers_other_data_every_launch():
     """One module, the same shapes (so the caching allocator hands back the same tape and workspace), new inputs and new
     upstream gradients every iteration: a stale progress word or a stale row of an earlier launch would show up in the
