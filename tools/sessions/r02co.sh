@@ -1,0 +1,3 @@
+cd $GRAFT_REPO_ROOT
+for i in 1 2; do timeout 200 python bench.py --no-cpu-baseline --no-extra 2>/dev/null < /dev/null | tail -1 | grep -o '"ms_per_step": [0-9.]*'; done
+timeout 1500 python -m pytest tests/ -m gpu -x -q 2>&1 | grep -E "passed|failed|FAILED|rror|assert" | head -8

@@ -76,7 +76,7 @@ int env_pos(const char* name, int dflt) {
 }
 const int g_wchunks = env_pos("VMLMF_WCHUNKS", 64);
 const int g_rc = env_pos("VMLMF_RC", 0);   // dqx_dx rows per workgroup (A/B); 0 = derived from the row count
-const int g_wmin = env_pos("VMLMF_WMIN", 64);
+const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
 // weight-gradient workers riding on rec_bwd_kernel's launch (vmlmf_atb.inc): VMLMF_WRIDE=0 off; VMLMF_WRIDE_K = workers per
 // task, VMLMF_WRIDE_MAXB = largest batch that rides (beyond it the rows fill the chip and the workers only compete with them)
 const bool g_wride = []() {
@@ -87,7 +87,8 @@ const int g_wride_k = env_pos("VMLMF_WRIDE_K", 32);
 const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 96);   // measured at H = 180, T = 128: B 32 +3 %, 64 +10 %, 80 and 96 +1 %, 112 -17 % (too few free CUs for the workers to keep up)
 const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
 const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
-const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
+// experiments (bits): 1 = the workers leave at once, 2 = a progress word every step
+const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);
 
 // Row-block MFMA kernels (vmlmf_rb.hip): -1 = automatic (large batches, and layers beyond the register-resident VALU kernels),
 // 0 = never, 1 = wherever an instantiation exists.  VMLMF_RB in the environment, or vmlmf_tune("rb", v) at run time.
