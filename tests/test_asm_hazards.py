@@ -20,7 +20,8 @@ def test_no_unguarded_hazard_at_an_asm_store():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_hazards.py"), LIB], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     first = r.stdout.splitlines()[0]
-    assert "0 hazard(s)" in first and int(first.split()[2]) > 1000, first   # it did look at the stores
+    assert "0 hazard(s)" in first and int(first.split()[2]) > 1000, first   # it did look at the stores ...
+    assert int(first.split(";")[1].split()[0]) > 1000, first                # ... and at the DPP rank reduces
 
 
 def test_the_checker_finds_a_planted_hazard(tmp_path):
@@ -33,7 +34,10 @@ def test_the_checker_finds_a_planted_hazard(tmp_path):
     good = ["v_readlane_b32 s29, v184, 14", "s_nop 4", "global_store_dwordx4 v8, v[4:7], s[28:29]", "s_nop 1", "v_add_u32_e32 v4, 1, v4",
             "v_readlane_b32 s31, v1, 2", "s_mov_b32 s0, 0", "s_mov_b32 s0, 0", "s_mov_b32 s0, 0", "s_mov_b32 s0, 0", "s_mov_b32 s0, 0",
             "global_store_dword v14, v4, s[30:31]", "v_mov_b32_e32 v4, 0"]
-    for lines, n in ((bad_a, 1), (bad_b, 1), (good, 0)):
+    bad_c = ["v_mul_f32_e32 v5, v1, v2", "v_fmac_f32_dpp v9, v5, v7 row_ror:1 row_mask:0xf bank_mask:0xf"]
+    good_c = ["v_mul_f32_e32 v5, v1, v2", "s_nop 1", "v_fmac_f32_dpp v9, v5, v7 row_ror:1 row_mask:0xf bank_mask:0xf",
+              "v_fmac_f32_dpp v9, v5, v8 row_ror:2 row_mask:0xf bank_mask:0xf"]
+    for lines, n in ((bad_a, 1), (bad_b, 1), (good, 0), (bad_c, 1), (good_c, 0)):
         problems = []
         C.check_kernel("k", lines, problems)
         assert len(problems) == n, (lines, problems)

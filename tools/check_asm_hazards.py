@@ -4,7 +4,9 @@
 
   A. a vector memory instruction that takes its address from scalar registers needs five wait states after a VALU
      instruction wrote those registers (v_readlane / v_readfirstlane / v_cmp ... -> s[N:N+1]);
-  B. a store of more than 8 bytes needs two wait states before a VALU instruction overwrites its data registers.
+  B. a store of more than 8 bytes needs two wait states before a VALU instruction overwrites its data registers;
+  C. a DPP instruction (v_fmac_f32_dpp ... row_ror, the rank reduce of the recurrent kernels, also inline asm) needs two
+     wait states after a VALU instruction wrote the register it reads across lanes.
 
 The compiler inserts the wait states for the memory instructions it emits itself; the stores written as inline asm
 (scalar base + 32-bit vector offset: st4_sv, st1_sv and their write-through variants) are invisible to it.  This script
@@ -60,9 +62,25 @@ def dest_regs(ins):
     return out
 
 
+DPP = re.compile(r"^\s*(v_\w+_dpp)\s+(v\d+),\s*(v\d+)")
+
+
 def check_kernel(name, lines, problems):
     n = len(lines)
     for i, ins in enumerate(lines):
+        d = DPP.match(ins)
+        if d:   # C: a DPP instruction reads its first source from other lanes: two wait states after a VALU write of it
+            src, ws, j = d.group(3), 0, i - 1
+            while j >= 0 and ws < 2:
+                prev = lines[j]
+                if prev.endswith(":"):
+                    break
+                if src in dest_regs(prev):
+                    problems.append(f"{name}: VALU write of {src} {ws} wait state(s) before the DPP read `{ins.strip()}`: `{prev.strip()}`")
+                    break
+                ws += wait_states(prev)
+                j -= 1
+            continue
         m = STORE.match(ins)
         if not m:
             continue
@@ -109,7 +127,7 @@ def disassemble(lib):
 
 
 def main(lib):
-    problems, kernels, stores = [], 0, 0
+    problems, kernels, stores, dpps = [], 0, 0, 0
     for _, text in disassemble(lib):
         name, cur = None, []
         for raw in text.splitlines():
@@ -121,6 +139,7 @@ def main(lib):
                 if name is not None:
                     kernels += 1
                     stores += sum(1 for x in cur if STORE.match(x))
+                    dpps += sum(1 for x in cur if DPP.match(x))
                     check_kernel(name, cur, problems)
                 name, cur = m.group(1), []
             elif name is not None:
@@ -132,8 +151,9 @@ def main(lib):
         if name is not None:
             kernels += 1
             stores += sum(1 for x in cur if STORE.match(x))
+            dpps += sum(1 for x in cur if DPP.match(x))
             check_kernel(name, cur, problems)
-    print(f"{kernels} functions, {stores} stores with a scalar base checked, {len(problems)} hazard(s)")
+    print(f"{kernels} functions, {stores} stores with a scalar base checked, {len(problems)} hazard(s); {dpps} DPP reads checked")
     for p in problems[:50]:
         print("  " + p)
     return 1 if problems else 0
