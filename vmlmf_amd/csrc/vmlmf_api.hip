@@ -358,6 +358,11 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
   w->K = K;
   w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
   w->dry = g_wride_dry;
+  if (g_wride_dry & 1) {   // a timing experiment must not pass for a result
+    static bool told = false;
+    if (!told) fprintf(stderr, "vmlmf: VMLMF_WRIDE_DRY=1 - the weight-gradient workers leave at once, parameter gradients are NOT computed\n");
+    told = true;
+  }
 }
 
 static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
