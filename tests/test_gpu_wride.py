@@ -40,8 +40,11 @@ RIDING = [
     (O.V1, 128, 10, 8, 100, 8, [16]),       # just above it: the stand-alone kernel
     (O.V1, 37, 9, 5, 70, 6, [12]),          # odd batch: whole-step chunks, row pairs straddle steps
     (O.V1, 3, 1, 4, 40, 4, [8]),            # one step: the only progress word is the final one
-    (O.V1, 16, 2, 9, 64, 8, [8]),           # shorter than the lag of the progress words
+    (O.V1, 16, 2, 9, 64, 8, [8]),           # too few chunks to ride (fewer than four): the stand-alone kernel
     (O.V1, 16, 5, 9, 64, 8, [8]),
+    (O.V1, 64, 2, 9, 64, 16, [8]),          # rides with fewer steps than the lag of the progress words: only the final word counts
+    (O.V1, 96, 3, 7, 100, 8, [16]),         # as many steps as the lag
+    (O.V1, 64, 4, 9, 180, 16, [16]),
     (O.V2, 32, 12, 9, 180, 16, [16, 16]),   # group cell: two 32-wide tiles of B columns
     (O.V1, 8, 7, 30, 130, 32, [32]),        # rank 32 on both sides
     (O.V3, 24, 6, 24, 24, 24, [8]),         # PTB cell (input size = hidden size), small enough to fold
