@@ -4,8 +4,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "vmlmf_rec_fwd.inc"
-#include "vmlmf_rec_bwd.inc"
+#ifdef VMLMF_STW7
+#define MOVER_THREADS 320
+#else
+#define MOVER_THREADS 128
+#endif
+#include "vmlmf_rec3.inc"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
@@ -18,11 +22,28 @@ float run(const VGeo& g, const FwdArgs& a, const XwArgs& xw, int iters) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a, xw);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + MOVER_THREADS), lds, 0, g, a, xw);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, a, xw);
+    hipLaunchKernelGGL((rec_fwd_kernel<16, 1, false, 256, 3, ABL, XW>), dim3(g.nwg), dim3(g.NT + MOVER_THREADS), lds, 0, g, a, xw);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+template <int ABL>
+float run3(const VGeo& g, const FwdArgs& a, const XwArgs& xw, int iters) {
+  const size_t lds = sizeof(float) * rec3_fwd_lds_floats(g.NT, g.T, 12);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rec3_fwd_kernel<16, 12, ABL>), dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((rec3_fwd_kernel<16, 12, ABL>), dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -37,11 +58,28 @@ float run_bwd(const VGeo& g, const BwdArgs& b, int iters) {
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
   for (int i = 0; i < 3; ++i)
-    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
+    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + MOVER_THREADS), lds, 0, g, b);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
   for (int i = 0; i < iters; ++i)
-    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
+    hipLaunchKernelGGL((rec_bwd_kernel<16, 1, false, 256, 3, ABL>), dim3(g.nwg), dim3(g.NT + MOVER_THREADS), lds, 0, g, b);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  float ms = 0;
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  return ms * 1000.f / iters;
+}
+
+template <int ABL>
+float run3_bwd(const VGeo& g, const BwdArgs& b, int iters) {
+  const size_t lds = sizeof(float) * rec3_bwd_lds_floats(g.NT);
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rec3_bwd_kernel<16, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((rec3_bwd_kernel<16, ABL>), dim3(g.nwg), dim3(g.NT + 128), lds, 0, g, b);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -85,6 +123,32 @@ int main(int argc, char** argv) {
   a.qxw = dalloc((size_t)g.T * g.B * g.KX, 0.f);
   const bool xwave = argc > 1;
   a.xwave = xwave ? 1 : 0;
+  if (argc > 1 && argv[1][0] == '3') {
+    printf("rec3 fwd full                %8.2f us\n", (run3<0>(g, a, xw, 50)));
+    printf("rec3 fwd, no x FMAs          %8.2f us\n", (run3<1>(g, a, xw, 50)));
+    printf("rec3 fwd, storer idle        %8.2f us\n", (run3<2048>(g, a, xw, 50)));
+    printf("rec3 fwd, both               %8.2f us\n", (run3<2049>(g, a, xw, 50)));
+    printf("rec3 fwd, stamps             %8.2f us\n", (run3<256>(g, a, xw, 5)));
+    printf("rec3 fwd, stamps, no x, idle storer %8.2f us\n", (run3<256 + 2049>(g, a, xw, 5)));
+    {
+      float hb[256];
+      CK(hipMemcpy(hb, a.trash, sizeof(hb), hipMemcpyDeviceToHost));
+      const char* nm[7] = {"dpp", "rowsum+write+xload", "wait+barrier", "read+xproj", "sum+readlane+fma", "gates", "outs"};
+      for (int w = 0; w < 3; ++w) { printf("wave %d ticks/step:", w); float tot = 0; for (int i = 0; i < 7; ++i) { printf("  %s %.0f", nm[i], hb[64 + w * 8 + i]); tot += hb[64 + w * 8 + i]; } printf("  total %.0f\n", tot); }
+    }
+    {
+      BwdArgs b = {};
+      b.gates = a.gates, b.cs = a.cs, b.dy = nullptr, b.dhT = a.hT, b.dcT = nullptr;
+      b.VR = dalloc((size_t)4 * 16 * g.NT, 0.2f), b.UE = dalloc((size_t)16 * g.NT, 0.2f), b.EH = a.EH, b.VE = a.VE;
+      b.dpre = dalloc(TS * 4, 0.f), b.dQs = dalloc((size_t)g.T * g.B * 16, 0.f), b.trash = a.trash;
+      printf("rec_bwd  full                %8.2f us\n", run_bwd<0>(g, b, 50));
+      printf("rec3 bwd full                %8.2f us\n", run3_bwd<0>(g, b, 50));
+      printf("rec3 bwd, storer idle        %8.2f us\n", run3_bwd<2048>(g, b, 50));
+      printf("rec3 bwd, loader idle        %8.2f us\n", run3_bwd<4096>(g, b, 50));
+      printf("rec3 bwd, both idle          %8.2f us\n", run3_bwd<6144>(g, b, 50));
+    }
+    return 0;
+  }
   if (xwave) {
     printf("x-wave full                  %8.2f us\n", (run<0, true>(g, a, xw, 50)));
     printf("x-wave, storer: no stores    %8.2f us\n", (run<1024, true>(g, a, xw, 50)));

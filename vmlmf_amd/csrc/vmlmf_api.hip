@@ -99,6 +99,9 @@ int g_rb_mode = []() { const char* e = getenv("VMLMF_RB"); return e ? atoi(e) : 
 int g_rb_minB = env_pos("VMLMF_RB_MINB", 0);
 int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
 int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgroup: 16 / 8 / 4 (0 = automatic)
+// third form of the recurrent kernels (vmlmf_rec3.inc) where it covers the layer: VMLMF_REC3=0 / vmlmf_tune("rec3", 0) keeps
+// rec_fwd_kernel / rec_bwd_kernel (A/B runs); bit 1 = forward, bit 2 = backward
+int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 2; }();
 int g_tune_generation = 0;                        // bumped by every vmlmf_tune(): kept parameter images of an older one are stale
 
 // ---- geometry ----
@@ -588,7 +591,9 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   a.prog = g.training ? reinterpret_cast<unsigned*>(rs + L.r_prog) : nullptr;
   {
     Scope sc(2, s);
-    if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
+    if (xwave && (g_rec3 & 1) && rec3_fwd_supported(g)) {
+      if ((rc = hip_fail(launch_rec3_fwd(g, a, xw, s), "rec3_fwd")) != 0) return rc;
+    } else if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
   }
   return 0;
 }
@@ -701,14 +706,16 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   } else {
   BwdArgs a;
   a.gates = rs + L.r_gates, a.cs = rs + L.r_cs, a.c0 = c0, a.dy = dy, a.dhT = dhT, a.dcT = dcT;
-  a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH;
+  a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH, a.VE = pack + P.VE;
   a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
   a.hd = hb;
   plan_wride(g, L, x, y, h0, rs, ws, &ride);
   a.wr = ride;
   {
     Scope sc(3, s);
-    if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
+    if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
+      if ((rc = hip_fail(launch_rec3_bwd(g, a, s), "rec3_bwd")) != 0) return rc;
+    } else if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
   }
   WgxArgs wx;
   wx.dpre = ws + L.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
@@ -945,13 +952,15 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       BwdArgs b;
       b.gates = rs + Lr.r_gates, b.cs = rs + Lr.r_cs, b.c0 = ly[l].c0, b.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
       b.dhT = ly[l].dhT, b.dcT = ly[l].dcT;
-      b.VR = pack + P.VR, b.UE = pack + P.UE, b.EH = pack + P.EH;
+      b.VR = pack + P.VR, b.UE = pack + P.UE, b.EH = pack + P.EH, b.VE = pack + P.VE;
       b.dpre = wl + Lr.b_dpre, b.dQs = wl + Lr.b_dQs, b.dh0 = ly[l].dh0, b.dc0 = ly[l].dc0, b.trash = wl + Lr.b_trash;
       b.hd = hb;
       memset(&b.wr, 0, sizeof(b.wr));   // (the tape of a stack launch: its progress words are not this path's)
       {
         Scope sc(3, s);
-        if ((rc = hip_fail(launch_rec_bwd(g, b, s), "rec_bwd")) != 0) return rc;
+        if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
+          if ((rc = hip_fail(launch_rec3_bwd(g, b, s), "rec3_bwd")) != 0) return rc;
+        } else if ((rc = hip_fail(launch_rec_bwd(g, b, s), "rec_bwd")) != 0) return rc;
       }
       WgxArgs wx;
       wx.dpre = wl + Lr.b_dpre, wx.VRX = pack + P.VRX, wx.UXO = pack + P.UXO, wx.EXI = pack + P.EXI;
@@ -972,6 +981,7 @@ int vmlmf_tune(const char* key, int value) {
   if (key == nullptr) return fail(VMLMF_E_BADARG, "tune: null key");
   const std::string k(key);
   if (k == "rb") g_rb_mode = value;
+  else if (k == "rec3") g_rec3 = value;
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
   else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;

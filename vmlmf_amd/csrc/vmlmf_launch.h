@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include "vmlmf_device.h"
 
+// launch bounds of rec_fwd_kernel / rec_bwd_kernel.  (VMLMF_STW7, probe builds only: the storer as wave NW + 4, i.e. on the SIMD
+// of the loader / x-projection wave instead of compute wave 0's; measured in tools/microbench/rec_probe.hip: -1.5 us with the
+// loader, +1.8 us with the x-projection wave - not shipped.)
+#ifdef VMLMF_STW7
+#define VG_REC_BOUNDS 512
+#else
+#define VG_REC_BOUNDS (MAXT + 128)
+#endif
+
 // Classifier riding on a layer (Net.lin on the final hidden state, vmlmf.py:345,353-355): logits in the epilogue of the
 // forward recurrence, d(hT) = dlogits W in the prologue of the backward one, dW / db among finish_kernel's outputs.  C = 0: none.
 struct HeadFwd {
@@ -50,6 +59,7 @@ struct WRide {
 };
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
+  const float* VE;   // un-rotated V_h image (the forward's): rec3_bwd_kernel builds its own rotation from it
   float *dpre, *dQs, *dh0, *dc0;
   float* trash;
   HeadBwd hd;   // read from the kernel-argument segment by the prologue only
@@ -105,6 +115,12 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
                  hipStream_t s);
 int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
+// third form of the recurrent kernels (vmlmf_rec3.inc): one-group layers, padded hidden rank <= 16, <= 3 waves of units; the
+// forward also needs the x-projection wave's envelope (narrow input, x-fold).  Same tapes as the kernels above.
+bool rec3_fwd_supported(const VGeo& g);
+bool rec3_bwd_supported(const VGeo& g);
+int launch_rec3_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);
+int launch_rec3_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL
