@@ -34,16 +34,18 @@ float run(const VGeo& g, const FwdArgs& a, const XwArgs& xw, int iters) {
   return ms * 1000.f / iters;
 }
 
-template <int ABL>
+template <int ABL, int XM>
 float run3(const VGeo& g, const FwdArgs& a, const XwArgs& xw, int iters) {
-  const size_t lds = sizeof(float) * rec3_fwd_lds_floats(g.NT, g.T, 12);
+  const size_t lds = sizeof(float) * rec3_fwd_lds_floats_xm(g.NT, g.T, 12, XM);
+  auto kern = rec3_fwd_kernel<16, 12, ABL, XM>;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0));
   CK(hipEventCreate(&e1));
-  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL((rec3_fwd_kernel<16, 12, ABL>), dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(kern, dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL((rec3_fwd_kernel<16, 12, ABL>), dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(kern, dim3(g.nwg), dim3(g.NT + 64), lds, 0, g, a, xw);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms = 0;
@@ -124,18 +126,16 @@ int main(int argc, char** argv) {
   const bool xwave = argc > 1;
   a.xwave = xwave ? 1 : 0;
   if (argc > 1 && argv[1][0] == '3') {
-    printf("rec3 fwd full                %8.2f us\n", (run3<0>(g, a, xw, 50)));
-    printf("rec3 fwd, no x FMAs          %8.2f us\n", (run3<1>(g, a, xw, 50)));
-    printf("rec3 fwd, storer idle        %8.2f us\n", (run3<2048>(g, a, xw, 50)));
-    printf("rec3 fwd, both               %8.2f us\n", (run3<2049>(g, a, xw, 50)));
-    printf("rec3 fwd, stamps             %8.2f us\n", (run3<256>(g, a, xw, 5)));
-    printf("rec3 fwd, stamps, no x, idle storer %8.2f us\n", (run3<256 + 2049>(g, a, xw, 5)));
-    {
-      float hb[256];
-      CK(hipMemcpy(hb, a.trash, sizeof(hb), hipMemcpyDeviceToHost));
-      const char* nm[7] = {"dpp", "rowsum+write+xload", "wait+barrier", "read+xproj", "sum+readlane+fma", "gates", "outs"};
-      for (int w = 0; w < 3; ++w) { printf("wave %d ticks/step:", w); float tot = 0; for (int i = 0; i < 7; ++i) { printf("  %s %.0f", nm[i], hb[64 + w * 8 + i]); tot += hb[64 + w * 8 + i]; } printf("  total %.0f\n", tot); }
-    }
+    printf("rec3 fwd XM0 full            %8.2f us\n", (run3<0, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM0 no x            %8.2f us\n", (run3<1, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM0 storer idle     %8.2f us\n", (run3<2048, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM0 both            %8.2f us\n", (run3<2049, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM1 full            %8.2f us\n", (run3<0, 1>(g, a, xw, 50)));
+    printf("rec3 fwd XM1 no x            %8.2f us\n", (run3<1, 1>(g, a, xw, 50)));
+    printf("rec3 fwd XM1 storer idle     %8.2f us\n", (run3<2048, 1>(g, a, xw, 50)));
+    printf("rec3 fwd XM2 full            %8.2f us\n", (run3<0, 2>(g, a, xw, 50)));
+    printf("rec3 fwd XM2 no x            %8.2f us\n", (run3<1, 2>(g, a, xw, 50)));
+    printf("rec3 fwd XM2 storer idle     %8.2f us\n", (run3<2048, 2>(g, a, xw, 50)));
     {
       BwdArgs b = {};
       b.gates = a.gates, b.cs = a.cs, b.dy = nullptr, b.dhT = a.hT, b.dcT = nullptr;
