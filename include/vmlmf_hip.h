@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 7
+#define VMLMF_ABI_VERSION 8
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -34,6 +34,11 @@ extern "C" {
 #define VMLMF_E_UNSUPPORTED (-3) /* valid for the reference, not yet covered by the HIP kernels       */
 #define VMLMF_E_WORKSPACE (-4)   /* workspace / reserve smaller than vmlmf_query() asked for          */
 #define VMLMF_E_COMM (-5)        /* RCCL reported an error (text in vmlmf_last_error())                */
+#define VMLMF_E_PROTOCOL (-6)    /* ABI 8: a launch gave up a bounded wait for another workgroup (riding weight-gradient workers,
+                                  * row-block clusters, wavefront hand-overs).  Its results are NaN (never a plausible wrong
+                                  * number); nothing in the launch hangs.  Launches are asynchronous, so the code comes back from
+                                  * the NEXT forward / backward / stack call on the device (from the failing call itself under
+                                  * VMLMF_DEBUG_SYNC=1), or from vmlmf_check_status() once the stream has been synchronised.   */
 
 /* One layer's problem description.  x is (T,B,I) when time_major else (B,T,I); y likewise with H. */
 typedef struct vmlmf_desc {
@@ -106,6 +111,10 @@ const char *vmlmf_last_error(void);
  *                   = more workgroups, each streaming fewer tape bytes through its CU
  */
 int vmlmf_tune(const char *key, int value);
+
+/* ABI 8.  0, or VMLMF_E_PROTOCOL when a launch that has already run on the current device gave up a bounded wait (text in
+ * vmlmf_last_error(); the condition is cleared).  Host only: reads a status word in mapped host memory, no GPU call. */
+int vmlmf_check_status(void);
 
 /* Validate `d` and report buffer sizes + launch geometry.  Host only, no GPU call. */
 int vmlmf_query(const vmlmf_desc *d, vmlmf_sizes *out);

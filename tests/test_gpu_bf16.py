@@ -116,8 +116,9 @@ def test_bf16_variant_within_the_derived_tolerance(case):
 def test_config_c_two_layers_bf16_vs_reference_golden():
     """BASELINE configs[2]: OPP shape, 2 layers x 256, rank 24, B 128, T 24, through MyLSTM with the bf16 variant, against the
     imported reference's fp32 vectors (tests/golden/cfgC_v1_opp2.npz).  Two stacked layers compound the per-layer error, so
-    the golden check uses whole-configuration bounds: y and hT within 2^-6 of their scale, every gradient within 3 % of its
-    largest entry (the per-layer, oracle-derived bound is the parametrised test above)."""
+    the golden check uses whole-configuration bounds set at twice what the kernels measure on this configuration (round 3, MI355X:
+    y 1.9e-3, hT 2.8e-3 of scale; gradients 2.1e-3 ... 5.9e-3 of their largest entry): outputs within 6e-3 of their scale, every
+    gradient within 1.2e-2 of its largest entry (the per-layer, oracle-derived bound is the parametrised test above)."""
     from vmlmf_amd import MyLSTM, MyVMLMFCell, set_compute_dtype
     d = load_golden("cfgC_v1_opp2")
     _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
@@ -139,12 +140,12 @@ def test_config_c_two_layers_bf16_vs_reference_golden():
         print(f"config C bf16 {what}: err {err:.3e} = {err / scale:.2e} of scale")
         assert np.all(np.isfinite(a)) and err <= frac * scale, (what, err, scale)
 
-    close(y.detach().cpu().numpy()[:, ::6], d["y_s"], 2.0 ** -6, "y")
-    close(hcat.detach().cpu().numpy(), d["hT"], 2.0 ** -6, "hT")
-    close(x.grad.cpu().numpy()[::4], d["dx_s"], 0.03, "dx")
+    close(y.detach().cpu().numpy()[:, ::6], d["y_s"], 6e-3, "y")
+    close(hcat.detach().cpu().numpy(), d["hT"], 6e-3, "hT")
+    close(x.grad.cpu().numpy()[::4], d["dx_s"], 1.2e-2, "dx")
     for li, G in ((0, d["G0"]), (1, d["G1"])):
         for k, v in G.items():
-            close(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, 0.03, f"layer{li}.{k}")
+            close(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, 1.2e-2, f"layer{li}.{k}")
 
 
 def test_bf16_is_refused_where_it_is_not_implemented():

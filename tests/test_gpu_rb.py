@@ -135,6 +135,64 @@ def test_config_e_at_batch_256_vs_oracle():
     compare_all(got, ref, "E.B256")
 
 
+def test_config_e_two_layers_at_its_own_size_vs_oracle():
+    """configs[4] exactly as bench.py times it: TWO chained MyVMLSTMGroup layers (vmlmf_lm.py:53-174 under the layer loop of
+    vmlmf_lm.py:437-439), B = 256, T = 35, H = 650, ranks 32 / [32, 32], states carried in and gradients into both layers'
+    final states - against the literal fp64 restatement with v4_scratch_rows = 256 (the reference itself only executes
+    B = 40).  About a minute of host time: the oracle replays 2 x 35 cell steps at batch 256 in fp64."""
+    from vmlmf_amd import vmlmf_sequence
+    from hip_util import ORDER
+    variant, B, T, H, rw, ru, L = O.V4, 256, 35, 650, 32, [32, 32], 2
+    assert uses_rb(variant, B, T, H, H, rw, ru, True)[0]
+    Ps = [O.make_params(variant, H, H, rw, ru, seed=21 + l, scale=0.05) for l in range(L)]
+    r = np.random.Generator(np.random.PCG64(35))
+    x = (0.05 * r.standard_normal((T, B, H))).astype(np.float32)
+    h0 = (0.3 * r.standard_normal((L, B, H))).astype(np.float32)
+    c0 = (0.3 * r.standard_normal((L, B, H))).astype(np.float32)
+    dy = r.standard_normal((T, B, H)).astype(np.float32)
+    dhT = r.standard_normal((L, B, H)).astype(np.float32)
+    dcT = r.standard_normal((L, B, H)).astype(np.float32)
+    names = ORDER[variant]
+    # ---- HIP: the two layers chained through autograd, as Model.forward does
+    dev = "cuda"
+    params = [[torch.tensor(np.asarray(P[k]), device=dev).requires_grad_(True) for k in names] for P in Ps]
+    xg = torch.tensor(x, device=dev).requires_grad_(True)
+    h0g = torch.tensor(h0, device=dev).requires_grad_(True)
+    c0g = torch.tensor(c0, device=dev).requires_grad_(True)
+    cur, loss = xg, 0.0
+    outs = []
+    for l in range(L):
+        cur, hT, cT = vmlmf_sequence(variant, cur, h0g[l], c0g[l], params[l], rw, ru, g=2, time_major=True)
+        outs.append((hT, cT))
+        loss = loss + (hT * torch.tensor(dhT[l], device=dev)).sum() + (cT * torch.tensor(dcT[l], device=dev)).sum()
+    loss = loss + (cur * torch.tensor(dy, device=dev)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    # ---- oracle, fp64
+    Pt = [O.to_torch(P, dtype=torch.float64, requires_grad=True) for P in Ps]
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    h0t = torch.tensor(h0, dtype=torch.float64, requires_grad=True)
+    c0t = torch.tensor(c0, dtype=torch.float64, requires_grad=True)
+    curr, lossr = xt, 0.0
+    outr = []
+    for l in range(L):
+        curr, hT, cT = O.literal_sequence(variant, Pt[l], curr, h0t[l], c0t[l], time_major=True, v4_scratch_rows=B)
+        outr.append((hT, cT))
+        lossr = lossr + (hT * torch.tensor(dhT[l], dtype=torch.float64)).sum() + (cT * torch.tensor(dcT[l], dtype=torch.float64)).sum()
+    lossr = lossr + (curr * torch.tensor(dy, dtype=torch.float64)).sum()
+    lossr.backward()
+    assert_out(cur.detach().cpu().numpy(), curr.detach().numpy(), "y")
+    for l in range(L):
+        assert_out(outs[l][0].detach().cpu().numpy(), outr[l][0].detach().numpy(), f"hT[{l}]")
+        assert_out(outs[l][1].detach().cpu().numpy(), outr[l][1].detach().numpy(), f"cT[{l}]")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "dx")
+    assert_grad(h0g.grad.cpu().numpy(), h0t.grad.numpy(), "dh0")
+    assert_grad(c0g.grad.cpu().numpy(), c0t.grad.numpy(), "dc0")
+    for l in range(L):
+        for k, p_ in zip(names, params[l]):
+            assert_grad(p_.grad.cpu().numpy(), Pt[l][k].grad.numpy(), f"layer {l} {k}")
+
+
 def test_row_block_and_valu_kernels_agree_at_large_batch():
     """B = 1024, T = 16 at the UCI layer: both kernel families against each other (they sum in different orders)."""
     P = O.make_params(O.V1, 9, 180, 16, 16, seed=3)

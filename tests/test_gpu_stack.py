@@ -353,7 +353,7 @@ def test_stack_backward_switch_chains_the_per_layer_kernels():
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6
 
 
-@pytest.mark.parametrize("variant_name,time_major", [("V1", False), ("V3", True), ("V5", False)])
+@pytest.mark.parametrize("variant_name,time_major", [("V1", False), ("V3", True), ("V5", False), ("V2", False), ("V6", False)])
 def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_major):
     """The stack entry points with everything the per-layer calls take - initial states of every layer, gradients into
     every layer's final states, gradients of the initial states - against the literal fp64 restatement of the reference
@@ -366,6 +366,9 @@ def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_ma
     from vmlmf_amd import functional as F
     variant = getattr(O, variant_name)
     L, B, T, I, H, rw, ru = 3, 6, 7, (48 if variant_name == "V3" else 20), 48, 13, 10
+    grouped = variant_name in ("V2", "V6")   # the group cells (vmlmf_group.py:85-155 / 158-251): two groups, ranks per shift
+    if grouped:
+        ru = [6, 5]
     rng = np.random.Generator(np.random.PCG64(77))
     Ps = [O.make_params(variant, I if l == 0 else H, H, rw, ru, seed=3 + l) for l in range(L)]
     shp = (T, B, I) if time_major else (B, T, I)
@@ -396,7 +399,7 @@ def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_ma
     c0g = torch.tensor(c0, device="cuda").requires_grad_(True)
     os.environ["VMLMF_STACK"] = "1"
     try:
-        out = F.vmlmf_stack(variant, xg, params, rw, [ru], g=1, time_major=time_major, h0=h0g, c0=c0g)
+        out = F.vmlmf_stack(variant, xg, params, rw, ru if grouped else [ru], g=2 if grouped else 1, time_major=time_major, h0=h0g, c0=c0g)
     finally:
         os.environ.pop("VMLMF_STACK", None)
     assert out is not None
@@ -416,3 +419,50 @@ def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_ma
     for l in range(L):
         for k, p in zip(names, params[l]):
             assert_grad(p.grad.cpu().numpy(), Pt[l][k].grad.numpy(), f"layer {l} {k}")
+
+
+@pytest.mark.parametrize("cell_name,variant_name", [("MyVMLMFCellg2", "V2"), ("MyVMLMFCell", "V1")])
+def test_reference_demo_shapes_through_mylstm_on_the_default_path_against_the_fp64_oracle(cell_name, variant_name):
+    """script/demo.sh's two models (1 x 180, w_rank 8, u_ranks [2, 4] for the group cell / 6 for the plain one, batch 81, 24 steps,
+    77 inputs) through MyLSTM with the default launch policy (VMLMF_STACK unset = auto: a single layer with a wide input takes
+    the wavefront launch) against the literal fp64 restatement of vmlmf_group.py:85-155 / vmlmf.py:78-125 under the loop of
+    vmlmf.py:300-314: outputs, input gradient, every parameter gradient."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "oracle"), here]
+    import vmlmf_oracle as O
+    import vmlmf_amd
+    from hip_util import ORDER, assert_grad, assert_out
+    from vmlmf_amd import functional as F
+    variant = getattr(O, variant_name)
+    B, T, I, H, rw = 81, 24, 77, 180, 8
+    ru = [2, 4] if variant_name == "V2" else 6
+    assert os.environ.get("VMLMF_STACK") is None
+    torch.manual_seed(3)
+    model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=[H], batch_first=True, w_rank=rw, u_ranks=ru, cell=getattr(vmlmf_amd, cell_name)).cuda()
+    cell = model.rnncells[0]
+    named = dict(cell.named_parameters())
+    P = {}
+    for k in ORDER[variant]:
+        key = ("layers." + k) if ("layers." + k) in named else k
+        P[k] = named[key].detach().cpu().numpy()
+    rng = np.random.Generator(np.random.PCG64(81))
+    x = rng.standard_normal((B, T, I)).astype(np.float32)
+    dy = rng.standard_normal((B, T, H)).astype(np.float32)
+    cfg = cell.kernel_cfg()
+    ur = tuple(ru) if isinstance(ru, list) else (ru,)
+    assert F._stack_plan((cfg["variant"], cfg["g"], rw, ur, False, 0), 1, B, T, I, H, True) is not None, "auto must pick the wavefront launch here"
+    xg = torch.tensor(x, device="cuda").requires_grad_(True)
+    y, hid = model(xg)
+    (y * torch.tensor(dy, device="cuda")).sum().backward()
+    torch.cuda.synchronize()
+    Pt = O.to_torch(P, dtype=torch.float64, requires_grad=True)
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    yr, hT, cT = O.literal_sequence(variant, Pt, xt, None, None, time_major=False)
+    (yr * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    assert_out(y.detach().cpu().numpy(), yr.detach().numpy(), "y")
+    assert_out(hid.detach().cpu().numpy(), hT.detach().numpy(), "hidden")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "dx")
+    for k in ORDER[variant]:
+        key = ("layers." + k) if ("layers." + k) in named else k
+        assert_grad(named[key].grad.cpu().numpy(), Pt[k].grad.numpy(), k)

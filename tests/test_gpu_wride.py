@@ -188,3 +188,43 @@ def test_switches_of_the_riding_workers(env):
         "print('ok')\n") % (ROOT, os.path.join(ROOT, "oracle"), HERE)
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_worker_that_gives_up_surfaces_as_an_error_code_not_only_as_nan():
+    """Failure path of the riding workers (verdict r2: "in-kernel protocol failures are silent").  With the number of looks a
+    worker takes at the rows' progress words cut to one (vmlmf_tune("test_wride_spin", 1): the rows need ~0.4 us a step, so
+    the first chunk is never there at the first look) the workers give up: the parameter gradients are NaN - never a
+    plausible wrong number - the launch ends, and the library reports VMLMF_E_PROTOCOL: from vmlmf_check_status() once the
+    stream is synchronised, and from the next forward / backward call on the device.  Afterwards the same call works again."""
+    from vmlmf_amd import _lib
+    variant, B, T, I, H, rw, ru = O.V1, 64, 40, 9, 180, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=5)
+    good = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    _lib.check_status()                                  # nothing pending
+    _lib.tune("test_wride_spin", 1)
+    try:
+        bad = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)   # returns normally: launches are asynchronous
+        torch.cuda.synchronize()
+        assert not np.all(np.isfinite(bad["G"]["v_h"])), "the workers were expected to give up"
+        # outputs and the input / state gradients do not come from the workers
+        assert np.array_equal(bad["y"], good["y"]) and np.array_equal(bad["dx"], good["dx"])
+        with pytest.raises(_lib.VmlmfError) as ei:
+            _lib.check_status()
+        assert ei.value.code == _lib.E_PROTOCOL and "progress words" in str(ei.value)
+        _lib.check_status()                              # reported once, then cleared
+        # ... and unsynchronised, the NEXT call on the device is the one that fails
+        run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError) as ei:     # (_lib.VmlmfError through ctypes, c10::Error through the C++ binding)
+            run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+        assert "error -6" in str(ei.value) and "progress words" in str(ei.value)
+    finally:
+        _lib.tune("test_wride_spin", 0)
+        torch.cuda.synchronize()
+        try:
+            _lib.check_status()
+        except _lib.VmlmfError:
+            pass
+    again = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    for k in good["G"]:
+        assert np.array_equal(again["G"][k], good["G"][k]), k

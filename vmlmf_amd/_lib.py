@@ -18,10 +18,10 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
-E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM = -1, -2, -3, -4, -5
+E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM, E_PROTOCOL = -1, -2, -3, -4, -5, -6
 SUM, AVG = 0, 1
 COMM_ID_BYTES = 128
 
@@ -82,6 +82,7 @@ SYMBOLS = {
     "vmlmf_build_info": (ctypes.c_char_p, []),
     "vmlmf_last_error": (ctypes.c_char_p, []),
     "vmlmf_tune": (_i, [ctypes.c_char_p, _i]),
+    "vmlmf_check_status": (_i, []),
     "vmlmf_stack_query": (_i, [_i, _vp, _vp, _vp]),
     "vmlmf_stack_forward": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vmlmf_stack_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -166,6 +167,12 @@ def tune(key, value):
     check(lib().vmlmf_tune(key.encode(), int(value)))
     from . import functional
     functional._DESC_CACHE.clear()
+
+
+def check_status():
+    """Raises VmlmfError(E_PROTOCOL) if a launch that already ran on the current device gave up a bounded wait for another
+    workgroup (its results are NaN); call after a synchronisation to learn about the launches before it."""
+    check(lib().vmlmf_check_status())
 
 
 def check(rc):

@@ -61,6 +61,66 @@ struct Scope {
 
 long long align64(long long v) { return (v + 63) / 64 * 64; }
 
+// ---- protocol failures inside a launch ----
+// The riding weight-gradient workers, the clusters of the row-block kernels and the wavefront hand-overs all wait for other
+// workgroups with a bounded number of looks; a wait that gives up leaves NaN in the results (never a plausible wrong number)
+// and a code in a status word.  The word lives in host memory mapped into the device (one per device, allocated at the first
+// call): the kernel's store costs nothing unless it happens, and the host reads it without a copy or a synchronisation.
+// Every forward / backward entry point looks at it first: a failure of an EARLIER launch on the device comes back as
+// VMLMF_E_PROTOCOL from the next call (under VMLMF_DEBUG_SYNC from the failing call itself); vmlmf_check_status() after a
+// synchronisation tells at once.
+constexpr int MAX_DEV = 16;
+unsigned* g_status[MAX_DEV] = {nullptr};
+bool g_status_tried[MAX_DEV] = {false};
+std::mutex g_status_mu;
+
+unsigned* status_word() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (g_status[dev] != nullptr || g_status_tried[dev]) return g_status[dev];
+  std::lock_guard<std::mutex> lk(g_status_mu);
+  if (g_status[dev] == nullptr && !g_status_tried[dev]) {
+    g_status_tried[dev] = true;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    void* p = nullptr;
+    // (not from inside a stream capture: the allocation is not capturable; such a process simply runs without the word)
+    if (hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone &&
+        hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p != nullptr) {
+      memset(p, 0, 64);
+      g_status[dev] = (unsigned*)p;
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  return g_status[dev];
+}
+
+const char* status_text(unsigned code) {
+  switch (code) {
+    case VMLMF_ST_WRIDE: return "a weight-gradient worker riding on the backward launch never saw its rows' progress words (parameter gradients of that call are NaN)";
+    case VMLMF_ST_CLUSTER: return "a member of a row-block cluster never published its partial (outputs of that call are NaN)";
+    case VMLMF_ST_WF_FWD: return "a layer of a wavefront forward launch never received the rows of the layer below (outputs are NaN)";
+    case VMLMF_ST_WF_BWD: return "a layer of a wavefront backward launch never received the gradient rows of the layer above (gradients are NaN)";
+  }
+  return "unknown status code";
+}
+
+// 0, or VMLMF_E_PROTOCOL with the text of the failure an earlier launch on this device reported (the word is cleared)
+int take_status() {
+  unsigned* w = status_word();
+  if (w == nullptr) return 0;
+  const unsigned code = *(volatile unsigned*)w;
+  if (code == 0) return 0;
+  *(volatile unsigned*)w = 0;
+  return fail(VMLMF_E_PROTOCOL, std::string("an earlier launch on this device gave up a bounded wait: ") + status_text(code));
+}
+// at the end of an entry point under VMLMF_DEBUG_SYNC: the failure of THIS call
+int debug_status(hipStream_t s) {
+  if (!g_debug_sync) return 0;
+  (void)hipStreamSynchronize(s);
+  return take_status();
+}
+
 const bool g_xwave = []() {
   const char* e = getenv("VMLMF_XWAVE");
   return e == nullptr || e[0] != '0';
@@ -88,7 +148,25 @@ const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 96);   // measured at H = 1
 const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
 const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
 // experiments (bits): 1 = the workers leave at once, 2 = a progress word every step
+#ifdef VMLMF_EXPERIMENTS   // (builds with -DVMLMF_EXPERIMENTS only: a switch that yields wrong results is not in the product library)
 const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);
+#else
+const int g_wride_dry = 0;
+#endif
+// looks a riding worker takes at the progress words before it gives up; vmlmf_tune("test_wride_spin", n) shortens it so that
+// tests can provoke the failure path (NaN gradients + VMLMF_E_PROTOCOL) on purpose
+int g_wride_spin = 1 << 16;
+int g_cus[MAX_DEV] = {0};   // compute units of the device (hipDeviceProp_t::multiProcessorCount), looked up once
+int device_cus() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return 256;
+  if (g_cus[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    g_cus[dev] = n;
+  }
+  return g_cus[dev];
+}
 
 // Row-block MFMA kernels (vmlmf_rb.hip): -1 = automatic (large batches, and layers beyond the register-resident VALU kernels),
 // 0 = never, 1 = wherever an instantiation exists.  VMLMF_RB in the environment, or vmlmf_tune("rb", v) at run time.
@@ -355,12 +433,16 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
   w->ntg = (w->tasks + wpw - 1) / wpw;
   // every workgroup of the launch has a CU of its own (the launch asks for more than half a CU's LDS): rows + workers must
   // fit the chip at once, or the workers behind the last CU would only start when the others have finished
-  const int room = (248 - g.nwg) / w->ntg;
+  // (the CU count of THIS device, less a margin of eight for whatever else is resident: on a partitioned or masked device a
+  // fixed 248 would queue workers behind the rows, and a queued worker can only give up)
+  const int room = (device_cus() - 8 - g.nwg) / w->ntg;
   K = K < room ? K : room;
   if (K < 4) return;
   w->K = K;
   w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
   w->dry = g_wride_dry;
+  w->spin = (unsigned)g_wride_spin;
+  w->status = status_word();
   if (g_wride_dry & 1) {   // a timing experiment must not pass for a result
     static bool told = false;
     if (!told) fprintf(stderr, "vmlmf: VMLMF_WRIDE_DRY=1 - the weight-gradient workers leave at once, parameter gradients are NOT computed\n");
@@ -495,8 +577,9 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   const vmlmf_head* head = (ex != nullptr && ex->head != nullptr && ex->head->classes != 0) ? ex->head : nullptr;
   VGeo g;
   RbGeo q;
-  int rc = make_geo(d, &g, &q);
+  int rc = take_status();
   if (rc != 0) return rc;
+  if ((rc = make_geo(d, &g, &q)) != 0) return rc;
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "null x / y / workspace");
   if (g.training && reserve == nullptr) return fail(VMLMF_E_BADARG, "training forward needs a reserve buffer");
@@ -540,7 +623,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     io.gx = gx, io.EH = pack + P.EH, io.h0 = h0, io.c0 = c0, io.img = pack + P.RB, io.y = y, io.hT = hT, io.cT = cT;
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
-    io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag);
+    io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word();
     {
       Scope sc(2, s);
       if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
@@ -595,7 +678,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
       if ((rc = hip_fail(launch_rec3_fwd(g, a, xw, s), "rec3_fwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
   }
-  return 0;
+  return debug_status(s);
 }
 
 int vmlmf_seq_backward(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
@@ -625,8 +708,9 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   const vmlmf_head* head = (ex != nullptr && ex->head != nullptr && ex->head->classes != 0) ? ex->head : nullptr;
   VGeo g;
   RbGeo q;
-  int rc = make_geo(d, &g, &q);
+  int rc = take_status();
   if (rc != 0) return rc;
+  if ((rc = make_geo(d, &g, &q)) != 0) return rc;
   if ((rc = check_params(g, p)) != 0) return rc;
   if (x == nullptr || y == nullptr || reserve == nullptr || workspace == nullptr || gr == nullptr)
     return fail(VMLMF_E_BADARG, "null x / y / reserve / workspace / grads");
@@ -669,7 +753,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     memset(&io, 0, sizeof(io));
     io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
     io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
-    io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag);
+    io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word();
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
@@ -725,7 +809,8 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  return backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride);
+  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride)) != 0) return rc;
+  return debug_status(s);
 }
 
 
@@ -797,8 +882,9 @@ int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_by
 int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, const vmlmf_head* head_in, void* workspace,
                         size_t workspace_bytes, void* stream) {
   StackPlan S;
-  int rc = stack_plan(L, ly, &S);
+  int rc = take_status();
   if (rc != 0) return rc;
+  if ((rc = stack_plan(L, ly, &S)) != 0) return rc;
   if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
   const vmlmf_head* head = (head_in != nullptr && head_in->classes != 0) ? head_in : nullptr;
   if ((rc = check_head(S.g[L - 1], head, true)) != 0) return rc;
@@ -808,7 +894,7 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
   const bool training = S.g[0].training != 0;
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L;
+  a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L, a.c.status = status_word();
   if (head != nullptr) a.hd.W = head->weight, a.hd.bias = head->bias, a.hd.logits = head->logits, a.hd.C = head->classes;
   RefP rps[WF_MAXL];
   float* packs[WF_MAXL];
@@ -850,8 +936,9 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
 int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, const float* dy, float* dx,
                          const vmlmf_head* head_in, void* workspace, size_t workspace_bytes, void* stream) {
   StackPlan S;
-  int rc = stack_plan(L, ly, &S);
+  int rc = take_status();
   if (rc != 0) return rc;
+  if ((rc = stack_plan(L, ly, &S)) != 0) return rc;
   if (x == nullptr || workspace == nullptr) return fail(VMLMF_E_BADARG, "stack: null x / workspace");
   const vmlmf_head* head = (head_in != nullptr && head_in->classes != 0) ? head_in : nullptr;
   if ((rc = check_head(S.g[L - 1], head, false)) != 0) return rc;
@@ -877,7 +964,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
   if (wave) {
     WfBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L;   // cleared by the forward
+    a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L, a.c.status = status_word();   // cleared by the forward
     a.hd = hb_top;
     for (int l = 0; l < L; ++l) {
       const VGeo& g = S.g[l];
@@ -977,11 +1064,14 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
 
 int vmlmf_tune_generation(void) { return g_tune_generation; }
 
+int vmlmf_check_status(void) { return take_status(); }
+
 int vmlmf_tune(const char* key, int value) {
   if (key == nullptr) return fail(VMLMF_E_BADARG, "tune: null key");
   const std::string k(key);
   if (k == "rb") g_rb_mode = value;
   else if (k == "rec3") g_rec3 = value;
+  else if (k == "test_wride_spin") g_wride_spin = value < 1 ? (1 << 16) : value;
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
   else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;

@@ -50,12 +50,20 @@ struct AtbArgs {
 // ntg workgroups per worker index; prog = one progress word per batch row (zero between launches)
 constexpr int WR_PROG_STRIDE = 32;   // unsigned words between two rows' progress words: one 128-byte line each (written through
                                      // every other step by 64+ workgroups: words sharing a line serialise at the memory side)
+// codes a kernel leaves in the host-visible status word when one of its bounded waits gives up (the results are NaN then); the
+// next C-ABI call on the device returns VMLMF_E_PROTOCOL (vmlmf_api.hip: take_status)
+constexpr unsigned VMLMF_ST_WRIDE = 1, VMLMF_ST_CLUSTER = 2, VMLMF_ST_WF_FWD = 3, VMLMF_ST_WF_BWD = 4;
+__device__ __forceinline__ void vg_raise(unsigned* status, unsigned code) {
+  if (status != nullptr) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 struct WRide {
   AtbArgs a;
   unsigned* prog;
   int K, S, ntg, tasks;
-  int lag, dry;   // lag: segments a progress word trails the stores it covers; dry: the workers leave at once (timing experiments)
-                  // dry bit 1: a progress word every segment instead of every other one
+  int lag, dry;   // lag: segments a progress word trails the stores it covers; dry (VMLMF_EXPERIMENTS builds only): the workers leave
+                  // at once (timing experiments); dry bit 1: a progress word every segment instead of every other one
+  unsigned spin;  // looks at the progress words before a worker gives up (WR_SPIN; vmlmf_tune("test_wride_spin") shortens it)
+  unsigned* status;   // host-visible status word (vmlmf_api.hip): VMLMF_ST_WRIDE is stored there when a worker gives up
 };
 struct BwdArgs {
   const float *gates, *cs, *c0, *dy, *dhT, *dcT, *VR, *UE, *EH;
@@ -101,6 +109,7 @@ struct RbIo {
   float *y, *hT, *cT, *gates, *cs, *Qs, *dpre, *dQs, *dh0, *dc0;
   float* xq;        // cluster exchange tiles (S > 1)
   unsigned* flag;   // cluster epoch words + error word
+  unsigned* status; // host-visible status word (or NULL)
 };
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
 bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
@@ -177,6 +186,7 @@ struct WfBwdLayer {
 };
 struct WfCommon {
   unsigned* flag;                   // [L - 1][B][WF_FLAG_STRIDE] progress words, then the error word
+  unsigned* status;                 // host-visible status word (or NULL)
   int L, pad;
 };
 struct WfFwdArgs {
