@@ -82,8 +82,27 @@ def spawn_ranks(n, argv):
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; without it RCCL's intra-node transport
+    # fails at hipIpcGetMemHandle (the image exports it already; it is only defaulted here, never overridden)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    import signal
+    import threading
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, start_new_session=True)
+    # a rank that hangs (a collective one rank never entered) must not hang the caller: after `limit` seconds the whole
+    # process group of the children is killed and the run fails
+    limit = float(os.environ.get("VMLMF_BENCH_RANK_TIMEOUT", "1500"))
+    timed_out = []
+
+    def reap():
+        timed_out.append(True)
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)
+        except OSError:
+            pass
+
+    timer = threading.Timer(limit, reap)
+    timer.daemon = True
+    timer.start()
     line = None
     for out in proc.stdout:
         if out.startswith("{") and '"metric"' in out:
@@ -91,6 +110,10 @@ def spawn_ranks(n, argv):
         else:
             sys.stderr.write(out)
     rc = proc.wait()
+    timer.cancel()
+    if timed_out:
+        print(f"[bench] the ranks did not finish within {limit:.0f} s: killed", file=sys.stderr)
+        return 3
     if rc == 0 and line is None:
         print("[bench] the ranks finished without a result line", file=sys.stderr)
         rc = 1
@@ -145,7 +168,16 @@ def cpu_baseline(budget_s=30.0):
             times.append(one())
         results[nt] = float(np.median(times))
     best = min(results, key=results.get)
-    return {"value": T / results[best], "unit": "RNN timesteps/s", "cores": best, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                cpu_model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": T / results[best], "unit": "RNN timesteps/s", "cores": best, "kind": "port", "cpu_model": cpu_model,
+            "host_cores_usable": cores,
             "sample": f"full steps of the bench workload (B={B_PER_GPU} T={T} I={I} H={H} r={RU}), 3 warm-up + 5-9 "
                       f"timed per thread count, median; s/step by threads: "
                       + ", ".join(f"{k}: {v:.3f}" for k, v in results.items())
@@ -241,12 +273,17 @@ def main():
     ap.add_argument("--graph-collective", action="store_true", help="capture the gradient all-reduce inside the hipGraph too")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
     ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
-    ap.add_argument("--repack", action="store_true",
-                    help="pack the parameters on every forward (default: kept images while the parameters are unchanged)")
+    ap.add_argument("--repack", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--keep-images", action="store_true",
+                    help="value = the step with kept parameter images (no pack_kernel while the parameters are unchanged: "
+                         "inference / gradient accumulation; a training loop re-packs every step, which is the default)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many rows in total, split contiguously over the ranks (configs[3]: 512)")
-    ap.add_argument("--transport", choices=("cabi", "torch"), default="cabi",
-                    help="gradient all-reduce through the C ABI (vmlmf_flat_allreduce_group, RCCL) or torch.distributed")
+    ap.add_argument("--transport", choices=("auto", "cabi", "torch"), default="auto",
+                    help="gradient all-reduce through the C ABI (vmlmf_flat_allreduce_group, RCCL) or torch.distributed "
+                         "(backend nccl = RCCL).  auto: torch.distributed with more than one rank (the C-ABI communicator has "
+                         "only ever run in a group of one: no multi-GPU box was available to the builder), the C ABI in the "
+                         "one-rank self-test of --force-collective")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
@@ -274,9 +311,11 @@ def main():
     # --force-collective: run the gradient all-reduce (RCCL) even on one GPU, to exercise the N > 1 code path
     collective = world > 1 or args.force_collective
     if collective:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        # a bounded timeout: a rank that never joins a collective makes the others fail instead of waiting for ever
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
 
     from vmlmf_amd import MyLSTM, MyVMLMFCell, Net, _lib
     from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters
@@ -297,9 +336,10 @@ def main():
     # values every forward (pack_kernel, 6 us).  --repack measures the step with the packing in it; train_step_ms
     # (optimizer inside the graph) re-packs every step by construction.
     import vmlmf_amd as _pkg
-    if not args.repack:
+    if args.keep_images:
         _pkg.cache_packed_parameters(net, True)
-    reducer = FlatGradAllReduce(net.parameters(), op="avg", transport=args.transport if collective else "torch")
+    transport = args.transport if args.transport != "auto" else ("cabi" if world == 1 else "torch")
+    reducer = FlatGradAllReduce(net.parameters(), op="avg", transport=transport if collective else "torch")
     reducer.always = args.force_collective
     lib = _lib.lib()
 
@@ -427,6 +467,89 @@ def main():
             launch_mode = "hipgraph" + ("+allreduce" if reduce_in_graph else "")
             dt = dt_graph
 
+    # ---- outside the metric: the same K steps with kept parameter images (pack_kernel leaves the step: what inference or
+    # gradient accumulation sees), or - under --keep-images - with the packing inside
+    alt_ms = None
+    if launch_mode.startswith("hipgraph"):
+        try:
+            _pkg.cache_packed_parameters(net, not args.keep_images)
+            for _ in range(3):
+                fwd_bwd()
+            agraph, _ = capture(fwd_bwd)
+
+            def astep():
+                agraph.replay()
+                if collective and not reduce_in_graph:
+                    reducer.reduce()
+
+            for _ in range(args.warmup):
+                astep()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                astep()
+            barrier()
+            ta = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            if collective:
+                dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+            alt_ms = float(ta.item()) / args.steps * 1e3
+            del agraph
+        except Exception as e:
+            log(f"alternate parameter-image mode failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
+        finally:
+            _pkg.cache_packed_parameters(net, args.keep_images)
+            for _ in range(2):
+                fwd_bwd()
+            torch.cuda.synchronize()
+
+    # ---- outside the metric, N > 1: the OTHER scaling mode in the same run (weak run: global batch 512 split over the ranks =
+    # BASELINE configs[3]; strong run: 64 rows per GPU), K graph-replayed steps each, MAX over ranks
+    other_mode = None
+    if world > 1 and launch_mode.startswith("hipgraph"):
+        try:
+            o_strong = not strong
+            o_global = 512 if o_strong else None
+            if o_strong and 512 % world != 0:
+                raise ValueError("512 rows do not split evenly")
+            o_rows = 512 // world if o_strong else B_PER_GPU
+            xo_np, to_np = synthetic_batch(rank, o_rows, o_global)
+            xo, to = torch.tensor(xo_np, device=dev), torch.tensor(to_np, device=dev)
+
+            def fb_other():
+                net.zero_grad(set_to_none=True)
+                lo = criterion(net(xo), to)
+                lo.backward(one)
+                return lo
+
+            for _ in range(5):
+                fb_other()
+                reducer.reduce()
+            ograph, _ = capture(fb_other)
+            for _ in range(args.warmup):
+                ograph.replay()
+                reducer.reduce()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                ograph.replay()
+                reducer.reduce()
+            barrier()
+            to_ = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+            dist.all_reduce(to_, op=dist.ReduceOp.MAX)
+            o_dt = float(to_.item())
+            o_batches = (512 / B_PER_GPU) if o_strong else world
+            other_mode = {"scaling": "strong" if o_strong else "weak", "global_batch": o_rows * world, "batch_per_gpu": o_rows,
+                          "ms_per_step": round(o_dt / args.steps * 1e3, 4), "value": round(o_batches * T * args.steps / o_dt, 1),
+                          "unit": "RNN timesteps/s (64-row batches x T per second)"}
+            del ograph
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:
+            log(f"other scaling mode failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
+
     # untimed extra pass: every internal kernel bracketed, for the breakdown
     lib.vmlmf_profile_enable((1 << _lib.NKERNELS) - 1)
     for _ in range(10):
@@ -487,9 +610,13 @@ def main():
             torch.cuda.synchronize()
 
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+    tmin = tmax.clone()
     if collective:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+        dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
+    dt, dt_min = float(tmax.item()), float(tmin.item())
+    rccl_ranks = reducer.rccl_ranks() if collective else None
+    collectives_per_step = reducer.last_collectives if collective else 0
     ms_per_step = dt / args.steps * 1e3
     value = batches_per_step * T * args.steps / dt
 
@@ -521,24 +648,42 @@ def main():
         F_WG = 2 * 4 * H * I + 2 * 4 * H * RU + 2 * H * RU
         flops = rows * (F_H + (F_WG if riding else 0))
         achieved = flops / (rec[dom] * 1e-6) / 1e12
+        achieved_rec = rows * F_H / (rec[dom] * 1e-6) / 1e12      # the recurrence's own 10 H ru per sample-step only
+        # workgroups of the dominant launch, one per CU (the launch asks for more than half a CU's LDS): the rows' (vmlmf_query)
+        # and, when the weight gradients ride, the workers' (launch geometry of vmlmf_api.hip: plan_wride; not a counter)
+        nwork = 0
+        if riding:
+            wpw = (192 + 128) // 64
+            ntg = -(-(192 // 8 + (H + 31) // 32) // wpw)
+            nwork = min(32, (256 - 8 - rows_gpu) // ntg) * ntg
+        launch_wgs = rows_gpu + nwork
         out = {
             "metric": "RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16; 1/2/4/8 GPU",
             "value": round(value, 1), "unit": "RNN timesteps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            # beside it: the same step in the other parameter-image mode, and the whole training step (forward + loss + backward
+            # + fused Adam in one graph: packs every step by construction) - config.workload says which one `value` is
+            ("ms_per_step_repack" if args.keep_images else "ms_per_step_kept_images"): None if alt_ms is None else round(alt_ms, 4),
+            "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
+            "ms_per_step_min_over_ranks": round(dt_min / args.steps * 1e3, 4),
+            "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("BASELINE configs[3]: UCI-HAR shape, global batch %d split contiguously over the ranks, "
                                     % args.global_batch if strong else "BASELINE configs[1]: UCI-HAR shape, ")
                                    + f"Net(MyLSTM[MyVMLMFCell]) 1 layer, B={rows_gpu}/GPU T=128 I=9 H=180 w_rank=16 "
-                                     "u_rank=16, CE loss, fwd+bwd"
+                                     "u_rank=16, CE loss, fwd+bwd; "
+                                   + ("kept parameter images (--keep-images): no pack_kernel in the step" if args.keep_images else
+                                      "parameters packed inside every step, as a training loop sees it (with kept parameter "
+                                      "images: ms_per_step_kept_images)")
                                    + (", in-place RCCL all-reduce (AVG) of the flat gradient buffers" if collective else ""),
                        "global_batch": rows_gpu * world, "batch_per_gpu": rows_gpu, "seq_len": T,
                        "parallelism": f"dp{world}", "scaling": "strong" if strong else "weak",
                        "value_counts": "64-row batches x T timesteps per second",
                        "allreduce_transport": reducer.transport_used() if collective else None,
+                       "rccl_ranks": rccl_ranks, "collectives_per_step": collectives_per_step,
                        "launch": launch_mode,
-                       "parameter_images": "packed every forward (--repack)" if args.repack else
-                                           "kept while the parameters are unchanged (no optimizer inside the timed step); "
-                                           "train_step_ms packs every step",
+                       "parameter_images": "kept while the parameters are unchanged (--keep-images)" if args.keep_images else
+                                           "packed inside every step (what a training loop sees)",
                        "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
@@ -546,12 +691,14 @@ def main():
             "step_tflops": round(rows * F_STEP * world / (ms_per_step * 1e-3) / 1e12, 3),
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 3),
                          "peak": F32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
+                         "frac": round(achieved / F32_MATRIX_PEAK_TFLOPS, 5),
+                         "recurrence_only_achieved": round(achieved_rec, 3),
+                         "recurrence_only_frac": round(achieved_rec / F32_MATRIX_PEAK_TFLOPS, 5), "traffic": traffic,
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                          "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
                          # one batch row per CU: rows_gpu of 256 CUs are busy; the same rate against THEIR share of the peak
-                         "active_cus": min(rows_gpu, 256) if not riding else min(rows_gpu + 180, 256),
-                         "frac_of_active_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * (min(rows_gpu, 256) if not riding else min(rows_gpu + 180, 256)) / 256.0), 5),
+                         "launch_workgroups_one_per_cu": min(launch_wgs, 256),
+                         "frac_of_those_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * min(launch_wgs, 256) / 256.0), 5),
                          "utilisation": util, "utilisation_source": util_note,
                          "flops_per_launch": flops,
                          "contains": ("recurrence (10 H ru per sample-step) + the weight-gradient products riding on the launch "
@@ -566,7 +713,7 @@ def main():
             "allreduce_bytes": 4 * reducer.numel() if collective else 0,
             "adam_ms": round(adam_ms, 4),
             "fused_adam_ms": round(fused_adam_ms, 4),
-            "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
+            "other_scaling_mode": other_mode,
             "loss": round(float(loss.item()), 6),
         }
         if world == 1 and not strong and not args.no_extra:

@@ -139,7 +139,9 @@ int vmlmf_seq_forward(const vmlmf_desc *d, const vmlmf_params *p, const float *x
  * `packed` must have been made for the same descriptor (batch and sequence length may differ) and must stay unchanged until the
  * backward that uses it has run; it is the caller's duty to re-pack after ANY change of the parameters.  Not offered for
  * the step-wise / clustered layers (VMLMF_E_UNSUPPORTED): their image carries per-call state.  vmlmf_tune_generation()
- * counts vmlmf_tune() calls: images made under an older generation may have another layout.
+ * counts vmlmf_tune() calls: images made under an older generation may have another layout.  The forward and backward calls
+ * do NOT verify that an image matches their descriptor or the current generation (the image is device memory and they never
+ * synchronise): an image made for another descriptor or generation is used as it is and yields wrong results.
  */
 int vmlmf_pack_bytes(const vmlmf_desc *d, size_t *bytes);
 int vmlmf_pack_params(const vmlmf_desc *d, const vmlmf_params *p, void *packed, void *stream);
@@ -322,6 +324,9 @@ int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_no
 #define VMLMF_COMM_ID_BYTES 128
 int vmlmf_comm_unique_id(void *id128);
 int vmlmf_comm_init(void **comm, int world, int rank, const void *id128);
+/* ABI 8: the number of ranks RCCL itself reports for the communicator (ncclCommCount): evidence, in a result line, that the
+ * exchange really spans N processes */
+int vmlmf_comm_count(void *comm, int *ranks);
 int vmlmf_comm_destroy(void *comm);
 int vmlmf_flat_allreduce(void *buf, size_t n, int op, void *comm, void *stream);
 int vmlmf_flat_allreduce_group(int nbuf, void *const *bufs, const size_t *counts, int op, void *comm, void *stream);

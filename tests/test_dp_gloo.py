@@ -69,7 +69,8 @@ def _worker(rank, world, port, op, out, tiled=False):
     red.reduce()
     if rank == 0:
         torch.save({"a": m.a.grad.clone(), "b": m.b.grad.clone(), "n": red.numel(), "a0": m.a.detach(),
-                    "in_place": in_place, "staged": red.flat is not None}, out)
+                    "in_place": in_place, "staged": red.flat is not None, "collectives": red.last_collectives,
+                    "ranks": red.rccl_ranks()}, out)
     dist.destroy_process_group()
 
 
@@ -78,7 +79,8 @@ def _run(op, tmp_path, tiled=False):
     port = 29500 + (os.getpid() % 2000) + (7 if tiled else 0)
     mp.spawn(_worker, args=(2, port, op, out, tiled), nprocs=2, join=True)
     got = torch.load(out)
-    if tiled:      # both gradients live in one allocation: reduced where they are, no staging buffer
+    assert got["collectives"] == 1 and got["ranks"] == 2          # ONE all-reduce per step, over both ranks
+    if tiled:      # both gradients live in one allocation (as a VMLMF layer's and its classifier's do): reduced where they are
         assert got["in_place"] == [True] and not got["staged"]
     else:          # gradients alone in their allocations share the staging buffer (one collective)
         assert not any(got["in_place"]) and got["staged"]

@@ -165,8 +165,22 @@ def test_lm_network_surface_matches_reference():
     with pytest.raises(TypeError):
         Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vmgroup")
     assert type(Model(V, H, 1, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vm_group").rnns[0]) is torch.nn.LSTM
-    # the dense baseline runs on CPU in stock ops, and so does the loss there
-    c = Model(V, H, L, 0.0, 0.1, lstm_type="custom")
+    # the dense baseline layer is the caller's own class (the reference's LSTM is not re-implemented: out of scope); the
+    # network around it runs on CPU in stock ops, and so does the loss there
+    with pytest.raises(ValueError, match="dense_layer"):
+        Model(V, H, L, 0.0, 0.1, lstm_type="custom")
+
+    class Dense(torch.nn.Module):          # stand-in with the reference's layer interface
+        def __init__(self, i, h):
+            super().__init__()
+            self.hidden_size = h
+            self.w = torch.nn.Parameter(torch.zeros(i, h))
+
+        def forward(self, x, states):
+            y = torch.tanh(x @ self.w)
+            return y, (y[-1], states[1])
+
+    c = Model(V, H, L, 0.0, 0.1, lstm_type="custom", dense_layer=Dense)
     scores, st = c(torch.tensor(d["x0"]), c.state_init(B))
     assert scores.shape == (T * B, V) and st[0][0].shape == (B, H)
     z = torch.randn(T * B, V)

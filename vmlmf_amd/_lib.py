@@ -113,6 +113,7 @@ SYMBOLS = {
     "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "vmlmf_comm_unique_id": (_i, [_vp]),
     "vmlmf_comm_init": (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
+    "vmlmf_comm_count": (_i, [_vp, ctypes.POINTER(_i)]),
     "vmlmf_comm_destroy": (_i, [_vp]),
     "vmlmf_flat_allreduce": (_i, [_vp, _sz, _i, _vp, _vp]),
     "vmlmf_flat_allreduce_group": (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _i, _vp, _vp]),

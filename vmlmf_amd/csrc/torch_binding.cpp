@@ -186,9 +186,12 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor dh0 = has_h0 ? at::empty({B, H}, x.options()) : Tensor(), dc0 = has_c0 ? at::empty({B, H}, x.options()) : Tensor();
     // one flat buffer for all parameter gradients (views are returned): a single allocation, contiguous for the
     // data-parallel all-reduce (vmlmf_amd/dp.py)
+    // (the classifier's weight and bias gradients are the tail of the same allocation: ONE flat buffer, ONE all-reduce per step,
+    // SURVEY section 8e)
     int64_t total = 0;
     for (const auto& p : params) total += p.numel();
-    Tensor flat = at::empty({total}, x.options());
+    const int64_t head_floats = dlogits.defined() ? head_w.size(0) * H + head_w.size(0) : 0;
+    Tensor flat = at::empty({total + head_floats}, x.options());
     std::vector<Tensor> grads;
     int64_t o = 0;
     for (const auto& p : params) {
@@ -200,15 +203,14 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     vmlmf_grads gs;
     fill_params(ps, params, (int)variant, (int)g);
     fill_params(gs, grads, (int)variant, (int)g);
-    // classifier gradients: weight and bias share one allocation (contiguous for the data-parallel all-reduce)
-    Tensor hflat, dW, db;
+    // classifier gradients: behind the layer's in the same allocation
+    Tensor dW, db;
     vmlmf_head hd;
     memset(&hd, 0, sizeof(hd));
     if (dlogits.defined()) {
       const int64_t C = head_w.size(0);
-      hflat = at::empty({C * H + C}, x.options());
-      dW = hflat.narrow(0, 0, C * H).view({C, H});
-      if (has_head_b) db = hflat.narrow(0, C * H, C);
+      dW = flat.narrow(0, total, C * H).view({C, H});
+      if (has_head_b) db = flat.narrow(0, total + C * H, C);
       hd.classes = (int)C, hd.weight = head_w.data_ptr<float>(), hd.dlogits = dlogits.data_ptr<float>();
       hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
     }
@@ -327,7 +329,9 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     Tensor dx = ctx->needs_input_grad(0) ? at::empty_like(x) : Tensor();
     int64_t total = 0;
     for (const auto& p : params) total += p.numel();
-    Tensor flat = at::empty({total}, x.options());   // the parameter gradients of the whole stack in one allocation (views are returned)
+    const int64_t head_floats = dlogits.defined() ? head_w.size(0) * H + head_w.size(0) : 0;
+    // the parameter gradients of the whole stack AND of the classifier in one allocation (views are returned): one all-reduce
+    Tensor flat = at::empty({total + head_floats}, x.options());
     std::vector<Tensor> grads;
     int64_t o = 0;
     for (const auto& p : params) {
@@ -354,14 +358,13 @@ struct StackFn : public torch::autograd::Function<StackFn> {
     }
     check(vmlmf_stack_query((int)L, ly.data(), rbytes.data(), &wbytes));
     Tensor ws = workspace(x, wbytes);
-    Tensor hflat, dW, db;
+    Tensor dW, db;
     vmlmf_head hd;
     memset(&hd, 0, sizeof(hd));
-    if (dlogits.defined()) {   // classifier gradients: weight and bias share one allocation
+    if (dlogits.defined()) {   // classifier gradients: the tail of the stack's allocation
       const int64_t C = head_w.size(0);
-      hflat = at::empty({C * H + C}, x.options());
-      dW = hflat.narrow(0, 0, C * H).view({C, H});
-      if (has_head_b) db = hflat.narrow(0, C * H, C);
+      dW = flat.narrow(0, total, C * H).view({C, H});
+      if (has_head_b) db = flat.narrow(0, total + C * H, C);
       hd.classes = (int)C, hd.weight = head_w.data_ptr<float>(), hd.dlogits = dlogits.data_ptr<float>();
       hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
     }

@@ -509,7 +509,10 @@ int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
 }
 
 // ---- parameter images kept by the caller (vmlmf_pack_params / *_packed) ----
-// header in front of the image: what geometry it was packed for (a forward with another one refuses it)
+// header in front of the image: what geometry it was packed for.  It documents the image (a debugger can read it); it is NOT
+// checked by the forward / backward calls - the image lives in device memory and they never synchronise.  Matching an image
+// with its descriptor and with the vmlmf_tune() generation it was made under is the caller's job (the Python PackCache keys
+// on both; include/vmlmf_hip.h says so).
 constexpr int PK_HDR = 64;   // floats
 static void pack_signature(const VGeo& g, const VPack& P, const RbGeo& q, float* sig) {
   const long long v[8] = {0x564d4c4dLL, P.total, g.rb, g.generic, g.bf, g.NT, (long long)g.KH * 1000 + g.KX, q.total};

@@ -97,6 +97,14 @@ int vmlmf_comm_init(void** comm, int world, int rank, const void* id128) {
   return 0;
 }
 
+int vmlmf_comm_count(void* comm, int* ranks) {
+  Rccl* r = rccl();
+  if (!r->why.empty()) return no_rccl();
+  if (comm == nullptr || ranks == nullptr) return vmlmf_set_error(VMLMF_E_BADARG, "comm_count: null communicator / result");
+  const ncclResult_t e = r->CommCount((ncclComm_t)comm, ranks);
+  return e == ncclSuccess ? 0 : nccl_fail(r, e, "ncclCommCount");
+}
+
 int vmlmf_comm_destroy(void* comm) {
   Rccl* r = rccl();
   if (!r->why.empty()) return no_rccl();

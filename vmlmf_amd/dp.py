@@ -3,8 +3,8 @@
 The reference has no distributed code.  Batch rows are independent through the
 whole forward/backward, so the only exchange is the sum over ranks of the parameter gradients.  The
 payload is tiny (HAR Net: 30 951 floats = 121 KiB), i.e. latency-bound on xGMI: bucketing would only add
-launches.  The kernels already write a layer's gradients into one flat allocation, so the exchange is one
-in-place all-reduce per such allocation on the compute stream (HAR Net: the layer's and the classifier's),
+launches.  The kernels already write a layer's gradients AND those of the classifier riding on it into one flat
+allocation (functional.VmlmfSeqFn.backward), so the exchange is ONE in-place all-reduce on the compute stream,
 with no staging copies (torch.distributed backend "nccl" == RCCL on ROCm; "gloo" in the CPU tests).
 
 Reduction op must reproduce single-process semantics:
@@ -27,18 +27,47 @@ class CabiComm:
     The calling process must have its HIP device current (torch.cuda.set_device)."""
 
     def __init__(self, device, group=None):
+        """EVERY rank of the group takes the same sequence of torch.distributed collectives whatever fails locally (a rank
+        that raised before a collective the others are already in would hang the job): rank 0 always broadcasts 1 + 128
+        bytes - a flag saying whether it could make the id, and the id - every rank calls vmlmf_comm_init only when the flag
+        is set (ncclCommInitRank is itself collective), and a MIN all-reduce of "my communicator exists" decides for all.
+        self.handle is None afterwards when any rank failed; self.error holds the local reason."""
         self.lib = _lib.lib()
         self.device = torch.device(device)
+        self.handle, self.error = None, None
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)()
+        have_id = 0
         if rank == 0:
-            _lib.check(self.lib.vmlmf_comm_unique_id(ident))
-        t = torch.tensor(list(ident), dtype=torch.uint8, device=self.device)
+            try:
+                _lib.check(self.lib.vmlmf_comm_unique_id(ident))
+                have_id = 1
+            except Exception as e:      # noqa: BLE001 - reported to every rank through the flag byte
+                self.error = e
+        t = torch.tensor([have_id] + list(ident), dtype=torch.uint8, device=self.device)
         dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-        ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)(*t.cpu().tolist())
-        self.handle = ctypes.c_void_p()
-        with _lib.on_device(self.device):
-            _lib.check(self.lib.vmlmf_comm_init(ctypes.byref(self.handle), world, rank, ident))
+        got = t.cpu().tolist()
+        handle, ok = ctypes.c_void_p(), 0
+        if got[0] == 1:
+            ident = (ctypes.c_ubyte * _lib.COMM_ID_BYTES)(*got[1:])
+            try:
+                with _lib.on_device(self.device):
+                    _lib.check(self.lib.vmlmf_comm_init(ctypes.byref(handle), world, rank, ident))
+                ok = 1
+            except Exception as e:      # noqa: BLE001
+                self.error = e
+        flag = torch.tensor([ok], device=self.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            self.handle = handle
+        elif ok:
+            self.lib.vmlmf_comm_destroy(handle)
+
+    def ranks(self):
+        """Ranks RCCL reports for the communicator (ncclCommCount)."""
+        n = ctypes.c_int(0)
+        _lib.check(self.lib.vmlmf_comm_count(self.handle, ctypes.byref(n)))
+        return n.value
 
     def all_reduce(self, tensors, op):
         """In place, every tensor of the list under one RCCL group call, on torch's current stream."""
@@ -52,7 +81,7 @@ class CabiComm:
     def close(self):
         if self.handle:
             self.lib.vmlmf_comm_destroy(self.handle)
-            self.handle = ctypes.c_void_p()
+            self.handle = None
 
 
 class FlatGradAllReduce:
@@ -70,6 +99,7 @@ class FlatGradAllReduce:
         self._comm_tried = False
         self.params = [p for p in params if p.requires_grad]
         self.always = False   # run the collectives even in a group of one (bench self-test of the RCCL path)
+        self.last_collectives = 0   # all-reduce operations the last reduce() issued (HAR Net: 1 - layer and classifier share a buffer)
         self.flat = None   # staging buffer for gradients that do not already share a flat allocation
 
     # parameters that never receive a gradient (e.g. Net.cell, the reference's unused duplicate,
@@ -98,6 +128,12 @@ class FlatGradAllReduce:
                 out.append((None, gs))
         return out
 
+    def rccl_ranks(self):
+        """Ranks of the communicator the exchange runs on, as RCCL reports them (C-ABI transport), else the group's size."""
+        if self._comm is not None:
+            return self._comm.ranks()
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
     def transport_used(self):
         return "cabi:vmlmf_flat_allreduce_group(rccl)" if self._comm is not None else f"torch.distributed:{dist.get_backend(self.group) if dist.is_initialized() else 'none'}"
 
@@ -107,17 +143,9 @@ class FlatGradAllReduce:
             return None
         if not self._comm_tried:
             self._comm_tried = True
-            comm, ok = None, 1
-            try:
-                comm = CabiComm(device, self.group)
-            except Exception:       # noqa: BLE001 - any failure means "use torch.distributed", decided collectively
-                ok = 0
-            flag = torch.tensor([ok], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
-            if int(flag.item()) == 1:
-                self._comm = comm
-            elif comm is not None:
-                comm.close()
+            comm = CabiComm(device, self.group)     # never raises before its collectives are done; decides collectively
+            self._comm = comm if comm.handle else None
+            self._comm_error = comm.error
         return self._comm
 
     def _all_reduce(self, tensors, op, backend):
@@ -150,6 +178,7 @@ class FlatGradAllReduce:
         op = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
         scale = None if (native_avg or self.op == "sum") else 1.0 / world
         loose, flats = [], []
+        self.last_collectives = 0
         for flat, gs in self._spans([p.grad for p in params]):
             if flat is None:
                 loose += gs
@@ -157,6 +186,7 @@ class FlatGradAllReduce:
                 flats.append(flat)
         if flats and (world > 1 or self.always):
             self._all_reduce(flats, op, backend)
+            self.last_collectives += len(flats)
             if scale is not None:
                 for flat in flats:
                     flat.mul_(scale)
@@ -170,6 +200,7 @@ class FlatGradAllReduce:
             torch._foreach_copy_(views, loose)
             if world > 1 or self.always:
                 self._all_reduce([self.flat], op, backend)
+                self.last_collectives += 1
                 if scale is not None:
                     self.flat.mul_(scale)
             torch._foreach_copy_(loose, views)

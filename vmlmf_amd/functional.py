@@ -240,7 +240,11 @@ class VmlmfSeqFn(torch.autograd.Function):
         dc0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_c0 else None
         # one flat buffer for all parameter gradients (views are returned): a single allocation, and the
         # gradients of a layer are contiguous for the data-parallel all-reduce
-        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        # (the classifier's weight and bias gradients are the tail of the same allocation: ONE flat buffer, ONE all-reduce per
+        # step)
+        use_head = hw is not None and dlogits is not None
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total + ((hw.shape[0] * H + hw.shape[0]) if use_head else 0), device=dev, dtype=torch.float32)
         grads, o = [], 0
         for p in params:
             grads.append(flat[o:o + p.numel()].view(p.shape))
@@ -252,13 +256,11 @@ class VmlmfSeqFn(torch.autograd.Function):
         stream = _lib.raw_stream(dev)
         dW = db = None
         hd = _lib.Head()
-        use_head = hw is not None and dlogits is not None
         if use_head:
             dl = dlogits.contiguous()
             C = hw.shape[0]
-            hflat = torch.empty(C * H + C, device=dev, dtype=torch.float32)   # weight + bias gradients in one allocation
-            dW = hflat[:C * H].view(C, H)
-            db = hflat[C * H:] if ctx.has_head_b else None
+            dW = flat[total:total + C * H].view(C, H)
+            db = flat[total + C * H:] if ctx.has_head_b else None
             hd.classes, hd.weight, hd.dlogits, hd.dweight = C, hw.data_ptr(), dl.data_ptr(), dW.data_ptr()
             hd.dbias = None if db is None else db.data_ptr()
         ex = _lib.Extra()
@@ -410,8 +412,10 @@ class VmlmfStackFn(torch.autograd.Function):
         dcT = [None if d is None else d.contiguous() for d in dstates[L:2 * L]]
         need_dx = ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_dx else None
-        # one flat buffer for the parameter gradients of the whole stack (views are returned)
-        flat = torch.empty(sum(p.numel() for p in params), device=dev, dtype=torch.float32)
+        # one flat buffer for the parameter gradients of the whole stack and of the classifier (views are returned)
+        use_head = hw is not None and dlogits is not None
+        total = sum(p.numel() for p in params)
+        flat = torch.empty(total + ((hw.shape[0] * hw.shape[1] + hw.shape[0]) if use_head else 0), device=dev, dtype=torch.float32)
         grads, o = [], 0
         for p in params:
             grads.append(flat[o:o + p.numel()].view(p.shape))
@@ -437,13 +441,11 @@ class VmlmfStackFn(torch.autograd.Function):
             ly.dcT = None if dcT[l] is None else dcT[l].data_ptr()
         dW = db = None
         hd = _lib.Head()
-        use_head = hw is not None and dlogits is not None
         if use_head:
             dl = dlogits.contiguous()
             C, H = hw.shape
-            hflat = torch.empty(C * H + C, device=dev, dtype=torch.float32)   # weight + bias gradients in one allocation
-            dW = hflat[:C * H].view(C, H)
-            db = hflat[C * H:] if ctx.has_head_b else None
+            dW = flat[total:total + C * H].view(C, H)
+            db = flat[total + C * H:] if ctx.has_head_b else None
             hd.classes, hd.weight, hd.dlogits, hd.dweight = C, hw.data_ptr(), dl.data_ptr(), dW.data_ptr()
             hd.dbias = None if db is None else db.data_ptr()
         with _lib.on_device(dev):
@@ -483,8 +485,11 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
         return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel; with a wide
                              #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
                              #  profiles/r02_stack_vs_chained_over_T.txt)
+    # (the classifier's weight and bias count: with a frozen RNN under a trainable head the launch runs in training mode, and the
+    #  coverage check must be made for that mode - otherwise an uncovered stack raised instead of falling back to chained layers)
     training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for ps in layer_params for p in ps)
-                                            or (h0 is not None and h0.requires_grad) or (c0 is not None and c0.requires_grad))
+                                            or (h0 is not None and h0.requires_grad) or (c0 is not None and c0.requires_grad)
+                                            or (head is not None and any(t is not None and t.requires_grad for t in head)))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
         return None
     flat = [p for ps in layer_params for p in ps]

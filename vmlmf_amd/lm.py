@@ -3,10 +3,11 @@
   MyVMLSTM       V/src/models/vmlmf_lm.py:178-280   forward(x:(T,B,X), (h,c)) -> (y, (h,c))
   MyVMLSTMGroup  V/src/models/vmlmf_lm.py:53-174    (the reference only runs at batch 40: its scratch is
                                                      hard-coded, 112-113; this implementation has no limit)
-  Embed, LSTM, Linear, Model   V/src/models/vmlmf_lm.py:33-51, 283-343, 345-364, 366-440: the rest of the LM network
-                               around those layers.  Embedding lookup, the vocabulary
-                               projection (one library GEMM) and the dense baseline LSTM are stock ops; the loss that
-                               consumes the scores is vmlmf_amd.nll_loss (fused kernels).
+  Embed, Linear, Model   V/src/models/vmlmf_lm.py:33-51, 345-364, 366-440: the rest of the LM network around those layers
+                         (SURVEY section 8f rank 3).  Embedding lookup and the vocabulary projection (one library GEMM) are
+                         stock ops; the loss that consumes the scores is vmlmf_amd.nll_loss (fused kernels).  The reference's
+                         dense "custom" LSTM layer (283-343) is the uncompressed baseline, out of scope: Model takes the
+                         caller's class for it (dense_layer=).
 Parameter names, shapes and registration order follow the reference (state_dict compatible).
 """
 from __future__ import annotations
@@ -123,41 +124,6 @@ class Embed(nn.Module):
         return f"Embedding(vocab: {self.vocab_size}, embedding: {self.embed_size})"
 
 
-class LSTM(nn.Module):
-    """The reference's dense "custom" LSTM layer (vmlmf_lm.py:283-343): the uncompressed baseline, stock GEMMs in
-    the reference's per-timestep loop.  Not the VMLMF path."""
-
-    def __init__(self, input_size, hidden_size, dropout=0):
-        super().__init__()
-        self.input_size = input_size
-        self.hidden_size = hidden_size
-        self.dropout = dropout
-        self.w_x = nn.Parameter(torch.zeros(4 * hidden_size, input_size))
-        self.w_h = nn.Parameter(torch.zeros(4 * hidden_size, hidden_size))
-        self.b_x = nn.Parameter(torch.zeros(4 * hidden_size))
-        self.b_h = nn.Parameter(torch.zeros(4 * hidden_size))
-
-    def __repr__(self):
-        return f"LSTM(input: {self.input_size}, hidden: {self.hidden_size})"
-
-    def lstm_step(self, x, h, c, w_x, w_h, b_x, b_h):
-        gx = torch.addmm(b_x, x, w_x.t())
-        gh = torch.addmm(b_h, h, w_h.t())
-        xi, xf, xo, xn = gx.chunk(4, 1)
-        hi, hf, ho, hn = gh.chunk(4, 1)
-        c = torch.sigmoid(xf + hf) * c + torch.sigmoid(xi + hi) * torch.tanh(xn + hn)
-        h = torch.sigmoid(xo + ho) * torch.tanh(c)
-        return h, c
-
-    def forward(self, x, states):
-        h, c = states
-        outputs = []
-        for x_t in x.unbind(0):
-            h, c = self.lstm_step(x_t, h, c, self.w_x, self.w_h, self.b_x, self.b_h)
-            outputs.append(h)
-        return torch.stack(outputs), (h, c)
-
-
 class Linear(nn.Module):
     """Vocabulary projection (vmlmf_lm.py:345-364): (T, B, H) -> (T*B, V) scores, one library GEMM."""
 
@@ -183,7 +149,10 @@ class Model(nn.Module):
     "vm_group" silently builds torch.nn.LSTM layers.  Build MyVMLSTMGroup layers directly for the group variant."""
 
     def __init__(self, vocab_size, hidden_size, layer_num, dropout, winit, w_rank=None, u_ranks=None,
-                 lstm_type="pytorch"):
+                 lstm_type="pytorch", dense_layer=None):
+        """dense_layer: the class to build for lstm_type="custom" - the reference's own dense `LSTM` layer
+        (vmlmf_lm.py:283-339), which is the uncompressed baseline, not the VMLMF path, and is not re-implemented here:
+        pass `models.vmlmf_lm.LSTM` (any class with the signature (input_size, hidden_size) and forward(x, states))."""
         super().__init__()
         self.vocab_size = vocab_size
         self.hidden_size = hidden_size
@@ -195,9 +164,13 @@ class Model(nn.Module):
             u_ranks = u_ranks[-1]
         if lstm_type == "vmgroup":
             rnns = [MyVMLSTMGroup(hidden_size, hidden_size, w_rank=w_rank, u_ranks=u_ranks) for _ in range(layer_num)]
+        elif lstm_type == "custom":
+            if dense_layer is None:
+                raise ValueError('vmlmf_amd.lm.Model(lstm_type="custom"): the dense baseline layer is the reference\'s own class '
+                                 "(vmlmf_lm.py:283-339) - pass it as dense_layer=...; this package only re-implements the VMLMF layers")
+            rnns = [dense_layer(hidden_size, hidden_size) for _ in range(layer_num)]
         elif lstm_type != "vmlmf":
-            rnns = [LSTM(hidden_size, hidden_size) if lstm_type == "custom" else nn.LSTM(hidden_size, hidden_size)
-                    for _ in range(layer_num)]
+            rnns = [nn.LSTM(hidden_size, hidden_size) for _ in range(layer_num)]
         else:
             rnns = [MyVMLSTM(hidden_size, hidden_size, w_rank=w_rank, u_ranks=u_ranks) for _ in range(layer_num)]
         self.rnns = nn.ModuleList(rnns)
