@@ -255,7 +255,7 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
   a.P = w.wpart;
   const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
-  const int GK = g.G * g.KH, n1 = (vg_nb1(g) + 31) / 32, n2 = (GK + 31) / 32;
+  const int GK = g.G * g.KH, n1 = (g.KX + g.KH + 31) / 32, n2 = (GK + 31) / 32;   // mode 1: [qx | own vector] per (slot block, gate) task
   const dim3 grid((tasks + 3) / 4, g.nchunk);
   // two waves per task while the hand-over buffer stays small (four measured slower at the headline shape:
   // 0.1990 vs 0.1966 ms per step)
@@ -275,6 +275,8 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   // groups n2 can exceed n1
   WG_CASE(2, 3);
   else WG_CASE(2, 4);
+  else WG_CASE(1, 3);
+  else WG_CASE(1, 4);
   else WG_CASE(3, 1);
   else WG_CASE(3, 2);
   else WG_CASE(3, 3);
