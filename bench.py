@@ -625,17 +625,27 @@ def main():
         # HBM traffic of that kernel: PMC counters cannot be read from inside the process; they were collected
         # with rocprofv3 in separate passes on this same command and committed under profiles/
         traffic, traffic_note, util, util_note = None, None, None, None
-        for name in ("r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        # (rocprof reports the kernels by their own names: the backward recurrence of this shape is rec3_bwd_kernel)
+        prof_names = {"rec_bwd_kernel": ("rec3_bwd_kernel", "rec_bwd_kernel"), "rec_fwd_kernel": ("rec_fwd_kernel", "rec3_fwd_kernel")}
+
+        def prof_entry(kernels):
+            for nm in prof_names.get(dom, (dom,)):
+                if nm in kernels:
+                    return kernels[nm]
+            raise KeyError(dom)
+
+        for name in ("r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
-                traffic = pmc["kernels"][dom]["hbm_bytes_per_launch"]
+                traffic = prof_entry(pmc["kernels"])["hbm_bytes_per_launch"]
                 traffic_note = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 2x FETCH correction)"
                 break
             except (OSError, KeyError, ValueError):
                 pass
         try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
-            util_file = "r02_zz4_pmc_util.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_zz4_pmc_util.json")) else "r02_pmc_util.json"
-            u = json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"][dom]["derived"]
+            util_file = next(f for f in ("r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json")
+                             if os.path.exists(os.path.join(ROOT, "profiles", f)))
+            u = prof_entry(json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"])["derived"]
             util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
                                           "lds_conflict_frac", "valu_insts_per_wave", "mfma_insts_per_wave")}
             util_note = f"profiles/{util_file} (rocprofv3 --pmc SQ_*; fractions of SQ_WAVE_CYCLES resp. of busy-CU cycles)"

@@ -466,3 +466,44 @@ def test_reference_demo_shapes_through_mylstm_on_the_default_path_against_the_fp
     for k in ORDER[variant]:
         key = ("layers." + k) if ("layers." + k) in named else k
         assert_grad(named[key].grad.cpu().numpy(), Pt[k].grad.numpy(), k)
+
+
+def test_lm_model_layer_loop_runs_as_one_wavefront_launch_with_carried_states():
+    """Model.forward (vmlmf_lm.py:433-441) with covered MyVMLSTM layers and no active dropout: the layer loop goes through
+    vmlmf_stack with the carried (h, c) of every layer as initial states - same scores, same new states, same gradients as
+    the layer-by-layer loop (VMLMF_STACK=0), over two consecutive minibatches (truncated BPTT: states detached in between)."""
+    import vmlmf_amd
+    from vmlmf_amd import functional as F
+    V, H, L, B, T, rw, ru = 60, 96, 2, 12, 9, 12, 10
+    res = {}
+    for mode in ("auto", "0"):
+        os.environ["VMLMF_STACK"] = mode
+        try:
+            torch.manual_seed(11)
+            m = vmlmf_amd.Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[ru], lstm_type="vmlmf").cuda()
+            if mode == "auto":
+                cfg = m.rnns[0]
+                assert F._stack_plan((cfg.variant, 1, rw, (ru,), True, 0), L, B, T, H, H, True) is not None
+            g = torch.Generator().manual_seed(3)
+            states = m.state_init(B)
+            outs = []
+            for step in range(2):
+                xs = torch.randint(0, V, (T, B), generator=g).cuda()
+                ys = torch.randint(0, V, (T, B), generator=g).cuda()
+                states = m.detach(states)
+                m.zero_grad(set_to_none=True)
+                scores, states = m(xs, states)
+                loss = vmlmf_amd.nll_loss(scores, ys)
+                loss.backward()
+                outs.append((scores.detach().clone(), [(h.detach().clone(), c.detach().clone()) for h, c in states],
+                             {n: p.grad.clone() for n, p in m.named_parameters()}))
+            torch.cuda.synchronize()
+            res[mode] = outs
+        finally:
+            os.environ.pop("VMLMF_STACK", None)
+    for a, b in zip(res["auto"], res["0"]):
+        assert float((a[0] - b[0]).abs().max()) <= 2e-5 * max(1.0, float(b[0].abs().max()))
+        for (ha, ca), (hb, cb) in zip(a[1], b[1]):
+            assert float((ha - hb).abs().max()) <= 2e-5 and float((ca - cb).abs().max()) <= 2e-5
+        for n, gref in b[2].items():
+            assert float((a[2][n] - gref).abs().max()) <= 1e-4 * float(gref.abs().max()) + 1e-6, n

@@ -130,6 +130,8 @@ int main(int argc, char** argv) {
     printf("rec3 fwd XM0 no x            %8.2f us\n", (run3<1, 0>(g, a, xw, 50)));
     printf("rec3 fwd XM0 storer idle     %8.2f us\n", (run3<2048, 0>(g, a, xw, 50)));
     printf("rec3 fwd XM0 both            %8.2f us\n", (run3<2049, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM0 narrow c/y st   %8.2f us\n", (run3<64, 0>(g, a, xw, 50)));
+    printf("rec3 fwd XM0 narrow, no x    %8.2f us\n", (run3<65, 0>(g, a, xw, 50)));
     printf("rec3 fwd XM1 full            %8.2f us\n", (run3<0, 1>(g, a, xw, 50)));
     printf("rec3 fwd XM1 no x            %8.2f us\n", (run3<1, 1>(g, a, xw, 50)));
     printf("rec3 fwd XM1 storer idle     %8.2f us\n", (run3<2048, 1>(g, a, xw, 50)));

@@ -192,11 +192,44 @@ class Model(nn.Module):
     def detach(self, states):
         return [(h.detach(), c.detach()) for (h, c) in states]
 
+    def _stack(self, x, states):
+        """The layer loop of forward() (vmlmf_lm.py:437-439) as ONE wavefront launch per direction with the carried states as
+        initial states (functional.vmlmf_stack), when that gives the same values: no dropout between the layers (p = 0 or
+        eval mode), MyVMLSTM layers of one configuration, and a stack the wavefront kernels cover (hidden sizes up to 256).
+        None otherwise: the caller loops over the layers."""
+        if (self.training and self.dropout.p > 0) or not x.is_cuda or len(self.rnns) < 2:
+            return None
+        if not all(type(r) is MyVMLSTM for r in self.rnns):
+            return None
+        r0 = self.rnns[0]
+        if any((r.input_size, r.hidden_size, r.w_rank, r.u_ranks) != (r0.input_size, r0.hidden_size, r0.w_rank, r0.u_ranks)
+               for r in self.rnns):
+            return None
+        if any(getattr(r, "compute_dtype", "f32") != "f32" for r in self.rnns):
+            return None
+        from .functional import vmlmf_stack
+        h0 = torch.stack([st[0] for st in states])
+        c0 = torch.stack([st[1] for st in states])
+        ur = r0.u_ranks if isinstance(r0.u_ranks, (list, tuple)) else [r0.u_ranks]
+        out = vmlmf_stack(variant=r0.variant, x=x, layer_params=[r.kernel_params() for r in self.rnns], w_rank=r0.w_rank,
+                          u_ranks=list(ur), g=1, time_major=True, h0=h0, c0=c0)
+        if out is None:
+            return None
+        y, hs, cs = out
+        return y, [(hs[i], cs[i]) for i in range(len(self.rnns))]
+
     def forward(self, x, states):
         x = self.embed(x)
         x = self.dropout(x)
-        for i, rnn in enumerate(self.rnns):
-            x, states[i] = rnn(x, states[i])
+        stacked = self._stack(x, states)
+        if stacked is not None:
+            x, new_states = stacked
+            for i, st in enumerate(new_states):
+                states[i] = st
             x = self.dropout(x)
+        else:
+            for i, rnn in enumerate(self.rnns):
+                x, states[i] = rnn(x, states[i])
+                x = self.dropout(x)
         scores = self.fc(x)
         return scores, states
