@@ -41,3 +41,13 @@ def test_the_checker_finds_a_planted_hazard(tmp_path):
         problems = []
         C.check_kernel("k", lines, problems)
         assert len(problems) == n, (lines, problems)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="llvm-objdump of the ROCm toolchain not present")
+def test_headline_kernels_stay_inside_their_register_budget():
+    """tools/kernel_budget.py: VGPR counts and scratch instructions of the recurrent kernels of configs A and C, read from the
+    built library's code objects.  Their speed moves with the register allocation (+-5 % for unrelated
+    edits); a spill into a per-step loop or a crossed occupancy step fails here instead of waiting for a re-measurement."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "kernel_budget.py"), LIB], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1500:]
+    assert "0 breach(es)" in r.stdout
