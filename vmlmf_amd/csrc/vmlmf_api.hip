@@ -178,8 +178,10 @@ int g_rb_minB = env_pos("VMLMF_RB_MINB", 0);
 int g_rb_S = env_pos("VMLMF_RB_S", 0);            // cluster size for large layers (0 = the smallest that has an instantiation)
 int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgroup: 16 / 8 / 4 (0 = automatic)
 // third form of the recurrent kernels (vmlmf_rec3.inc) where it covers the layer: VMLMF_REC3=0 / vmlmf_tune("rec3", 0) keeps
-// rec_fwd_kernel / rec_bwd_kernel (A/B runs); bit 1 = forward, bit 2 = backward
-int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 2; }();
+// rec_fwd_kernel / rec_bwd_kernel (A/B runs); bit 1 = forward always, bit 2 = backward, bit 4 = forward when there are more
+// batch rows than CUs (rec3_fwd_kernel needs ~170 VGPRs, two workgroups share a CU; rec_fwd_kernel's x-projection wave needs
+// 256, so its workgroups run in rounds: measured B = 512 138 -> 104 us, 0.402 -> 0.370 ms per step; up to B = 256 the two tie)
+int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 6; }();
 int g_tune_generation = 0;                        // bumped by every vmlmf_tune(): kept parameter images of an older one are stale
 
 // ---- geometry ----
@@ -677,7 +679,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   a.prog = g.training ? reinterpret_cast<unsigned*>(rs + L.r_prog) : nullptr;
   {
     Scope sc(2, s);
-    if (xwave && (g_rec3 & 1) && rec3_fwd_supported(g)) {
+    if (xwave && ((g_rec3 & 1) || ((g_rec3 & 4) && g.nwg > device_cus())) && rec3_fwd_supported(g)) {
       if ((rc = hip_fail(launch_rec3_fwd(g, a, xw, s), "rec3_fwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
   }
