@@ -593,3 +593,29 @@ def test_classifier_riding_on_the_last_layer_equals_the_separate_head(layers, B,
         assert_grad(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), k, rel=2e-5)
     with torch.no_grad():
         assert_out(a(x).cpu().numpy(), head_linear(b.rnn.run_layers(x)[1][-1], b.lin.weight, b.lin.bias).cpu().numpy(), "logits")
+
+
+def test_linear_nll_without_the_score_tensor_equals_projection_plus_loss():
+    """vmlmf_amd.linear_nll: Linear (vmlmf_lm.py:355-358) + nll_loss (lm_test.py:140-153) in row chunks whose scores never form
+    a (T*B, V) tensor - same loss, same gradients (the backward recomputes the chunk's scores) as the projection followed by
+    the loss; by default only taken when no gradient is needed."""
+    import vmlmf_amd
+    torch.manual_seed(4)
+    T, B, H, V = 7, 9, 40, 301
+    h = torch.randn(T, B, H, device="cuda", requires_grad=True)
+    w = (0.2 * torch.randn(V, H, device="cuda")).requires_grad_(True)
+    b = (0.1 * torch.randn(V, device="cuda")).requires_grad_(True)
+    y = torch.randint(0, V, (T, B), device="cuda")
+    ref = vmlmf_amd.nll_loss(torch.addmm(b, h.reshape(-1, H), w.t()), y)
+    ref.backward()
+    want = [t.grad.clone() for t in (h, w, b)]
+    for chunk in (5, 16, 64):
+        h.grad = w.grad = b.grad = None
+        got = vmlmf_amd.linear_nll(h, w, b, y, chunk_rows=chunk, fused=True)
+        got.backward()
+        assert abs(float(got) - float(ref)) <= 1e-5 * abs(float(ref))
+        for t, g in zip((h, w, b), want):
+            assert float((t.grad - g).abs().max()) <= 1e-5 * float(g.abs().max()) + 1e-7
+    with torch.no_grad():
+        assert abs(float(vmlmf_amd.linear_nll(h, w, b, y)) - float(ref)) <= 1e-5 * abs(float(ref))      # the chunked form
+    assert abs(float(vmlmf_amd.linear_nll(h, w, b, y)) - float(ref)) <= 1e-6 * abs(float(ref))          # needs a gradient: unfused

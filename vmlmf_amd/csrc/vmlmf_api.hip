@@ -144,7 +144,7 @@ const bool g_wride = []() {
   return e == nullptr || e[0] != '0';
 }();
 const int g_wride_k = env_pos("VMLMF_WRIDE_K", 32);
-const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 96);   // measured at H = 180, T = 128: B 32 +3 %, 64 +10 %, 80 and 96 +1 %, 112 -17 % (too few free CUs for the workers to keep up)
+const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 64);   // round 3, rec3_bwd_kernel rows (61 us alone): ride on / off at H = 180, T = 128: B 32 0.158 / 0.165 ms, 64 0.160 / 0.173, 72 0.185 / 0.178, 80 0.187 / 0.177, 96 0.192 / 0.181 (the faster rows outrun the workers once fewer than ~180 CUs are left for them; round 2, slower rows: rode up to 96)
 const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
 const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
 // experiments (bits): 1 = the workers leave at once, 2 = a progress word every step

@@ -712,3 +712,73 @@ def nll_loss(scores, y):
     probabilities = expscores / expscores.sum(1, keepdim=True)
     answerprobs = probabilities[range(len(y.reshape(-1))), y.reshape(-1)]
     return torch.mean(-torch.log(answerprobs) * batch_size)
+
+
+class LinearNllFn(torch.autograd.Function):
+    """Vocabulary projection + log-softmax + NLL of the LM loop (Linear, vmlmf_lm.py:355-358; nll_loss, lm_test.py:140-153)
+    WITHOUT the (T*B, V) score tensor in HBM: the rows are cut into chunks whose scores (chunk x V) live in one reused buffer
+    that stays in the memory-side cache; every chunk is one library GEMM + the fused NLL kernel.  The backward recomputes a
+    chunk's scores (a fourth GEMM-sized product) before it forms dscores, dh and accumulates dW, db.
+    Measured at config E's shape (tools/bench_lm_head.py, profiles/r03_lm_head_fusion.jsonl): the forward alone is faster than
+    GEMM + loss over the full tensor; forward + backward is slower (the recomputed product costs more than the three round
+    trips of 358 MB it saves) - so vmlmf_amd.linear_nll takes this path only when no gradient is needed."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, y, chunk_rows):
+        _require_hip(h, "h")
+        h2 = h.reshape(-1, h.shape[-1]).contiguous()
+        R, V = h2.shape[0], w.shape[0]
+        batch_size = y.size(1)
+        yrow = y.reshape(-1).contiguous()
+        scale = float(batch_size) / float(R)
+        C = min(int(chunk_rows), R)
+        buf = torch.empty((C, V), device=h.device, dtype=torch.float32)
+        stats = torch.empty(1 + 2 * R, device=h.device, dtype=torch.float32)       # (chunk loss) | lse | rowloss
+        losses = torch.empty((R + C - 1) // C, device=h.device, dtype=torch.float32)
+        stream = _lib.raw_stream(h.device)
+        lib = _lib.lib()
+        with _lib.on_device(h.device):
+            for ci, r0 in enumerate(range(0, R, C)):
+                n = min(C, R - r0)
+                sc = buf[:n]
+                torch.addmm(b, h2[r0:r0 + n], w.t(), out=sc)
+                _lib.check(lib.vmlmf_nll_forward(n, V, _ptr(sc), yrow.data_ptr() + 8 * r0, scale, losses.data_ptr() + 4 * ci,
+                                                 stats.data_ptr() + 4 * (1 + r0), stats.data_ptr() + 4 * (1 + R + r0), stream))
+        ctx.save_for_backward(h2, w, b, yrow, stats)
+        ctx.scale, ctx.C, ctx.hshape = scale, C, h.shape
+        return losses.sum()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        h2, w, b, yrow, stats = ctx.saved_tensors
+        R, V, C = h2.shape[0], w.shape[0], ctx.C
+        dloss = dloss.contiguous()
+        buf = torch.empty((C, V), device=h2.device, dtype=torch.float32)
+        dzb = torch.empty((C, V), device=h2.device, dtype=torch.float32)
+        dh = torch.empty_like(h2)
+        dw = torch.zeros_like(w)
+        db = torch.zeros_like(b)
+        stream = _lib.raw_stream(h2.device)
+        lib = _lib.lib()
+        with _lib.on_device(h2.device):
+            for r0 in range(0, R, C):
+                n = min(C, R - r0)
+                sc, dz = buf[:n], dzb[:n]
+                torch.addmm(b, h2[r0:r0 + n], w.t(), out=sc)                     # the scores again
+                _lib.check(lib.vmlmf_nll_backward(n, V, _ptr(sc), yrow.data_ptr() + 8 * r0, ctx.scale,
+                                                  stats.data_ptr() + 4 * (1 + r0), _ptr(dloss), _ptr(dz), stream))
+                torch.mm(dz, w, out=dh[r0:r0 + n])
+                dw.addmm_(dz.t(), h2[r0:r0 + n])
+                db.add_(dz.sum(0))
+        return dh.view(ctx.hshape), dw, db, None, None
+
+
+def linear_nll(h, weight, bias, y, chunk_rows=2048, fused=None):
+    """loss = nll_loss(Linear(h), y) of the LM loop (vmlmf_lm.py:355-358 + lm_test.py:140-153): h (T, B, H), weight (V, H), bias
+    (V), y (T, B) int64.  fused=None: the chunked form without the score tensor when no gradient is needed (evaluation,
+    perplexity), GEMM + loss over the full tensor when one is (measured: LinearNllFn's docstring); True / False force one."""
+    need_grad = torch.is_grad_enabled() and (h.requires_grad or weight.requires_grad or bias.requires_grad)
+    use = (not need_grad) if fused is None else bool(fused)
+    if use and h.is_cuda:
+        return LinearNllFn.apply(h, weight, bias, y, chunk_rows)
+    return nll_loss(torch.addmm(bias, h.reshape(-1, h.shape[-1]), weight.t()), y)
