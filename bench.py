@@ -74,6 +74,8 @@ def spawn_ranks(n, argv):
     import socket
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get("VMLMF_BENCH_REHEARSAL") == "1":
+        have = n       # every rank on GPU 0 over gloo (see main): a rehearsal of the N > 1 code path, not a measurement
     if have < n:
         print(f"[bench] --gpus {n} asked for, {have} visible", file=sys.stderr)
         return 2
@@ -305,6 +307,12 @@ def main():
     batches_per_step = (args.global_batch / B_PER_GPU) if strong else world   # 64-row batches one step processes
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    # VMLMF_BENCH_REHEARSAL=1: every rank on GPU 0, gradients exchanged over gloo - RCCL refuses two ranks on one device, and
+    # the builder's boxes have one GPU; this walks the N > 1 code path (spawn, sharding, exchange, barriers, max over ranks,
+    # both scaling modes, the JSON line) end to end.  The line says "rehearsal": its numbers are NOT a scaling measurement.
+    rehearsal = os.environ.get("VMLMF_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -315,7 +323,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # a bounded timeout: a rank that never joins a collective makes the others fail instead of waiting for ever
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
 
     from vmlmf_amd import MyLSTM, MyVMLMFCell, Net, _lib
     from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters
@@ -677,7 +688,8 @@ def main():
             "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
             "ms_per_step_min_over_ranks": round(dt_min / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not rehearsal else "synthetic; REHEARSAL: all ranks share GPU 0 over gloo - not a scaling measurement",
             "config": {"workload": ("BASELINE configs[3]: UCI-HAR shape, global batch %d split contiguously over the ranks, "
                                     % args.global_batch if strong else "BASELINE configs[1]: UCI-HAR shape, ")
                                    + f"Net(MyLSTM[MyVMLMFCell]) 1 layer, B={rows_gpu}/GPU T=128 I=9 H=180 w_rank=16 "

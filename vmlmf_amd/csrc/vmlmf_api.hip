@@ -97,7 +97,7 @@ unsigned* status_word() {
 
 const char* status_text(unsigned code) {
   switch (code) {
-    case VMLMF_ST_WRIDE: return "a weight-gradient worker riding on the backward launch never saw its rows' progress words (parameter gradients of that call are NaN)";
+    case VMLMF_ST_WRIDE: return "a weight-gradient worker riding on the backward launch never saw its rows' progress words (parameter gradients of that call are NaN); the workers wait for workgroups of their own launch and need them resident: when the GPU is shared with other processes or launches that fill its CUs, run with VMLMF_WRIDE=0";
     case VMLMF_ST_CLUSTER: return "a member of a row-block cluster never published its partial (outputs of that call are NaN)";
     case VMLMF_ST_WF_FWD: return "a layer of a wavefront forward launch never received the rows of the layer below (outputs are NaN)";
     case VMLMF_ST_WF_BWD: return "a layer of a wavefront backward launch never received the gradient rows of the layer above (gradients are NaN)";
