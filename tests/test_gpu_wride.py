@@ -228,3 +228,27 @@ def test_a_worker_that_gives_up_surfaces_as_an_error_code_not_only_as_nan():
     again = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
     for k in good["G"]:
         assert np.array_equal(again["G"][k], good["G"][k]), k
+
+
+def test_riding_can_be_switched_off_and_rearmed_at_run_time():
+    """vmlmf_tune("wride", 0): the stand-alone weight-gradient kernel behind the recurrence - what the library switches to by
+    itself once a worker has given up under the production bound (a GPU shared with other processes can starve the workers of
+    their rows); vmlmf_tune("wride", 1) re-arms the riding form.  Both against the oracle; the riding form bit-identical before
+    and after."""
+    from vmlmf_amd import _lib
+    variant, B, T, I, H, rw, ru = O.V1, 64, 40, 9, 180, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=6)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT)
+    riding = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    _lib.tune("wride", 0)
+    try:
+        alone = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    finally:
+        _lib.tune("wride", 1)
+    again = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    compare_all(alone, ref, "stand-alone")
+    compare_all(riding, ref, "riding")
+    for k in riding["G"]:
+        assert np.array_equal(again["G"][k], riding["G"][k]), k
+    # the two forms sum in different orders: close, and for this shape not bit-identical (which shows the switch did something)
+    assert any(not np.array_equal(alone["G"][k], riding["G"][k]) for k in riding["G"])

@@ -4,6 +4,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -95,9 +96,18 @@ unsigned* status_word() {
   return g_status[dev];
 }
 
+// looks a riding weight-gradient worker takes at its rows' progress words before it gives up (vmlmf_tune "test_wride_spin": tests)
+constexpr int WRIDE_SPIN_DEFAULT = 1 << 16;
+int g_wride_spin = WRIDE_SPIN_DEFAULT;
+// set when a worker gave up under the production bound: the workers wait for row workgroups of their own launch, which a GPU
+// shared with other processes / launches can keep from getting a CU.  From then on the process takes the
+// stand-alone weight-gradient kernel (plan_wride) instead of failing every step; vmlmf_tune("wride", 1) re-arms the riding form.
+// (Launches already captured into a hipGraph stay what they are.)
+std::atomic<int> g_wride_tripped{0};
+
 const char* status_text(unsigned code) {
   switch (code) {
-    case VMLMF_ST_WRIDE: return "a weight-gradient worker riding on the backward launch never saw its rows' progress words (parameter gradients of that call are NaN); the workers wait for workgroups of their own launch and need them resident: when the GPU is shared with other processes or launches that fill its CUs, run with VMLMF_WRIDE=0";
+    case VMLMF_ST_WRIDE: return "a weight-gradient worker riding on the backward launch never saw its rows' progress words (parameter gradients of that call are NaN); the workers wait for workgroups of their own launch and need them resident: when the GPU is shared with other processes or launches that fill its CUs, run with VMLMF_WRIDE=0 (after this report the process does so by itself for eager launches)";
     case VMLMF_ST_CLUSTER: return "a member of a row-block cluster never published its partial (outputs of that call are NaN)";
     case VMLMF_ST_WF_FWD: return "a layer of a wavefront forward launch never received the rows of the layer below (outputs are NaN)";
     case VMLMF_ST_WF_BWD: return "a layer of a wavefront backward launch never received the gradient rows of the layer above (gradients are NaN)";
@@ -112,6 +122,7 @@ int take_status() {
   const unsigned code = *(volatile unsigned*)w;
   if (code == 0) return 0;
   *(volatile unsigned*)w = 0;
+  if (code == VMLMF_ST_WRIDE && g_wride_spin == WRIDE_SPIN_DEFAULT) g_wride_tripped.store(1);
   return fail(VMLMF_E_PROTOCOL, std::string("an earlier launch on this device gave up a bounded wait: ") + status_text(code));
 }
 // at the end of an entry point under VMLMF_DEBUG_SYNC: the failure of THIS call
@@ -155,7 +166,6 @@ const int g_wride_dry = 0;
 #endif
 // looks a riding worker takes at the progress words before it gives up; vmlmf_tune("test_wride_spin", n) shortens it so that
 // tests can provoke the failure path (NaN gradients + VMLMF_E_PROTOCOL) on purpose
-int g_wride_spin = 1 << 16;
 int g_cus[MAX_DEV] = {0};   // compute units of the device (hipDeviceProp_t::multiProcessorCount), looked up once
 int device_cus() {
   int dev = 0;
@@ -418,7 +428,7 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
                        WRide* w) {
   memset(w, 0, sizeof(*w));
   const int n1 = (vg_nb1(g) + 31) / 32, n2 = (g.G * g.KH + 31) / 32;
-  if (!g_wride || g.rb || g.generic || g.bf || !g.foldx || g.R != 1 || g.NT > 256 || g.B > g_wride_maxb || n1 > 2 || n2 > 2) return;
+  if (!g_wride || g_wride_tripped.load() != 0 || g.rb || g.generic || g.bf || !g.foldx || g.R != 1 || g.NT > 256 || g.B > g_wride_maxb || n1 > 2 || n2 > 2) return;
   const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
   w->a.dpre = wh.dpre, w->a.x = wh.x, w->a.y = wh.y, w->a.h0 = wh.h0, w->a.qx = wh.qx, w->a.dqx = wh.dqx, w->a.Qs = wh.Qs;
   w->a.dQs = wh.dQs, w->a.P = wh.wpart;
@@ -1076,7 +1086,8 @@ int vmlmf_tune(const char* key, int value) {
   const std::string k(key);
   if (k == "rb") g_rb_mode = value;
   else if (k == "rec3") g_rec3 = value;
-  else if (k == "test_wride_spin") g_wride_spin = value < 1 ? (1 << 16) : value;
+  else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
+  else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
   else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;
