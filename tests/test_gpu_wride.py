@@ -252,3 +252,15 @@ def test_riding_can_be_switched_off_and_rearmed_at_run_time():
         assert np.array_equal(again["G"][k], riding["G"][k]), k
     # the two forms sum in different orders: close, and for this shape not bit-identical (which shows the switch did something)
     assert any(not np.array_equal(alone["G"][k], riding["G"][k]) for k in riding["G"])
+
+
+def test_processes_sharing_the_gpu_get_an_error_code_and_recover():
+    """tools/stress_shared_gpu.py: four processes queue forward + backward bursts on ONE GPU.  Their launches overlap, and a
+    riding worker can then wait for rows that other processes' workgroups keep off the CUs (seen about once per 10^4 steps with
+    four processes, within the first hundred with eight).  Whatever happens in a given run, every process must end with exit code
+    0: a give-up is reported as VMLMF_E_PROTOCOL for that step, the process goes on with the stand-alone weight-gradient kernel,
+    and no step without an error code differs from the quiet gradients; nothing hangs."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_shared_gpu.py"), "4", "3"], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "exit codes [0, 0, 0, 0]" in r.stdout
