@@ -1,7 +1,7 @@
 """Randomised parity sweep of the sequence entry point against the fp64 literal oracle (tests/hip_util.py's run_hip /
 run_literal / compare_all at the tolerances of the test suite): shapes, ranks, variants, optional initial states and upstream
 gradients drawn at random from a seed.  Prints every case that fails or that the library refuses, and a summary line.
-    python tools/fuzz_parity.py [cases] [seed] [seq|stack]
+    python tools/fuzz_parity.py [cases] [seed] [seq|stack|rb]
 stack: 2 - 4 like layers through vmlmf_stack (the wavefront launches; initial states of every layer at random) against the
 chained literal layers; stacks the library does not cover (vmlmf_stack returns None) are counted, not run."""
 import os, sys, time, traceback
@@ -18,6 +18,9 @@ SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.Generator(np.random.PCG64(SEED))
 VARIANTS = [O.V1, O.V2, O.V3, O.V4, O.V5, O.V6]
 MODE = sys.argv[3] if len(sys.argv) > 3 else "seq"
+if MODE == "rb":                      # the row-block MFMA kernels wherever an instantiation exists (vmlmf_tune "rb"), else the default choice
+    from vmlmf_amd import _lib
+    _lib.tune("rb", 1)
 
 
 def pick(lo, hi, small=0.5):
