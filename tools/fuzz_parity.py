@@ -1,7 +1,9 @@
 """Randomised parity sweep of the sequence entry point against the fp64 literal oracle (tests/hip_util.py's run_hip /
 run_literal / compare_all at the tolerances of the test suite): shapes, ranks, variants, optional initial states and upstream
 gradients drawn at random from a seed.  Prints every case that fails or that the library refuses, and a summary line.
-    python tools/fuzz_parity.py [cases] [seed] [seq|stack|rb]
+    python tools/fuzz_parity.py [cases] [seed] [seq|stack|rb|big]
+big: batches up to 1100 rows, sequences up to 200 steps, H up to 700 (more rows than CUs, the stand-alone weight-gradient
+kernels, the clustered layers)
 stack: 2 - 4 like layers through vmlmf_stack (the wavefront launches; initial states of every layer at random) against the
 chained literal layers; stacks the library does not cover (vmlmf_stack returns None) are counted, not run."""
 import os, sys, time, traceback
@@ -44,6 +46,18 @@ def draw():
     rw = pick(1, 32, 0.3)             # the kernels cover padded ranks up to 32 (beyond: VMLMF_E_UNSUPPORTED, by design)
     ru = [pick(1, 32, 0.3), pick(1, 32, 0.3)] if group else pick(1, 32, 0.3)
     B, T = pick(1, 200, 0.4), pick(1, 40, 0.4)
+    if MODE == "big":
+        B, T = int(rng.integers(64, 1101)), int(rng.integers(16, 201))
+        H = int(rng.integers(32, 701)) + (0 if not group else 0)
+        if group and H % 2:
+            H += 1
+        if lm:
+            H = min(H, 660)
+            I = H
+        else:
+            I = int(rng.integers(2, (150 if novm else min(H, 150)) + 1))
+        while B * T * H > 24_000_000:      # keeps the float64 oracle of a case within seconds
+            T = max(8, T // 2)
     if v == O.V4 and B == 1:
         B = 2                         # (B = 1: the reference's squeeze() in vmlmf_lm.py:257 drops the batch dimension and the layer raises)
     return dict(v=v, B=B, T=T, I=I, H=H, rw=rw, ru=ru, states=bool(rng.random() < 0.5), tm=bool(rng.random() < 0.3),
