@@ -667,7 +667,10 @@ def main():
         # (no wgrad_mfma_kernel launch in the breakdown pass) also does their products: dpre^T x, dpre^T Q, h^T dQ
         riding = dom == "rec_bwd_kernel" and kern.get("wgrad_mfma_kernel", 0.0) == 0.0
         F_WG = 2 * 4 * H * I + 2 * 4 * H * RU + 2 * H * RU
-        flops = rows * (F_H + (F_WG if riding else 0))
+        # a forward launch whose x-projection wave forms the input side itself (no xproj_kernel launch in the breakdown pass) does
+        # the forward's whole algorithmic work, section 8d's F = 2 I rw + 8 H rw + 10 H ru per sample-step
+        x_inside = dom == "rec_fwd_kernel" and kern.get("xproj_kernel", 0.0) == 0.0
+        flops = rows * (F_H + (F_WG if riding else 0) + (F_X if x_inside else 0))
         achieved = flops / (rec[dom] * 1e-6) / 1e12
         achieved_rec = rows * F_H / (rec[dom] * 1e-6) / 1e12      # the recurrence's own 10 H ru per sample-step only
         # workgroups of the dominant launch, one per CU (the launch asks for more than half a CU's LDS): the rows' (vmlmf_query)
@@ -725,6 +728,8 @@ def main():
                          "flops_per_launch": flops,
                          "contains": ("recurrence (10 H ru per sample-step) + the weight-gradient products riding on the launch "
                                       "(8 H I + 8 H ru + 2 H ru per sample-step, on otherwise idle CUs)") if riding else
+                                     ("the forward's algorithmic work of SURVEY section 8d: input side 2 I rw + 8 H rw (formed by the "
+                                      "launch's x-projection wave) + recurrence 10 H ru per sample-step") if x_inside else
                                      "recurrence (10 H ru per sample-step)",
                          "measured": "HIP event pairs on the launch stream over the eager timed region of the same K "
                                      "steps (events cannot be read inside a replayed hipGraph)",
