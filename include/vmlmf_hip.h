@@ -109,6 +109,13 @@ const char *vmlmf_last_error(void);
  *   "rb_cluster"    workgroups a 16-row block's hidden units are split over for layers beyond one CU (0 = automatic)
  *   "rb_rows"       live batch rows of a row-block workgroup: 16, 8 or 4 of the 16 MFMA columns (0 = automatic); fewer rows
  *                   = more workgroups, each streaming fewer tape bytes through its CU
+ *   "rec3"          bit mask of the round-3 recurrent kernels (default 6): 1 forward always, 2 backward, 4 forward when the
+ *                   batch has more rows than the device CUs
+ *   "wride"         1 (default): the weight-gradient products ride on the backward recurrence's launch where they fit;
+ *                   0: always the stand-alone kernel behind it.  The library sets 0 by itself after a riding worker gave up
+ *                   its bounded wait (VMLMF_E_PROTOCOL; a GPU shared with other processes can starve the workers of their
+ *                   rows); 1 re-arms
+ *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)
  */
 int vmlmf_tune(const char *key, int value);
 
