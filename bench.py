@@ -427,7 +427,9 @@ def main():
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             net.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
+            # with a process group alive its watchdog thread may call into the runtime while this thread captures: thread-local
+            # capture mode keeps such calls from invalidating the capture (the capturing thread's own rules are unchanged)
+            with torch.cuda.graph(graph, capture_error_mode="thread_local" if collective else "global"):
                 out = body()
             return graph, out
 
