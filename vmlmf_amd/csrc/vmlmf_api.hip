@@ -42,9 +42,10 @@ struct Scope {
   Scope(int which, hipStream_t st) : k(which), s(st) {
     if (g_debug_sync) fprintf(stderr, "[vmlmf] launching %s\n", kernel_label(which));
     if ((g_prof.mask >> which) & 1u) {
-      hipEventCreate(&e0);
-      hipEventCreate(&e1);
-      hipEventRecord(e0, s);
+      // (profiling instrumentation: an event that could not be made or recorded shows up as a missing / zero sample)
+      (void)hipEventCreate(&e0);
+      (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, s);
     }
   }
   ~Scope() {
@@ -53,7 +54,7 @@ struct Scope {
       fprintf(stderr, "[vmlmf] %s done: %s\n", kernel_label(k), hipGetErrorString(e));
     }
     if (e0 != nullptr) {
-      hipEventRecord(e1, s);
+      (void)hipEventRecord(e1, s);
       std::lock_guard<std::mutex> lk(g_prof.mu);
       g_prof.ev[k].push_back({e0, e1});
     }
@@ -1167,17 +1168,17 @@ int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   for (int k = 0; k < NKERN; ++k) {
     float sum = 0.f;
     for (auto& pr : g_prof.ev[k]) {
-      hipEventSynchronize(pr.second);
+      (void)hipEventSynchronize(pr.second);
       float ms = 0.f;
-      hipEventElapsedTime(&ms, pr.first, pr.second);
+      (void)hipEventElapsedTime(&ms, pr.first, pr.second);
       sum += ms * 1000.f;
     }
     if (usec_sum != nullptr) usec_sum[k] = sum;
     if (count != nullptr) count[k] = (int32_t)g_prof.ev[k].size();
     if (reset) {
       for (auto& pr : g_prof.ev[k]) {
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
       }
       g_prof.ev[k].clear();
     }
