@@ -188,15 +188,20 @@ __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
 //      a base, more spills).  The instantiations whose scalar registers do spill around the stores set SAFE (see the
 //      SAFE_ST constants of the kernels), and tools/check_asm_hazards.py, run by the CPU tests on the built library,
 //      disassembles every kernel and fails on either hazard at any store with a scalar base.
-template <bool SAFE = false>
+// NT: the non-temporal hint (streamed data nobody re-reads soon: the forward's tape, 41 MB per launch at the headline shape - ten
+// times the L2 of an XCD; rec_fwd_kernel's storer 69.1 -> 67.5 us, 0.1566 -> 0.1559 ms per step same-box, tools/sessions/r03y6.sh)
+template <bool SAFE = false, bool NT = false>
 __device__ __forceinline__ void st4_sv(const void* sbase, unsigned voff, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};
-  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  static_assert(!(SAFE && NT), "no instantiation needs both");
+  if constexpr (NT) asm volatile("global_store_dwordx4 %0, %1, %2 nt\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+  else if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
   else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
 }
-template <bool SAFE = false>
+template <bool SAFE = false, bool NT = false>
 __device__ __forceinline__ void st1_sv(const void* sbase, unsigned voff, float v) {
-  if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  if constexpr (NT) asm volatile("global_store_dword %0, %1, %2 nt" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
+  else if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
   else asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
 // system-scope write-through variants (sc0 sc1): rows another workgroup, possibly on another XCD, consumes during the launch
