@@ -148,6 +148,12 @@ int main(int argc, char** argv) {
       printf("rec3 bwd, storer idle        %8.2f us\n", run3_bwd<2048>(g, b, 50));
       printf("rec3 bwd, loader idle        %8.2f us\n", run3_bwd<4096>(g, b, 50));
       printf("rec3 bwd, both idle          %8.2f us\n", run3_bwd<6144>(g, b, 50));
+      printf("rec3 bwd instrumented (256)  %8.2f us\n", run3_bwd<256>(g, b, 20));
+      float tb[64];
+      CK(hipMemcpy(tb, a.trash + 64, sizeof(tb), hipMemcpyDeviceToHost));
+      for (int w = 0; w < 3; ++w)
+        printf("rec3 bwd wave %d memtime ticks/step:  derivs+fold %.0f  rotate-add+rowsum+write %.0f  prepare %.0f  barrier %.0f  read+total+expansion %.0f  step total %.0f\n",
+               w, tb[w * 8 + 0], tb[w * 8 + 1], tb[w * 8 + 2], tb[w * 8 + 3], tb[w * 8 + 4], tb[w * 8 + 5]);
     }
     return 0;
   }
