@@ -281,6 +281,12 @@ def main():
                          "inference / gradient accumulation; a training loop re-packs every step, which is the default)")
     ap.add_argument("--global-batch", type=int, default=0,
                     help="strong scaling: this many rows in total, split contiguously over the ranks (configs[3]: 512)")
+    ap.add_argument("--config", choices=("A", "E"), default="A",
+                    help="A: the headline (BASELINE configs[1], and [3] with --global-batch).  E: BASELINE configs[4], the PTB LM "
+                         "network data-parallel (tools/bench_lm.py: run_config_e) - global batch 256 unless --global-batch / "
+                         "--batch-per-gpu say otherwise; its line is NOT the graded metric")
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="config E: weak scaling with this many rows per GPU")
+    ap.add_argument("--plain-layers", action="store_true", help="config E: MyVMLSTM layers instead of MyVMLSTMGroup")
     ap.add_argument("--transport", choices=("auto", "cabi", "torch"), default="auto",
                     help="gradient all-reduce through the C ABI (vmlmf_flat_allreduce_group, RCCL) or torch.distributed "
                          "(backend nccl = RCCL).  auto: torch.distributed with more than one rank (the C-ABI communicator has "
@@ -301,7 +307,7 @@ def main():
     if args.gpus != world:
         print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     strong = args.global_batch > 0
-    if strong and args.global_batch % world != 0:
+    if args.config == "A" and strong and args.global_batch % world != 0:
         raise SystemExit(f"--global-batch {args.global_batch} is not divisible by {world} ranks")
     rows_gpu = args.global_batch // world if strong else B_PER_GPU      # batch rows of this rank
     batches_per_step = (args.global_batch / B_PER_GPU) if strong else world   # 64-row batches one step processes
@@ -327,6 +333,22 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=300))
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=300))
+
+    if args.config == "E":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_lm
+
+        def e_barrier():
+            if collective:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        bench_lm.run_config_e(args, {"world": world, "rank": rank, "dev": dev, "collective": collective, "rehearsal": rehearsal,
+                                     "result_fd": result_fd, "barrier": e_barrier,
+                                     "log": lambda m: rank == 0 and print(f"[bench] {m}", file=sys.stderr, flush=True)})
+        if collective:
+            dist.destroy_process_group()
+        return
 
     from vmlmf_amd import MyLSTM, MyVMLMFCell, Net, _lib
     from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters
@@ -587,6 +609,16 @@ def main():
         dist.all_reduce(tar, op=dist.ReduceOp.MAX)
         allreduce_ms = float(tar.item())
 
+    # every rank must hold the SAME reduced gradients after the exchange: the norm each rank computes has to agree bit for bit
+    grads_equal = None
+    if collective:
+        step()
+        gn = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in net.parameters() if p.grad is not None)).reshape(1)
+        ghi, glo = gn.clone(), gn.clone()
+        dist.all_reduce(ghi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(glo, op=dist.ReduceOp.MIN)
+        grads_equal = bool(torch.isfinite(ghi).item() and ghi.item() == glo.item())
+
     # optimizer, outside the metric (train.py:47,65): the stock one and the package's single-launch one, and the
     # whole training step (forward + loss + backward + optimizer) replayed from one hipGraph
     def time_opt(opt):
@@ -628,7 +660,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tmin, op=dist.ReduceOp.MIN)
     dt, dt_min = float(tmax.item()), float(tmin.item())
-    rccl_ranks = reducer.rccl_ranks() if collective else None
+    rccl_ranks, ranks_counted_by = reducer.exchange_ranks() if collective else (None, None)
     collectives_per_step = reducer.last_collectives if collective else 0
     ms_per_step = dt / args.steps * 1e3
     value = batches_per_step * T * args.steps / dt
@@ -707,7 +739,12 @@ def main():
                        "parallelism": f"dp{world}", "scaling": "strong" if strong else "weak",
                        "value_counts": "64-row batches x T timesteps per second",
                        "allreduce_transport": reducer.transport_used() if collective else None,
-                       "rccl_ranks": rccl_ranks, "collectives_per_step": collectives_per_step,
+                       # ranks of the gradient exchange and WHO counted them: RCCL itself (ncclCommCount, C-ABI transport) or only
+                       # the size of the torch.distributed group (backend named: over gloo there is no RCCL communicator)
+                       "exchange_ranks": rccl_ranks, "exchange_ranks_counted_by": ranks_counted_by,
+                       "rccl_ranks": rccl_ranks if "nccl" in (ranks_counted_by or "") else None,
+                       "collectives_per_step": collectives_per_step,
+                       "reduced_grad_norm_equal_across_ranks": grads_equal,
                        "launch": launch_mode,
                        "parameter_images": "kept while the parameters are unchanged (--keep-images)" if args.keep_images else
                                            "packed inside every step (what a training loop sees)",

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 8
+#define VMLMF_ABI_VERSION 9
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -311,6 +311,21 @@ int vmlmf_adam_step(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp
                     float beta1, float beta2, float eps, float weight_decay, void *stream);
 int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_norm, float *norm, float *scratch,
                         void *stream);
+/* ABI 9: non-finite gradients never reach the parameters.  A launch that gave up a bounded wait leaves NaN gradients and the
+ * host learns of it one call later (VMLMF_E_PROTOCOL) - inside a replayed hipGraph not at all - so the decision is taken on
+ * the device:
+ *   vmlmf_adam_step_guarded  `guard`: VMLMF_GUARD_WORDS zero-initialised uint32 device words the caller keeps between steps
+ *                            (NULL = vmlmf_adam_step).  A gate launch scans every listed gradient; if any value is Inf / NaN
+ *                            the whole step is skipped: no step counter ticks, parameters and moments keep their values,
+ *                            guard[VMLMF_GUARD_SKIPPED] counts it (guard[VMLMF_GUARD_GO] = 0 for that step).  One call =
+ *                            one gate: models of more than VMLMF_MAX_TENSORS tensors are gated per call.
+ *   vmlmf_sgd_clip_step      skips the step (parameters and gradients untouched) when the total norm is not finite; `norm`
+ *                            carries the non-finite value back to the caller. */
+#define VMLMF_GUARD_WORDS 72
+#define VMLMF_GUARD_GO 64
+#define VMLMF_GUARD_SKIPPED 66
+int vmlmf_adam_step_guarded(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp_avg_sq, float *steps, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, void *guard, void *stream);
 
 /*
  * Data-parallel gradient exchange (no reference line: the reference has no distributed

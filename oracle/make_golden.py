@@ -334,14 +334,15 @@ def case_flop_counts(name="flop_counts"):
     print(f"{name:28s} ok")
 
 
-def case_lm_model(name="lm_model_v3"):
-    """The whole LM network of lm_test.py (vmlmf_lm.py:366-440, lstm_type "vmlmf", dropout 0) on two consecutive
-    minibatches of the training loop (lm_test.py:196-209): scores, nll_loss, gradients, clip + SGD step, carried states."""
+def case_lm_model(name="lm_model_v3", lstm_type="vmlmf"):
+    """The whole LM network of lm_test.py (vmlmf_lm.py:366-440, lstm_type "vmlmf" - or "custom", the dense baseline layer -
+    dropout 0) on two consecutive minibatches of the training loop (lm_test.py:196-209): scores, nll_loss, gradients,
+    clip + SGD step, carried states."""
     from models.vmlmf_lm import Model
     from train_test.lm_test import nll_loss
     V, H, L, B, T = 60, 16, 2, 4, 5
     torch.manual_seed(7)
-    model = Model(V, H, L, 0.0, 0.1, w_rank=4, u_ranks=[5], lstm_type="vmlmf")
+    model = Model(V, H, L, 0.0, 0.1, w_rank=4, u_ranks=[5], lstm_type=lstm_type)
     init = {k: v.detach().numpy().copy() for k, v in model.state_dict().items()}
     r = rng_of(61)
     out = dict(meta=np.array([V, H, L, B, T, 4, 5]), init=init)
@@ -418,6 +419,7 @@ CASES = {
     "state_dict_names": lambda n: case_state_dict_names(n),
     "flop_counts": lambda n: case_flop_counts(n),
     "lm_model_v3": lambda n: case_lm_model(n),
+    "lm_model_custom": lambda n: case_lm_model(n, lstm_type="custom"),
     "nll_v10000": lambda n: case_nll(n),
 }
 

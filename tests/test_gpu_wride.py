@@ -264,3 +264,148 @@ def test_processes_sharing_the_gpu_get_an_error_code_and_recover():
                        text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "exit codes [0, 0, 0, 0]" in r.stdout
+
+
+def _har_net(seed=0):
+    from vmlmf_amd import MyLSTM, MyVMLMFCell, Net
+    torch.manual_seed(seed)
+    net = Net(9, layer_sizes=[180], w_rank=16, u_rank=[16], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    x = torch.randn(64, 40, 9, device="cuda")
+    t = torch.randint(0, 18, (64,), device="cuda")
+    return net, x, t
+
+
+def _clear_status():
+    from vmlmf_amd import _lib
+    torch.cuda.synchronize()
+    try:
+        _lib.check_status()
+    except _lib.VmlmfError:
+        pass
+
+
+def test_nan_gradients_of_a_failed_step_never_reach_the_parameters():
+    """nothing between a failing backward and the optimizer looked at the status word, so the NaN gradients
+    of step N were applied before step N+1's forward raised.  The optimizers now decide on the device: vmlmf_amd.optim.Adam's
+    gate launch skips the whole step (parameters, moments, step counts untouched, skipped_steps() == 1), clip_sgd_step skips
+    on a non-finite norm; the steps around the failed one are ordinary Adam steps (same trajectory as torch.optim.Adam with
+    that step dropped)."""
+    import vmlmf_amd
+    from vmlmf_amd import _lib
+    net, x, t = _har_net()
+    ref, _, _ = _har_net()
+    opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.01)
+    ropt = torch.optim.Adam(ref.parameters(), lr=0.01)
+
+    def step(m, o, update=True):
+        m.zero_grad(set_to_none=True)
+        vmlmf_amd.cross_entropy(m(x), t).backward()
+        if update:
+            o.step()
+
+    step(net, opt), step(ref, ropt)
+    held = [p.detach().clone() for p in net.parameters()]
+    _lib.tune("test_wride_spin", 1)
+    try:
+        step(net, opt)                                   # the riding workers give up: NaN parameter gradients
+        torch.cuda.synchronize()
+        assert not torch.isfinite(net.rnn.rnncells[0].v_h.grad).all(), "the workers were expected to give up"
+        for p, h in zip(net.parameters(), held):
+            assert torch.equal(p.detach(), h)                # the update was skipped on the device
+        assert opt.skipped_steps() == 1
+        assert all(float(st["step"]) == 1.0 for st in opt.state.values())
+        # the LM loop's update on the same NaN gradients: skipped as well, and the norm says why
+        live = [p for p in net.parameters() if p.grad is not None]
+        gheld = [p.grad.clone() for p in live]
+        norm = vmlmf_amd.optim.clip_sgd_step(live, lr=1.0, max_norm=5.0)
+        assert not torch.isfinite(norm)
+        for p, h in zip(net.parameters(), held):
+            assert torch.equal(p.detach(), h)
+        for p, gh in zip(live, gheld):
+            assert torch.equal(torch.nan_to_num(p.grad, nan=7.0), torch.nan_to_num(gh, nan=7.0))    # gradients not scaled either
+    finally:
+        _lib.tune("test_wride_spin", 0)
+        _clear_status()
+    step(net, opt), step(ref, ropt)                      # step 2 of the trajectory, as if the failed one had not happened
+    for (k, p), q in zip(net.named_parameters(), ref.parameters()):
+        assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), k
+    assert opt.skipped_steps() == 1
+
+
+def test_graphed_train_step_captures_again_after_a_failed_replay():
+    """Verdict r3 item 6: a launch captured into a hipGraph stays what it was - after a give-up every replay would produce NaN
+    again.  GraphedTrainStep reads the status word in front of every replay: the failed step's update is skipped by the
+    optimizer's gate (parameters intact), the step is captured again (here: with the production wait bound restored), and
+    training goes on; the tune generation alone (kernel selection changed, nothing failed) re-captures as well."""
+    import warnings
+    import vmlmf_amd
+    from vmlmf_amd import _lib
+    net, x, t = _har_net(1)
+    opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.01)
+    _clear_status()
+    gstep = vmlmf_amd.GraphedTrainStep(net, vmlmf_amd.cross_entropy, opt, x, t)
+    gstep(x, t)
+    torch.cuda.synchronize()
+    assert getattr(gstep, "recaptures", 0) == 0 and opt.skipped_steps() == 0
+    held = [p.detach().clone() for p in net.parameters()]
+    _lib.tune("test_wride_spin", 1)      # (moves the generation: the step is captured again, now with a one-look wait inside)
+    try:
+        gstep(x, t)                      # capture (executes nothing), replay: the riding workers give up
+        torch.cuda.synchronize()
+        assert gstep.recaptures == 1
+        for p, h in zip(net.parameters(), held):
+            assert torch.equal(p.detach(), h)            # the failed step's update never happened
+        assert opt.skipped_steps() == 1
+    finally:
+        _lib.tune("test_wride_spin", 0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        loss = gstep(x, t)                               # sees E_PROTOCOL of the replay before: captures again, then steps
+    torch.cuda.synchronize()
+    assert gstep.failed_steps == 1 and gstep.recaptures == 2 and any("captured again" in str(m.message) for m in w)
+    assert torch.isfinite(loss) and opt.skipped_steps() == 1
+    assert any(not torch.equal(p.detach(), h) for p, h in zip(net.parameters(), held))      # this one did update
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    _lib.tune("wride", 0)                                # kernel selection changes, nothing failed: generation moves
+    try:
+        gstep(x, t)
+        assert gstep.recaptures == 3 and gstep.failed_steps == 1
+    finally:
+        _lib.tune("wride", 1)
+    gstep(x, t)
+    torch.cuda.synchronize()
+    assert gstep.recaptures == 4 and all(torch.isfinite(p).all() for p in net.parameters())
+    _lib.check_status()
+
+
+def test_status_word_is_not_lost_when_the_first_call_on_a_device_is_captured():
+    """the first library call of a process made inside a stream capture must not disable status reporting for
+    good (the word's allocation is skipped for that call only).  Run in a fresh process: capture first, then provoke a give-up
+    eagerly and expect the error code."""
+    code = (
+        "import sys; sys.path[:0] = [%r]\n"
+        "import torch, vmlmf_amd\n"
+        "from vmlmf_amd import _lib, MyLSTM, MyVMLMFCell, Net\n"
+        "torch.manual_seed(0)\n"
+        "net = Net(9, layer_sizes=[180], w_rank=16, u_rank=[16], model=MyLSTM, cell=MyVMLMFCell).cuda()\n"
+        "x = torch.randn(64, 40, 9, device='cuda'); t = torch.randint(0, 18, (64,), device='cuda')\n"
+        "def fb():\n"
+        "    net.zero_grad(set_to_none=True)\n"
+        "    vmlmf_amd.cross_entropy(net(x), t).backward()\n"
+        "z = torch.randn(4, 6, device='cuda', requires_grad=True)      # loads the library's code object; touches no status word\n"
+        "vmlmf_amd.cross_entropy(z, torch.zeros(4, dtype=torch.long, device='cuda')).backward()\n"
+        "torch.cuda.synchronize()\n"
+        "g = torch.cuda.CUDAGraph()\n"
+        "with torch.cuda.graph(g):\n"
+        "    fb()                           # the first forward / backward entry points of the process: inside a capture\n"
+        "g.replay(); torch.cuda.synchronize()\n"
+        "assert all(torch.isfinite(p.grad).all() for p in net.parameters() if p.grad is not None)\n"
+        "_lib.tune('test_wride_spin', 1)\n"
+        "fb(); torch.cuda.synchronize()\n"
+        "try:\n"
+        "    _lib.check_status()\n"
+        "    print('no error reported')\n"
+        "except _lib.VmlmfError as e:\n"
+        "    print('ok' if e.code == _lib.E_PROTOCOL else 'wrong code')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]

@@ -165,10 +165,7 @@ def test_lm_network_surface_matches_reference():
     with pytest.raises(TypeError):
         Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vmgroup")
     assert type(Model(V, H, 1, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vm_group").rnns[0]) is torch.nn.LSTM
-    # the dense baseline layer is the caller's own class (the reference's LSTM is not re-implemented: out of scope); the
-    # network around it runs on CPU in stock ops, and so does the loss there
-    with pytest.raises(ValueError, match="dense_layer"):
-        Model(V, H, L, 0.0, 0.1, lstm_type="custom")
+    # dense_layer= overrides the class built for lstm_type="custom" (default: vmlmf_amd.LSTM, tested against the reference below)
 
     class Dense(torch.nn.Module):          # stand-in with the reference's layer interface
         def __init__(self, i, h):
@@ -187,3 +184,34 @@ def test_lm_network_surface_matches_reference():
     y = torch.tensor(d["y0"])
     want = -torch.log_softmax(z, 1)[torch.arange(T * B), y.reshape(-1)].mean() * B
     assert torch.allclose(nll_loss(z, y), want, rtol=1e-5)
+
+
+def test_dense_baseline_network_matches_the_reference():
+    """Model(lstm_type="custom") (lm_test.py:52 offers it) builds the dense baseline layer of vmlmf_lm.py:283-339 - stock ops,
+    off the VMLMF path, runs wherever the tensors are: two minibatches of the LM loop against the reference's own run."""
+    from vmlmf_amd import LSTM, Model, nll_loss
+    d = load_golden("lm_model_custom")
+    V, H, L, B, T, _, _ = (int(v) for v in d["meta"])
+    torch.manual_seed(7)
+    m = Model(V, H, L, 0.0, 0.1, lstm_type="custom")
+    assert all(type(r) is LSTM for r in m.rnns) and list(m.state_dict()) == list(d["init"])
+    for k, v in m.state_dict().items():
+        assert np.array_equal(v.numpy(), d["init"][k]), k
+    states = m.state_init(B)
+    for i in range(2):
+        m.zero_grad()
+        states = m.detach(states)
+        scores, states = m(torch.tensor(d[f"x{i}"]), states)
+        loss = nll_loss(scores, torch.tensor(d[f"y{i}"]))
+        loss.backward()
+        assert np.allclose(scores.detach().numpy(), d[f"scores{i}"], atol=2e-6, rtol=1e-5)
+        assert abs(loss.item() - float(d[f"loss{i}"][0])) < 1e-5 * abs(loss.item())
+        for k, p in m.named_parameters():
+            g = d[f"G{i}"][k]
+            assert np.abs(p.grad.numpy() - g).max() <= 1e-5 * max(np.abs(g).max(), 1e-6), k
+        with torch.no_grad():
+            norm = torch.nn.utils.clip_grad_norm_(m.parameters(), 0.25)
+            for p in m.parameters():
+                p -= 1.0 * p.grad
+        assert abs(float(norm) - float(d[f"norm{i}"][0])) < 1e-5 * float(norm)
+    assert np.allclose(torch.stack([s[0] for s in states]).detach().numpy(), d["hT"], atol=2e-6, rtol=1e-4)

@@ -19,12 +19,20 @@ def child(idx, seconds):
     t = torch.randint(0, 18, (64,), device="cuda")
     one = vmlmf_amd.unit_gradient("cuda")
 
-    def step():
+    # an optimizer step behind every backward, as a training loop has it: lr = 0 leaves finite parameters where they are (so
+    # the comparison with the quiet gradients below stays valid) but would turn them into NaN if a failing step's NaN gradients
+    # ever reached the update (0 * NaN); the device-side gate of vmlmf_amd.optim.Adam has to skip exactly those steps
+    opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.0)
+    before = [p.detach().clone() for p in net.parameters()]
+
+    def step(update=True):
         net.zero_grad(set_to_none=True)
         vmlmf_amd.cross_entropy(net(x), t).backward(one)
+        if update:
+            opt.step()
 
     _lib.tune("wride", 0)          # the reference gradients: stand-alone weight-gradient kernel, nothing waits for anything
-    step()
+    step(update=False)
     torch.cuda.synchronize()
     quiet = [p.grad.clone() for p in net.parameters() if p.grad is not None]
     _lib.tune("wride", 1)
@@ -54,7 +62,21 @@ def child(idx, seconds):
             if not torch.isfinite(a).all() or (a - b).abs().max() > 5e-5 * (b.abs().max() + 1e-30):
                 print(f"[{idx}] step {steps}: a gradient differs from the quiet run WITHOUT an error code", flush=True)
                 sys.exit(3)
-    print(f"[{idx}] {steps} steps, {errors} reported VMLMF_E_PROTOCOL, {after} good steps after the first report", flush=True)
+    torch.cuda.synchronize()
+    skipped = opt.skipped_steps()
+    for p, b in zip(net.parameters(), before):
+        if not torch.equal(p.detach(), b):
+            print(f"[{idx}] a parameter changed or went non-finite: NaN gradients reached the optimizer", flush=True)
+            sys.exit(4)
+    for st in opt.state.values():
+        if not (torch.isfinite(st["exp_avg"]).all() and torch.isfinite(st["exp_avg_sq"]).all()):
+            print(f"[{idx}] optimizer moments are not finite", flush=True)
+            sys.exit(4)
+    if (errors > 0) != (skipped > 0):
+        print(f"[{idx}] {errors} reported failures but the optimizer's gate skipped {skipped} steps", flush=True)
+        sys.exit(5)
+    print(f"[{idx}] {steps} steps, {errors} reported VMLMF_E_PROTOCOL, {after} good steps after the first report, "
+          f"{skipped} optimizer steps skipped by the device-side gate, parameters intact", flush=True)
 
 
 if __name__ == "__main__":

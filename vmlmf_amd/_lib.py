@@ -18,7 +18,8 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 8
+ABI_VERSION = 9
+GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM, E_PROTOCOL = -1, -2, -3, -4, -5, -6
@@ -110,6 +111,8 @@ SYMBOLS = {
     "vmlmf_nll_backward": (_i, [_i, _i, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),
     "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
+    "vmlmf_adam_step_guarded": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                                     ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
     "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "vmlmf_comm_unique_id": (_i, [_vp]),
     "vmlmf_comm_init": (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),
@@ -160,7 +163,24 @@ def lib():
         if handle.vmlmf_abi_version() != ABI_VERSION:
             raise RuntimeError("libvmlmf_hip.so ABI version mismatch: rebuild")
         _lib = handle
+        if ranks_share_a_device() and "VMLMF_WRIDE" not in os.environ:
+            # the riding weight-gradient workers wait for row workgroups of their own launch; when several processes queue
+            # launches on ONE device a resident worker can starve the rows it waits for: such jobs
+            # start on the stand-alone weight-gradient kernel instead of finding out through a failed step
+            handle.vmlmf_tune(b"wride", 0)
     return _lib
+
+
+def ranks_share_a_device():
+    """True when the launcher's environment says more local ranks than visible devices (torchrun: LOCAL_WORLD_SIZE)."""
+    try:
+        local = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+    except ValueError:
+        return False
+    if local <= 1:
+        return False
+    import torch
+    return local > max(torch.cuda.device_count(), 1)
 
 
 def tune(key, value):

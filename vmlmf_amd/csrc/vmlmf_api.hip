@@ -72,29 +72,45 @@ long long align64(long long v) { return (v + 63) / 64 * 64; }
 // VMLMF_E_PROTOCOL from the next call (under VMLMF_DEBUG_SYNC from the failing call itself); vmlmf_check_status() after a
 // synchronisation tells at once.
 constexpr int MAX_DEV = 16;
-unsigned* g_status[MAX_DEV] = {nullptr};
-bool g_status_tried[MAX_DEV] = {false};
+std::atomic<unsigned*> g_status[MAX_DEV];
+std::atomic<bool> g_status_failed[MAX_DEV];   // the allocation itself failed (not: was skipped because of a capture)
 std::mutex g_status_mu;
 
-unsigned* status_word() {
+// `s`: the stream the caller is about to launch on.  The first call on a device allocates the word; that allocation is not
+// capturable, so a first call made while `s` is being captured returns NULL WITHOUT remembering anything (the launch simply
+// carries no word; the next call outside a capture allocates it).  Torch captures on a side stream, never the null stream:
+// the caller's own stream is what has to be asked.
+unsigned* status_word(hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
-  if (g_status[dev] != nullptr || g_status_tried[dev]) return g_status[dev];
+  unsigned* w = g_status[dev].load(std::memory_order_acquire);
+  if (w != nullptr || g_status_failed[dev].load(std::memory_order_acquire)) return w;
   std::lock_guard<std::mutex> lk(g_status_mu);
-  if (g_status[dev] == nullptr && !g_status_tried[dev]) {
-    g_status_tried[dev] = true;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    void* p = nullptr;
-    // (not from inside a stream capture: the allocation is not capturable; such a process simply runs without the word)
-    if (hipStreamIsCapturing(nullptr, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone &&
-        hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p != nullptr) {
-      memset(p, 0, 64);
-      g_status[dev] = (unsigned*)p;
-    } else {
-      (void)hipGetLastError();
-    }
+  w = g_status[dev].load(std::memory_order_acquire);
+  if (w != nullptr || g_status_failed[dev].load(std::memory_order_acquire)) return w;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cs) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  if (cs != hipStreamCaptureStatusNone) return nullptr;          // not now; nothing is latched
+  // another thread of the process may be capturing in global mode: the allocation must not invalidate its capture
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+  void* p = nullptr;
+  const bool ok = hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p != nullptr;
+  if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+  if (ok) {
+    memset(p, 0, 64);
+    g_status[dev].store((unsigned*)p, std::memory_order_release);
+    return (unsigned*)p;
   }
-  return g_status[dev];
+  (void)hipGetLastError();
+  g_status_failed[dev].store(true, std::memory_order_release);
+  return nullptr;
+}
+// the word if it exists already (host-side readers: never allocates)
+unsigned* status_word_if_any() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  return g_status[dev].load(std::memory_order_acquire);
 }
 
 // looks a riding weight-gradient worker takes at its rows' progress words before it gives up (vmlmf_tune "test_wride_spin": tests)
@@ -117,13 +133,14 @@ const char* status_text(unsigned code) {
 }
 
 // 0, or VMLMF_E_PROTOCOL with the text of the failure an earlier launch on this device reported (the word is cleared)
+int g_tune_generation = 0;                        // bumped by every vmlmf_tune() and by the automatic switch below: kept parameter images / captured graphs of an older one are stale
 int take_status() {
-  unsigned* w = status_word();
+  unsigned* w = status_word_if_any();
   if (w == nullptr) return 0;
   const unsigned code = *(volatile unsigned*)w;
   if (code == 0) return 0;
   *(volatile unsigned*)w = 0;
-  if (code == VMLMF_ST_WRIDE && g_wride_spin == WRIDE_SPIN_DEFAULT) g_wride_tripped.store(1);
+  if (code == VMLMF_ST_WRIDE && g_wride_spin == WRIDE_SPIN_DEFAULT && g_wride_tripped.exchange(1) == 0) ++g_tune_generation;
   return fail(VMLMF_E_PROTOCOL, std::string("an earlier launch on this device gave up a bounded wait: ") + status_text(code));
 }
 // at the end of an entry point under VMLMF_DEBUG_SYNC: the failure of THIS call
@@ -193,7 +210,6 @@ int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgro
 // batch rows than CUs (rec3_fwd_kernel needs ~170 VGPRs, two workgroups share a CU; rec_fwd_kernel's x-projection wave needs
 // 256, so its workgroups run in rounds: measured B = 512 138 -> 104 us, 0.402 -> 0.370 ms per step; up to B = 256 the two tie)
 int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 6; }();
-int g_tune_generation = 0;                        // bumped by every vmlmf_tune(): kept parameter images of an older one are stale
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -426,7 +442,7 @@ static WghArgs wgrad_args(const Layout& L, const float* x, const float* y, const
 // gradient folds into the dpre product (no dqx operand, which only exists after that launch), with few enough batch rows that
 // most of the chip is idle during the recurrence.  Fills w (K = 0: no).
 static void plan_wride(const VGeo& g, const Layout& L, const float* x, const float* y, const float* h0, const float* rs, float* ws,
-                       WRide* w) {
+                       WRide* w, hipStream_t s) {
   memset(w, 0, sizeof(*w));
   const int n1 = (vg_nb1(g) + 31) / 32, n2 = (g.G * g.KH + 31) / 32;
   if (!g_wride || g_wride_tripped.load() != 0 || g.rb || g.generic || g.bf || !g.foldx || g.R != 1 || g.NT > 256 || g.B > g_wride_maxb || n1 > 2 || n2 > 2) return;
@@ -455,7 +471,7 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
   w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
   w->dry = g_wride_dry;
   w->spin = (unsigned)g_wride_spin;
-  w->status = status_word();
+  w->status = status_word(s);
   if (g_wride_dry & 1) {   // a timing experiment must not pass for a result
     static bool told = false;
     if (!told) fprintf(stderr, "vmlmf: VMLMF_WRIDE_DRY=1 - the weight-gradient workers leave at once, parameter gradients are NOT computed\n");
@@ -639,7 +655,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     io.gx = gx, io.EH = pack + P.EH, io.h0 = h0, io.c0 = c0, io.img = pack + P.RB, io.y = y, io.hT = hT, io.cT = cT;
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
-    io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word();
+    io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word(s);
     {
       Scope sc(2, s);
       if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
@@ -769,7 +785,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     memset(&io, 0, sizeof(io));
     io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
     io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
-    io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word();
+    io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word(s);
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
@@ -809,7 +825,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH, a.VE = pack + P.VE;
   a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
   a.hd = hb;
-  plan_wride(g, L, x, y, h0, rs, ws, &ride);
+  plan_wride(g, L, x, y, h0, rs, ws, &ride, s);
   a.wr = ride;
   {
     Scope sc(3, s);
@@ -910,7 +926,7 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
   const bool training = S.g[0].training != 0;
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
-  a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L, a.c.status = status_word();
+  a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L, a.c.status = status_word(s);
   if (head != nullptr) a.hd.W = head->weight, a.hd.bias = head->bias, a.hd.logits = head->logits, a.hd.C = head->classes;
   RefP rps[WF_MAXL];
   float* packs[WF_MAXL];
@@ -980,7 +996,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
   if (wave) {
     WfBwdArgs a;
     memset(&a, 0, sizeof(a));
-    a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L, a.c.status = status_word();   // cleared by the forward
+    a.c.flag = reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total), a.c.L = L, a.c.status = status_word(s);   // cleared by the forward
     a.hd = hb_top;
     for (int l = 0; l < L; ++l) {
       const VGeo& g = S.g[l];

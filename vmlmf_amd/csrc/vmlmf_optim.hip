@@ -24,11 +24,54 @@ __global__ void tick_kernel(TensorList t, int count, float* steps) {
   if ((int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
 }
 
+// Guarded form of the tick (ABI 9): a launch that gave up a bounded wait leaves NaN parameter gradients (vmlmf_hip.h:
+// VMLMF_E_PROTOCOL), and the host only learns of it at its next call - inside a replayed hipGraph never.  An optimizer
+// step over such gradients would poison the model for good, so the update is gated ON THE DEVICE: every workgroup scans a
+// slice of every gradient for non-finite values and leaves a flag; the last one to arrive (ticket) decides - all clear: the
+// step counters tick and guard[GO] = 1; otherwise nothing ticks, guard[GO] = 0 and guard[SKIPPED] counts the skipped step.
+// adam_kernel returns at once when guard[GO] is 0: parameters and moments keep their values.
+constexpr int GUARD_FLAGS = 64, GUARD_GO = 64, GUARD_TICKET = 65, GUARD_SKIPPED = 66;   // words of the guard block
+__global__ __launch_bounds__(256) void adam_gate_kernel(TensorList t, int count, float* steps, unsigned* guard) {
+  __shared__ unsigned bad_s;
+  __shared__ unsigned last_s;
+  if (threadIdx.x == 0) bad_s = 0;
+  __syncthreads();
+  unsigned bad = 0;
+  for (int ti = 0; ti < count; ++ti) {
+    const unsigned* g = reinterpret_cast<const unsigned*>(t.g[ti]);
+    const long long n = t.n[ti];
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+      bad |= ((g[i] & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;       // exponent all ones: Inf or NaN
+  }
+  if (bad) atomicOr(&bad_s, 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&guard[blockIdx.x], bad_s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    last_s = atomicAdd(&guard[GUARD_TICKET], 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_s == 0) return;
+  __threadfence();
+  if (threadIdx.x == 0) bad_s = 0;
+  __syncthreads();
+  if (threadIdx.x < gridDim.x && __hip_atomic_load(&guard[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicOr(&bad_s, 1u);
+  __syncthreads();
+  const bool go = bad_s == 0;
+  if (go && (int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
+  if (threadIdx.x == 0) {
+    guard[GUARD_GO] = go ? 1u : 0u;
+    guard[GUARD_TICKET] = 0;
+    if (!go) guard[GUARD_SKIPPED] += 1u;
+  }
+}
+
 // Same operation order as torch.optim.Adam's reference implementation (lerp for the first moment, mul + addcmul
 // for the second, sqrt / sqrt(bias_correction2) + eps, addcdiv), so that results agree to rounding.
 __global__ __launch_bounds__(256) void adam_kernel(TensorList t, float* __restrict__ m, float* __restrict__ v,
                                                    const float* __restrict__ step, float lr, float b1, float b2,
-                                                   float eps, float wd) {
+                                                   float eps, float wd, const unsigned* __restrict__ guard) {
+  if (guard != nullptr && guard[GUARD_GO] == 0) return;      // non-finite gradients: this step is skipped (adam_gate_kernel)
   const int ti = blockIdx.y;
   const long long n = t.n[ti];
   float* __restrict__ p = t.p[ti];
@@ -112,6 +155,9 @@ __global__ __launch_bounds__(256) void sgd_clip_kernel(TensorList t, const float
   const long long n = t.n[ti];
   float* __restrict__ p = t.p[ti];
   float* __restrict__ g = const_cast<float*>(t.g[ti]);
+  // a non-finite norm (NaN gradients of a launch that gave up a bounded wait, VMLMF_E_PROTOCOL; an overflow): the step is
+  // skipped - parameters AND gradients keep their values, `norm` tells the caller
+  if (!isfinite(norm[0])) return;
   float coef = 1.f;
   if (max_norm > 0.f) {
     coef = max_norm / (norm[0] + 1e-6f);
@@ -149,18 +195,31 @@ unsigned blocks_for(long long maxn) {
 
 extern "C" {
 
-int vmlmf_adam_step(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
-                    float beta1, float beta2, float eps, float weight_decay, void* stream) {
+int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, void* guard, void* stream) {
   TensorList t;
   long long maxn = 0;
   const int rc = fill(tensors, &t, &maxn);
   if (rc != 0) return rc;
   if (exp_avg == nullptr || exp_avg_sq == nullptr || steps == nullptr) return VMLMF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps);
+  if (guard != nullptr) {
+    long long total = 0;
+    for (int i = 0; i < tensors->count; ++i) total += tensors->numel[i];
+    long long nb = (total + 4095) / 4096;          // sixteen elements per thread before a second workgroup is worth its launch
+    nb = nb < 1 ? 1 : (nb > GUARD_FLAGS ? GUARD_FLAGS : nb);
+    hipLaunchKernelGGL(adam_gate_kernel, dim3((unsigned)nb), dim3(256), 0, s, t, tensors->count, steps, (unsigned*)guard);
+  } else {
+    hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps);
+  }
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(maxn), tensors->count), dim3(256), 0, s, t, exp_avg, exp_avg_sq,
-                     steps, lr, beta1, beta2, eps, weight_decay);
+                     steps, lr, beta1, beta2, eps, weight_decay, (const unsigned*)guard);
   return (int)hipGetLastError();
+}
+
+int vmlmf_adam_step(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  return vmlmf_adam_step_guarded(tensors, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, nullptr, stream);
 }
 
 int vmlmf_sgd_clip_step(const vmlmf_tensor_list* tensors, float lr, float max_norm, float* norm, float* scratch,

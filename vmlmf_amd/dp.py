@@ -130,9 +130,16 @@ class FlatGradAllReduce:
 
     def rccl_ranks(self):
         """Ranks of the communicator the exchange runs on, as RCCL reports them (C-ABI transport), else the group's size."""
+        return self.exchange_ranks()[0]
+
+    def exchange_ranks(self):
+        """(ranks, who counted them): RCCL's own ncclCommCount on the C-ABI transport; otherwise only the size of the
+        torch.distributed group, labelled with its backend - over gloo no RCCL communicator exists at all."""
         if self._comm is not None:
-            return self._comm.ranks()
-        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+            return self._comm.ranks(), "ncclCommCount (RCCL communicator behind the C ABI)"
+        if not dist.is_initialized():
+            return 1, "no process group"
+        return dist.get_world_size(self.group), f"torch.distributed.get_world_size (backend {dist.get_backend(self.group)})"
 
     def transport_used(self):
         return "cabi:vmlmf_flat_allreduce_group(rccl)" if self._comm is not None else f"torch.distributed:{dist.get_backend(self.group) if dist.is_initialized() else 'none'}"
@@ -204,6 +211,252 @@ class FlatGradAllReduce:
                 if scale is not None:
                     self.flat.mul_(scale)
             torch._foreach_copy_(loose, views)
+
+
+class BucketedGradAllReduce:
+    """Gradient exchange for a model whose gradient BYTES matter (the LM network: 13.44 M parameters = 53.8 MB, 97 % of
+    them `fc.w` and `embed.w`): the parameters are cut into buckets in the order the backward pass
+    finishes their gradients, and a bucket's all-reduce is started - asynchronously, on the communication stream - the
+    moment its last gradient has been accumulated, so the vocabulary projection's 26 MB travel over xGMI while the
+    recurrent layers' backward still runs.  wait() joins them all; only then may the caller look at the gradients
+    (clip_grad_norm_ over the REDUCED gradients, lm_test.py:204).
+
+    buckets: [[parameters]], in backward order.  op "sum" (the LM loss, lm_test.py:147-153: Σ over ranks of the local losses
+    is the global-batch loss) or "avg".  transport "torch": torch.distributed (backend nccl = RCCL; gloo on CPU tensors and
+    in the one-GPU rehearsal), "cabi": the package's own RCCL entry points on a side stream.
+    Every rank issues the same collectives in the same order: a bucket is launched from the hook of its LAST outstanding
+    gradient, buckets that never completed (a parameter without a gradient this step) are launched by wait() in bucket
+    order, and launches from hooks are forced into bucket order too (bucket k waits for buckets < k to have been issued)."""
+
+    IN_PLACE_BYTES = 256 * 1024     # a lone gradient at least this big is reduced where it is; smaller ones share a staging buffer
+
+    def __init__(self, buckets, op="sum", group=None, transport="torch"):
+        assert op in ("sum", "avg") and transport in ("torch", "cabi")
+        self.op, self.group, self.transport = op, group, transport
+        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self.buckets = [b for b in self.buckets if b]
+        self._of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                if id(p) in self._of:
+                    raise ValueError("a parameter may be in one bucket only")
+                self._of[id(p)] = bi
+        self._pending = [{id(p) for p in b} for b in self.buckets]
+        self._issued = [False] * len(self.buckets)
+        self._work = []             # (handle or None, staging or None) per issued collective
+        self._stage = {}            # bucket -> flat staging buffer of its small loners
+        self._comm, self._comm_tried, self._side = None, False, None
+        self.always = False         # run the collectives in a group of one as well (self-test)
+        self.last_collectives = 0
+        self.last_overlapped = 0    # collectives started from a hook, i.e. before the backward pass had ended
+        self.bytes_per_step = 0
+        self._armed = False
+        self._handles = [p.register_post_accumulate_grad_hook(self._hook) for b in self.buckets for p in b]
+
+    def close(self):
+        for h in self._handles:
+            h.remove()
+        self._handles = []
+        if self._comm is not None:
+            self._comm.close()
+            self._comm = None
+
+    # ---- per step ---------------------------------------------------------------------------------------------------
+    def arm(self):
+        """Before backward(): a new step begins."""
+        self._pending = [{id(p) for p in b} for b in self.buckets]
+        self._issued = [False] * len(self.buckets)
+        self._work = []
+        self.last_collectives = self.last_overlapped = self.bytes_per_step = 0
+        self._armed = True
+
+    def _world(self):
+        return dist.get_world_size(self.group) if dist.is_initialized() else 1
+
+    def _hook(self, p):
+        if not self._armed:
+            return
+        bi = self._of[id(p)]
+        self._pending[bi].discard(id(p))
+        # launch every bucket that is complete AND whose predecessors have been issued: the same order on every rank
+        for k in range(len(self.buckets)):
+            if self._issued[k]:
+                continue
+            if self._pending[k]:
+                break
+            self._launch(k, from_hook=True)
+
+    def _tensors(self, bi):
+        """What bucket bi reduces: (tensors reduced where they are, small loners to stage)."""
+        grads = [p.grad for p in self.buckets[bi] if p.grad is not None]
+        in_place, loose = [], []
+        for flat, gs in FlatGradAllReduce._spans(grads):
+            if flat is not None:
+                in_place.append(flat)
+            else:
+                for g in gs:
+                    if g.is_contiguous() and g.dtype == torch.float32 and g.numel() * 4 >= self.IN_PLACE_BYTES:
+                        in_place.append(g.view(-1))
+                    else:
+                        loose.append(g)
+        return in_place, loose
+
+    def _launch(self, bi, from_hook):
+        self._issued[bi] = True
+        in_place, loose = self._tensors(bi)
+        if not in_place and not loose:
+            return
+        world = self._world()
+        if world == 1 and not self.always:
+            return
+        stage = None
+        if loose:
+            n = sum(g.numel() for g in loose)
+            stage = self._stage.get(bi)
+            if stage is None or stage.numel() != n or stage.device != loose[0].device:
+                stage = self._stage[bi] = torch.empty(n, dtype=torch.float32, device=loose[0].device)
+            views, o = [], 0
+            for g in loose:
+                views.append(stage[o:o + g.numel()].view_as(g))
+                o += g.numel()
+            torch._foreach_copy_(views, loose)
+            self._work.append((None, (loose, views)))
+        tensors = in_place + ([stage] if stage is not None else [])
+        backend = dist.get_backend(self.group) if dist.is_initialized() else ""
+        native_avg = self.op == "avg" and backend == "nccl"
+        rop = dist.ReduceOp.AVG if native_avg else dist.ReduceOp.SUM
+        comm = self._cabi(tensors[0].device, backend)
+        if comm is not None:
+            cur = torch.cuda.current_stream(tensors[0].device)
+            if self._side is None:
+                self._side = torch.cuda.Stream(tensors[0].device)
+            self._side.wait_stream(cur)                      # the gradients are complete on the compute stream
+            with torch.cuda.stream(self._side):
+                comm.all_reduce(tensors, "avg" if native_avg else "sum")
+            self._work.append(("side", None))
+        else:
+            for t in tensors:
+                self._work.append((dist.all_reduce(t, op=rop, group=self.group, async_op=True), None))
+        if self.op == "avg" and not native_avg:
+            self._work.append((None, ("scale", tensors, 1.0 / world)))
+        self.last_collectives += len(tensors)
+        self.last_overlapped += len(tensors) if from_hook else 0
+        self.bytes_per_step += 4 * sum(t.numel() for t in tensors)
+
+    def _cabi(self, device, backend):
+        if self.transport != "cabi" or backend != "nccl" or device.type != "cuda":
+            return None
+        if not self._comm_tried:
+            self._comm_tried = True
+            comm = CabiComm(device, self.group)
+            self._comm = comm if comm.handle else None
+        return self._comm
+
+    def wait(self):
+        """After backward(): launch what the hooks could not, join every collective (the current stream waits for the
+        communication stream; over gloo the host does), copy staged gradients back."""
+        for k in range(len(self.buckets)):
+            if not self._issued[k]:
+                self._launch(k, from_hook=False)
+        later = []
+        for handle, extra in self._work:
+            if handle == "side":
+                torch.cuda.current_stream(self._side.device).wait_stream(self._side)
+            elif handle is not None:
+                handle.wait()
+            if extra is not None:
+                later.append(extra)
+        for extra in later:
+            if extra[0] == "scale":
+                for t in extra[1]:
+                    t.mul_(extra[2])
+        for extra in later:
+            if extra[0] != "scale":
+                loose, views = extra
+                torch._foreach_copy_(loose, views)
+        self._work = []
+        self._armed = False
+
+    def exchange_ranks(self):
+        if self._comm is not None:
+            return self._comm.ranks(), "ncclCommCount (RCCL communicator behind the C ABI)"
+        if not dist.is_initialized():
+            return 1, "no process group"
+        return dist.get_world_size(self.group), f"torch.distributed.get_world_size (backend {dist.get_backend(self.group)})"
+
+    def transport_used(self):
+        return "cabi:vmlmf_flat_allreduce_group(rccl), side stream" if self._comm is not None else \
+            f"torch.distributed:{dist.get_backend(self.group) if dist.is_initialized() else 'none'}, async_op"
+
+
+def lm_buckets(model):
+    """Buckets of the LM network (vmlmf_lm.py:366-440) in the order its backward pass completes them: the vocabulary
+    projection first (its gradients exist before the recurrent layers' backward starts), then the recurrent layers from
+    the top one down, the embedding table last (its gradient needs layer 0's dx)."""
+    out = [list(model.fc.parameters())]
+    out += [list(r.parameters()) for r in reversed(list(model.rnns))]
+    out.append(list(model.embed.parameters()))
+    seen = {id(p) for b in out for p in b}
+    rest = [p for p in model.parameters() if id(p) not in seen]
+    return out + ([rest] if rest else [])
+
+
+class LmDataParallel:
+    """The reference's LM training step (lm_test.py:196-207) on one rank of a data-parallel job:
+
+        states = model.detach(states)                 rank-local rows: the carried (h, c) never leave the rank
+        scores, states = model(x_local, states)
+        loss = nll_loss(scores, y_local)              = (1/T) Σ over the LOCAL tokens  (lm_test.py:147-153)
+        loss.backward()                               buckets all-reduce (SUM) as they complete
+        clip_grad_norm_(REDUCED gradients, max_norm); param -= lr * grad        (lm_test.py:204-207)
+
+    With the batch columns split contiguously over the ranks (shard()), Σ over ranks of the local losses and gradients are
+    the single-process loss and gradients of the global minibatch, so every rank clips by the same norm and takes the same
+    update: the replicas stay identical without ever exchanging parameters.
+    loss_fn / update_fn default to the package's fused kernels (HIP tensors); the CPU tests pass stock formulations."""
+
+    def __init__(self, model, lr, max_norm, group=None, transport="torch", loss_fn=None, update_fn=None, buckets=None):
+        from .functional import nll_loss
+        from .optim import clip_sgd_step
+        self.model, self.lr, self.max_norm, self.group = model, lr, max_norm, group
+        self.loss_fn = loss_fn or nll_loss
+        self.update_fn = update_fn or clip_sgd_step
+        self.reducer = BucketedGradAllReduce(buckets or lm_buckets(model), op="sum", group=group, transport=transport)
+        broadcast_parameters(model, group=group)
+
+    def _rank_world(self):
+        if not dist.is_initialized():
+            return 0, 1
+        return dist.get_rank(self.group), dist.get_world_size(self.group)
+
+    def shard(self, x):
+        """This rank's contiguous block of batch columns of a (T, B) token tensor."""
+        rank, world = self._rank_world()
+        return shard_batch(x, rank, world, dim=1)
+
+    def forward_backward(self, x, y, states):
+        self.model.zero_grad(set_to_none=True)
+        states = self.model.detach(states)
+        scores, states = self.model(x, states)
+        loss = self.loss_fn(scores, y)
+        self.reducer.arm()
+        loss.backward()
+        self.reducer.wait()
+        return loss.detach(), states
+
+    def step(self, x, y, states):
+        """x, y: this rank's (T, B_local) tokens.  Returns (local loss, norm of the reduced gradients, new states)."""
+        loss, states = self.forward_backward(x, y, states)
+        norm = self.update_fn(self.model.parameters(), self.lr, self.max_norm)
+        return loss, norm, states
+
+    def global_loss(self, loss):
+        """Σ over ranks of the local losses = the reference's loss on the global minibatch."""
+        if not dist.is_initialized() or dist.get_world_size(self.group) == 1:
+            return loss
+        t = loss.detach().clone().reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t[0]
 
 
 def broadcast_parameters(module, src=0, group=None):

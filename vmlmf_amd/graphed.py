@@ -13,13 +13,24 @@ Constructing it leaves the model and the optimizer as they were (the warm-up ste
 snapshot that is restored).  A batch whose shape differs from the example's (the last, shorter DataLoader batch) runs
 the same body eagerly.  Scalars the kernels take by value are frozen in a capture (the learning rate of
 vmlmf_amd.optim.Adam): when a group's lr / betas / eps / weight_decay has changed since the capture, the step is captured again.
+
+A launch inside the graph that gives up a bounded wait (include/vmlmf_hip.h: VMLMF_E_PROTOCOL - a GPU shared with other
+processes can starve the riding weight-gradient workers) leaves NaN gradients.  vmlmf_amd.optim.Adam's device-side gate skips
+the update of such a step, so the parameters stay intact; the host reads the library's status word in front of every replay
+(a host memory read, no GPU call), and when an earlier replay failed - or the library's kernel selection changed since the
+capture (vmlmf_tune_generation) - the step is captured again: the library has switched to the stand-alone weight-gradient
+kernel by then, and the poisoned launch is not replayed any more.  `failed_steps` / `recaptures` count; the step that failed
+is lost (its update was skipped), nothing else is.
 """
 from __future__ import annotations
 
 import gc
 
+import warnings
+
 import torch
 
+from . import _lib
 from .functional import unit_gradient
 
 
@@ -78,6 +89,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         self.model.zero_grad(set_to_none=True)
         self._captured_hyper = self._hyper()
+        self._captured_generation = _lib.lib().vmlmf_tune_generation()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
 
@@ -93,6 +105,20 @@ class GraphedTrainStep:
             return self._body(x, target)     # e.g. the last, shorter batch of a DataLoader: same step, eager launches
         if self._hyper() != self._captured_hyper:
             self._capture()                  # a scheduler changed lr (by-value kernel argument): capture it again
+        # did a launch of an EARLIER replay give up a bounded wait?  (the status word is host memory: no GPU call)
+        lib = _lib.lib()
+        with _lib.on_device(self.x.device):
+            rc = lib.vmlmf_check_status()
+        if rc == _lib.E_PROTOCOL:
+            self.failed_steps = getattr(self, "failed_steps", 0) + 1
+            warnings.warn("vmlmf_amd.GraphedTrainStep: " + lib.vmlmf_last_error().decode() + " - that step's update was skipped "
+                          "on the device; the step is captured again without the launch that failed", RuntimeWarning)
+        elif rc != 0:
+            _lib.check(rc)
+        if rc != 0 or lib.vmlmf_tune_generation() != self._captured_generation:
+            torch.cuda.synchronize(self.x.device)
+            self.recaptures = getattr(self, "recaptures", 0) + 1
+            self._capture()
         self.x.copy_(x, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self.graph.replay()

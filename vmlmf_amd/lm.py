@@ -6,8 +6,8 @@
   Embed, Linear, Model   V/src/models/vmlmf_lm.py:33-51, 345-364, 366-440: the rest of the LM network around those layers
                          (SURVEY section 8f rank 3).  Embedding lookup and the vocabulary projection (one library GEMM) are
                          stock ops; the loss that consumes the scores is vmlmf_amd.nll_loss (fused kernels).  The reference's
-                         dense "custom" LSTM layer (283-343) is the uncompressed baseline, out of scope: Model takes the
-                         caller's class for it (dense_layer=).
+                         dense "custom" LSTM layer (283-339) is the uncompressed baseline, off the VMLMF path: class LSTM
+                         below keeps it available in stock library ops (Model(lstm_type="custom")); dense_layer= overrides it.
 Parameter names, shapes and registration order follow the reference (state_dict compatible).
 """
 from __future__ import annotations
@@ -108,6 +108,37 @@ class MyVMLSTMGroup(nn.Module):
         return y, (hT, cT)
 
 
+class LSTM(nn.Module):
+    """The reference's dense "custom" layer (vmlmf_lm.py:283-339): the uncompressed baseline Model(lstm_type="custom")
+    builds.  Not part of the VMLMF path, so stock library ops on whatever device the tensors live on: the input side of all
+    T steps is one GEMM ahead of the time loop, the recurrence one addmm per step.  Same parameter names and shapes."""
+
+    def __init__(self, input_size, hidden_size, dropout=0):
+        super().__init__()
+        self.input_size, self.hidden_size, self.dropout = input_size, hidden_size, dropout
+        self.w_x = nn.Parameter(torch.zeros(4 * hidden_size, input_size))
+        self.w_h = nn.Parameter(torch.zeros(4 * hidden_size, hidden_size))
+        self.b_x = nn.Parameter(torch.zeros(4 * hidden_size))
+        self.b_h = nn.Parameter(torch.zeros(4 * hidden_size))
+
+    def __repr__(self):
+        return f"LSTM(input: {self.input_size}, hidden: {self.hidden_size})"
+
+    def forward(self, x, states):
+        h, c = states
+        T, B, _ = x.shape
+        H = self.hidden_size
+        gx = torch.addmm(self.b_x + self.b_h, x.reshape(T * B, -1), self.w_x.t()).view(T, B, 4 * H)
+        w_ht = self.w_h.t()
+        ys = []
+        for t in range(T):
+            i, f, o, n = torch.addmm(gx[t], h, w_ht).split(H, 1)
+            c = torch.sigmoid(f) * c + torch.sigmoid(i) * torch.tanh(n)
+            h = torch.sigmoid(o) * torch.tanh(c)
+            ys.append(h)
+        return torch.stack(ys), (h, c)
+
+
 class Embed(nn.Module):
     """Embedding table indexed by token id (vmlmf_lm.py:33-51)."""
 
@@ -150,9 +181,8 @@ class Model(nn.Module):
 
     def __init__(self, vocab_size, hidden_size, layer_num, dropout, winit, w_rank=None, u_ranks=None,
                  lstm_type="pytorch", dense_layer=None):
-        """dense_layer: the class to build for lstm_type="custom" - the reference's own dense `LSTM` layer
-        (vmlmf_lm.py:283-339), which is the uncompressed baseline, not the VMLMF path, and is not re-implemented here:
-        pass `models.vmlmf_lm.LSTM` (any class with the signature (input_size, hidden_size) and forward(x, states))."""
+        """dense_layer: overrides the class built for lstm_type="custom" (default: LSTM above, the reference's dense baseline
+        layer in stock ops); any class with the signature (input_size, hidden_size) and forward(x, states)."""
         super().__init__()
         self.vocab_size = vocab_size
         self.hidden_size = hidden_size
@@ -165,10 +195,7 @@ class Model(nn.Module):
         if lstm_type == "vmgroup":
             rnns = [MyVMLSTMGroup(hidden_size, hidden_size, w_rank=w_rank, u_ranks=u_ranks) for _ in range(layer_num)]
         elif lstm_type == "custom":
-            if dense_layer is None:
-                raise ValueError('vmlmf_amd.lm.Model(lstm_type="custom"): the dense baseline layer is the reference\'s own class '
-                                 "(vmlmf_lm.py:283-339) - pass it as dense_layer=...; this package only re-implements the VMLMF layers")
-            rnns = [dense_layer(hidden_size, hidden_size) for _ in range(layer_num)]
+            rnns = [(dense_layer or LSTM)(hidden_size, hidden_size) for _ in range(layer_num)]
         elif lstm_type != "vmlmf":
             rnns = [nn.LSTM(hidden_size, hidden_size) for _ in range(layer_num)]
         else:

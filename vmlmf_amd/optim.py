@@ -42,12 +42,20 @@ def _check(p, g):
 class Adam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (betas, eps, L2 weight_decay; no amsgrad / maximize), one launch per step and
     parameter group.  state[p] holds 'step', 'exp_avg', 'exp_avg_sq' like the stock optimizer (the moments are
-    views of two flat buffers per group)."""
+    views of two flat buffers per group).
+    Non-finite gradients never reach the parameters: a gate launch in front of the update scans them on the device and
+    skips the whole step of the group when any is Inf / NaN (a launch that gave up a bounded wait, VMLMF_E_PROTOCOL, leaves NaN
+    gradients, and a replayed hipGraph cannot ask the host); skipped_steps() counts.  guard=False: the unguarded launch."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guard=True):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
             raise ValueError("invalid Adam hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._guarded = bool(guard)
+
+    def skipped_steps(self):
+        """Steps the device-side gate refused because a gradient was not finite (summed over groups and calls; synchronises)."""
+        return sum(int(gs["guard"][_lib.GUARD_SKIPPED].item()) for gs in getattr(self, "_flat", {}).values() if gs.get("guard") is not None)
 
     def _group_state(self, gi, group):
         """Flat moment buffers covering every parameter of the group (allocated at the first step; kept out of
@@ -63,7 +71,8 @@ class Adam(torch.optim.Optimizer):
                 offs[p], sidx[p] = total, k
                 total += p.numel()
             gs = dict(m=torch.zeros(total, device=dev), v=torch.zeros(total, device=dev),
-                      steps=torch.zeros(len(ps), device=dev), offs=offs, sidx=sidx)
+                      steps=torch.zeros(len(ps), device=dev), offs=offs, sidx=sidx,
+                      guard=torch.zeros(_lib.GUARD_WORDS, device=dev, dtype=torch.int32) if getattr(self, "_guarded", True) else None)
             self._flat[gi] = gs
             for p in ps:
                 o = offs[p]
@@ -114,10 +123,11 @@ class Adam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             with _lib.on_device(dev):
                 lists = _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live])
+                guard = None if gs.get("guard") is None else gs["guard"].data_ptr()
                 for tl in lists:
-                    _lib.check(lib.vmlmf_adam_step(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(),
-                                                   gs["steps"].data_ptr(), float(group["lr"]), float(b1), float(b2),
-                                                   float(group["eps"]), float(group["weight_decay"]), stream))
+                    _lib.check(lib.vmlmf_adam_step_guarded(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(),
+                                                           gs["steps"].data_ptr(), float(group["lr"]), float(b1), float(b2),
+                                                           float(group["eps"]), float(group["weight_decay"]), guard, stream))
             _bump_versions(live)
         return loss
 
@@ -143,7 +153,9 @@ class _Scratch:
 @torch.no_grad()
 def clip_sgd_step(parameters, lr, max_norm):
     """The LM loop's update (lm_test.py:203-209): norm = clip_grad_norm_(parameters, max_norm); p -= lr * p.grad.
-    Returns the total gradient norm before clipping as a 0-d device tensor (what clip_grad_norm_ returns)."""
+    Returns the total gradient norm before clipping as a 0-d device tensor (what clip_grad_norm_ returns).
+    A norm that is not finite (NaN gradients of a launch that gave up a bounded wait; an overflow) skips the step on the device:
+    parameters and gradients keep their values and the returned norm says so."""
     live = [p for p in parameters if p.grad is not None]
     if not live:
         return torch.zeros(())
