@@ -26,11 +26,12 @@ def ranks_of(variant, P):
     return rw, [P[f"u_h{sep}0"].shape[2], P[f"u_h{sep}1"].shape[2]], 2
 
 
-def run_hip(variant, P, x, h0=None, c0=None, dy=None, dhT=None, dcT=None, time_major=False, dev="cuda"):
-    """Forward (+ backward when any upstream gradient is given).  numpy in, numpy out."""
+def run_hip(variant, P, x, h0=None, c0=None, dy=None, dhT=None, dcT=None, time_major=False, dev="cuda", need_dx=True):
+    """Forward (+ backward when any upstream gradient is given).  numpy in, numpy out.  need_dx=False: the input asks for no
+    gradient (a first layer: the kernels that form the weight gradients inside the backward launch need that)."""
     names = ORDER[variant]
     params = [torch.tensor(np.asarray(P[k]), dtype=torch.float32, device=dev).requires_grad_(True) for k in names]
-    xt = torch.tensor(x, dtype=torch.float32, device=dev).requires_grad_(True)
+    xt = torch.tensor(x, dtype=torch.float32, device=dev).requires_grad_(need_dx)
     h0t = None if h0 is None else torch.tensor(h0, dtype=torch.float32, device=dev).requires_grad_(True)
     c0t = None if c0 is None else torch.tensor(c0, dtype=torch.float32, device=dev).requires_grad_(True)
     rw, ru, g = ranks_of(variant, P)
@@ -45,7 +46,8 @@ def run_hip(variant, P, x, h0=None, c0=None, dy=None, dhT=None, dcT=None, time_m
         if dcT is not None:
             loss = loss + (cT * torch.tensor(dcT, device=dev)).sum()
         loss.backward()
-        out["dx"] = xt.grad.cpu().numpy()
+        if need_dx:
+            out["dx"] = xt.grad.cpu().numpy()
         if h0t is not None:
             out["dh0"] = h0t.grad.cpu().numpy()
             out["dc0"] = c0t.grad.cpu().numpy()

@@ -210,6 +210,10 @@ int g_rb_rows = env_pos("VMLMF_RB_ROWS", 0);      // live batch rows per workgro
 // batch rows than CUs (rec3_fwd_kernel needs ~170 VGPRs, two workgroups share a CU; rec_fwd_kernel's x-projection wave needs
 // 256, so its workgroups run in rounds: measured B = 512 138 -> 104 us, 0.402 -> 0.370 ms per step; up to B = 256 the two tie)
 int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 6; }();
+// fourth form of the backward (vmlmf_rec4.inc: weight gradients formed inside the rows' workgroups, no dpre tape, no
+// weight-gradient launch): VMLMF_INROW / vmlmf_tune("inrow", v): 0 = never, 1 = wherever it covers the layer, -1 = automatic
+// (batches beyond the riding workers' range)
+int g_inrow = []() { const char* e = getenv("VMLMF_INROW"); return e ? atoi(e) : -1; }();
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -378,7 +382,8 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   L.b_dpre = o, o += align64(TS * 4);
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
   L.b_dqx = o, o += align64(TB * g.KX);
-  L.b_wpart = o, o += align64((long long)g.nchunk * g.PCH);
+  // (one partial block per chunk of rows, or - backward with the weight gradients formed in the rows' workgroups - per workgroup)
+  L.b_wpart = o, o += align64((long long)((!g.generic && !g.rb && rec4_bwd_supported(g) && g.nwg > g.nchunk) ? g.nwg : g.nchunk) * g.PCH);
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT + (g.I > g.H ? (long long)g.I * g.KX : 0));   // + dU_x by input when I > H
   L.b_trash = o, o += 64;
   {
@@ -480,11 +485,12 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
 }
 
 static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
-                         const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s, const WRide* ride = nullptr) {
+                         const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s, const WRide* ride = nullptr,
+                         const int inrow_blocks = 0) {
   int rc;
   const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
   const bool rode = ride != nullptr && ride->K > 0;
-  if (!rode) {
+  if (!rode && inrow_blocks == 0) {
     Scope sc(5, s);
     if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
   }
@@ -492,6 +498,7 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
     Scope sc(6, s);
     VGeo gr_ = g;
     if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
+    if (inrow_blocks > 0) gr_.nchunk = inrow_blocks;   // one partial block per workgroup of rec4_bwd_kernel
     if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s), "reduce")) != 0) return rc;
   }
   RefG og;
@@ -775,6 +782,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   }
   WRide ride;
   memset(&ride, 0, sizeof(ride));
+  bool inrow = false;
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -825,11 +833,21 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   a.VR = pack + P.VR, a.UE = pack + P.UE, a.EH = pack + P.EH, a.VE = pack + P.VE;
   a.dpre = ws + L.b_dpre, a.dQs = ws + L.b_dQs, a.dh0 = dh0, a.dc0 = dc0, a.trash = ws + L.b_trash;
   a.hd = hb;
-  plan_wride(g, L, x, y, h0, rs, ws, &ride, s);
+  // weight gradients inside the rows' workgroups (vmlmf_rec4.inc)?  Layers it covers whose input needs no gradient; automatic:
+  // batches beyond the riding workers' range (up to there the idle CUs form the products for free)
+  inrow = g_inrow != 0 && dx == nullptr && rec4_bwd_supported(g) && (g_inrow > 0 || g.B > g_wride_maxb);
+  if (inrow) {
+    const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
+    ride.a.x = wh.x, ride.a.y = wh.y, ride.a.h0 = wh.h0, ride.a.Qs = wh.Qs, ride.a.P = wh.wpart;
+  } else {
+    plan_wride(g, L, x, y, h0, rs, ws, &ride, s);
+  }
   a.wr = ride;
   {
     Scope sc(3, s);
-    if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
+    if (inrow) {
+      if ((rc = hip_fail(launch_rec4_bwd(g, a, s), "rec4_bwd")) != 0) return rc;
+    } else if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
       if ((rc = hip_fail(launch_rec3_bwd(g, a, s), "rec3_bwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
   }
@@ -841,7 +859,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride)) != 0) return rc;
+  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? g.nwg : 0)) != 0) return rc;
   return debug_status(s);
 }
 
@@ -1104,6 +1122,7 @@ int vmlmf_tune(const char* key, int value) {
   if (k == "rb") g_rb_mode = value;
   else if (k == "rec3") g_rec3 = value;
   else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
+  else if (k == "inrow") g_inrow = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

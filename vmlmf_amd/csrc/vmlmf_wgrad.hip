@@ -154,21 +154,50 @@ __global__ void __launch_bounds__(256 * NS) wgrad_mfma_stack_kernel(AtbStack S) 
 
 // One thread per element of a chunk's partial block P (coalesced over chunks), fixed-order sum over the
 // chunks (deterministic), then scatter into cgrad[accumulator][slot] (layout finish_kernel reads).
-__device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= g.PCH) return;
+// fixed-order sum over the blocks of element e: four interleaved accumulators, eight loads in flight
+__device__ __forceinline__ float reduce_cg_sum(const float* __restrict__ Pall, const long long PCH, const long long e, int c, const int c1) {
   float s[4] = {0.f, 0.f, 0.f, 0.f};
-  int c = 0;
-  for (; c + 7 < g.nchunk; c += 8) {
+  for (; c + 7 < c1; c += 8) {
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = Pall[(size_t)(c + i) * g.PCH + e];
+    for (int i = 0; i < 8; ++i) v[i] = Pall[(size_t)(c + i) * PCH + e];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s[i & 3] += v[i];
   }
-  for (; c < g.nchunk; ++c) s[0] += Pall[(size_t)c * g.PCH + e];
-  const float total = (s[0] + s[1]) + (s[2] + s[3]);
+  for (; c < c1; ++c) s[0] += Pall[(size_t)c * PCH + e];
+  return (s[0] + s[1]) + (s[2] + s[3]);
+}
 
+__device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long e, const float total, float* __restrict__ cgrad);
+
+__device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= g.PCH) return;
+  reduce_cg_scatter(g, e, reduce_cg_sum(Pall, g.PCH, e, 0, g.nchunk), cgrad);
+}
+
+// The same sum when there are many blocks (one per workgroup of rec4_bwd_kernel: up to the batch size): as one thread per
+// element the loop over 256 blocks was a chain of 32 memory round trips (18 us at B = 256).  Here a workgroup takes 32 elements,
+// its eight 32-lane groups an eighth of the blocks each, and the eight partial sums meet in LDS in group order - still a fixed
+// order for a given block count.
+__global__ void __launch_bounds__(256) reduce_cg_many_kernel(VGeo g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
+  __shared__ float red[8][32];
+  const int li = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + li;
+  const long long ec = e < g.PCH ? e : g.PCH - 1;
+  const int per = (g.nchunk + 7) / 8;
+  const int c0 = grp * per < g.nchunk ? grp * per : g.nchunk, c1 = c0 + per < g.nchunk ? c0 + per : g.nchunk;
+  red[grp][li] = reduce_cg_sum(Pall, g.PCH, ec, c0, c1);
+  __syncthreads();
+  if (grp == 0 && e < g.PCH) {
+    float total = red[0][li];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) total += red[q][li];
+    reduce_cg_scatter(g, e, total, cgrad);
+  }
+}
+
+__device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long e, const float total, float* __restrict__ cgrad) {
   const int KX = g.KX, KH = g.KH, GK = g.G * KH, NT = g.NT;
   const int MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
   const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
@@ -292,6 +321,10 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
 }
 
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s) {
+  if (g.nchunk > 96 && prog == nullptr) {
+    hipLaunchKernelGGL(reduce_cg_many_kernel, dim3((unsigned)((g.PCH + 31) / 32)), dim3(256), 0, s, g, wpart, cgrad);
+    return (int)hipGetLastError();
+  }
   hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad, prog);
   return (int)hipGetLastError();
 }
