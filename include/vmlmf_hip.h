@@ -283,6 +283,26 @@ int vmlmf_nll_forward(int R, int V, const float *scores, const int64_t *y, float
                       float *rowloss, void *stream);
 int vmlmf_nll_backward(int R, int V, const float *scores, const int64_t *y, float scale, const float *lse,
                        const float *dloss, float *dscores, void *stream);
+/* ABI 9, the training form of the same loss: ONE pass over the score matrix.  `scores` (R,V) are the projection's outputs
+ * WITHOUT the bias (`bias` (V) or NULL is added here, so the GEMM in front needs no bias epilogue); on return the matrix holds
+ * its own gradient for d(loss) = 1, dscores = scale (softmax(scores + bias) - onehot(y)), IN PLACE - the two backward GEMMs of
+ * the projection (Linear, V/src/models/vmlmf_lm.py:355-358) consume it where it lies, no second R x V buffer exists - and
+ * dbias (V, may be NULL) holds its column sums, the bias gradient.  loss (1), rowloss (R) as above.  scratch:
+ * vmlmf_nll_grad_scratch_floats(R, V) floats.  Rows must be 16-byte aligned, V % 4 == 0, V <= 12288 (VMLMF_E_UNSUPPORTED
+ * otherwise: use the two calls above).  Fixed summation orders, no atomics. */
+size_t vmlmf_nll_grad_scratch_floats(int R, int V);
+int vmlmf_nll_forward_grad(int R, int V, float *scores, const float *bias, const int64_t *y, float scale, float *loss,
+                           float *rowloss, float *dbias, float *scratch, void *stream);
+
+/*
+ * Gradient of the embedding table (Embed, V/src/models/vmlmf_lm.py:46-48: x = w[tokens]; autograd's backward scatter-adds the
+ * R = T*B rows of dy (R,H) into a zero (V,H) matrix).  dweight[v] = sum of dy[p] over the positions p with tokens[p] == v, in
+ * ascending position order (deterministic, no float atomics); rows no token selects are written as zeros: the call fills all of
+ * dweight.  scratch: vmlmf_embed_backward_scratch_bytes(R, V) bytes (one bit per (vocabulary row, position)).  H <= 1024.
+ */
+size_t vmlmf_embed_backward_scratch_bytes(int R, int V);
+int vmlmf_embed_backward(int R, int H, int V, const int64_t *tokens, const float *dy, float *dweight, void *scratch,
+                         size_t scratch_bytes, void *stream);
 
 /*
  * Optimizer steps of the reference's two training loops, one launch over every parameter tensor.

@@ -619,3 +619,117 @@ def test_linear_nll_without_the_score_tensor_equals_projection_plus_loss():
     with torch.no_grad():
         assert abs(float(vmlmf_amd.linear_nll(h, w, b, y)) - float(ref)) <= 1e-5 * abs(float(ref))      # the chunked form
     assert abs(float(vmlmf_amd.linear_nll(h, w, b, y)) - float(ref)) <= 1e-6 * abs(float(ref))          # needs a gradient: unfused
+
+
+# ---- the LM head for training and the embedding table's gradient (verdict r3 item 5) --------------
+def test_lm_network_with_the_fused_head_and_embedding_gradient_vs_reference():
+    """The LM loop of lm_test.py:196-209 through Model.loss: projection + loss with the scores' gradient formed in place
+    (vmlmf_nll_forward_grad), the two backward GEMMs reading it there, the embedding table's gradient by vmlmf_embed_backward -
+    two minibatches with carried states against the reference's own run, once with the package's unit gradient and once with a
+    plain loss.backward() (a foreign d(loss) tensor: the scaled path)."""
+    import vmlmf_amd
+    from vmlmf_amd import Model, optim
+    d = load_golden("lm_model_v3")
+    V, H, L, B, T, rw, ru = (int(v) for v in d["meta"])
+    for plain_backward in (False, True):
+        model = Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[ru], lstm_type="vmlmf")
+        model.load_state_dict({k: torch.tensor(v) for k, v in d["init"].items()})
+        model = model.to(DEV)
+        states = model.state_init(B)
+        for i in range(2):
+            model.zero_grad()
+            states = model.detach(states)
+            loss, states = model.loss(torch.tensor(d[f"x{i}"], device=DEV), torch.tensor(d[f"y{i}"], device=DEV), states)
+            if plain_backward:
+                loss.backward()
+            else:
+                loss.backward(vmlmf_amd.unit_gradient(DEV))
+            assert abs(loss.item() - float(d[f"loss{i}"][0])) < 1e-4 * float(d[f"loss{i}"][0])
+            for k, p in model.named_parameters():
+                assert_grad(p.grad.cpu().numpy(), d[f"G{i}"][k], f"G{i}.{k}")
+            norm = optim.clip_sgd_step(model.parameters(), lr=1.0, max_norm=0.25)
+            assert abs(float(norm) - float(d[f"norm{i}"][0])) < 1e-4 * float(d[f"norm{i}"][0])
+        sd = model.state_dict()
+        for k, v in d["final"].items():
+            assert_out(sd[k].cpu().numpy(), v, "final." + k, atol=2e-5, rtol=1e-3)
+        assert_out(torch.stack([s[0].detach() for s in states]).cpu().numpy(), d["hT"], "hT")
+
+
+def test_nll_forward_grad_at_the_vocabulary_width_vs_reference():
+    """vmlmf_nll_forward_grad on the reference's own loss fixture (R = 70 rows of 10 000 scores): loss, the in-place gradient
+    (sampled columns and the target columns, upstream gradient 3) and the bias gradient = its column sums; the bias is added
+    by the kernel (the scores arrive without it)."""
+    from vmlmf_amd.functional import lm_head_loss
+    d = load_golden("nll_v10000")
+    T, B, V, seed = (int(v) for v in d["meta"])
+    r = np.random.Generator(np.random.PCG64(seed))
+    z = (2.0 * r.standard_normal((T * B, V))).astype(np.float32)
+    y = d["y"]
+    # scores = h W^T + b with H = V and W = I would be a 400 MB weight: drive the kernel through the C ABI instead
+    import ctypes
+    from vmlmf_amd import _lib
+    lib = _lib.lib()
+    rb = np.random.Generator(np.random.PCG64(5))
+    bias = rb.standard_normal(V).astype(np.float32)
+    zt = torch.tensor(z - bias[None, :], device=DEV)                 # what the projection would hand over: scores without the bias
+    bt = torch.tensor(bias, device=DEV)
+    yt = torch.tensor(y.reshape(-1), device=DEV)
+    R = T * B
+    stats = torch.empty(1 + R, device=DEV)
+    db = torch.empty(V, device=DEV)
+    scratch = torch.empty(lib.vmlmf_nll_grad_scratch_floats(R, V), device=DEV)
+    _lib.check(lib.vmlmf_nll_forward_grad(R, V, zt.data_ptr(), bt.data_ptr(), yt.data_ptr(), ctypes.c_float(B / R), stats.data_ptr(),
+                                          stats.data_ptr() + 4, db.data_ptr(), scratch.data_ptr(), _lib.raw_stream(torch.device(DEV, 0))))
+    torch.cuda.synchronize()
+    up = float(d["upstream"][0])
+    g = zt.cpu().numpy().astype(np.float64) * up
+    # z - bias + bias differs from z by one rounding: the fixture's own tolerance for the stable form (1e-4 relative)
+    assert abs(stats[0].item() - float(d["loss"][0])) < 1e-4 * float(d["loss"][0])
+    assert_grad(g[:, ::97], d["g_s"], "dscores sample", rel=2e-4)
+    assert_grad(g[np.arange(R), y.reshape(-1)], d["g_target"], "dscores at the targets", rel=2e-4)
+    assert_grad(db.cpu().numpy(), zt.cpu().numpy().astype(np.float64).sum(0), "dbias = column sums")
+    want, gwant = O.nll_loss_stable(z, y)
+    assert_grad(g / up, gwant, "dscores vs the stable oracle", rel=2e-4)
+    # and through autograd on a small projection: values and gradients against stock ops in fp64
+    torch.manual_seed(3)
+    Hs, Vs, Ts, Bs = 24, 64, 5, 6
+    h = torch.randn(Ts, Bs, Hs, device=DEV, requires_grad=True)
+    w = (0.3 * torch.randn(Vs, Hs, device=DEV)).requires_grad_(True)
+    b = torch.randn(Vs, device=DEV, requires_grad=True)
+    yy = torch.randint(0, Vs, (Ts, Bs), device=DEV)
+    loss = lm_head_loss(h, w, b, yy)
+    (2.5 * loss).backward()
+    hd, wd, bd = (t.detach().double().cpu().requires_grad_(True) for t in (h, w, b))
+    ref = -torch.log_softmax(hd.reshape(-1, Hs) @ wd.t() + bd, 1)[torch.arange(Ts * Bs), yy.cpu().reshape(-1)].mean() * Bs
+    (2.5 * ref).backward()
+    assert abs(loss.item() - ref.item()) < 1e-5 * abs(ref.item())
+    for got, want_, name in ((h.grad, hd.grad, "dh"), (w.grad, wd.grad, "dW"), (b.grad, bd.grad, "db")):
+        assert_grad(got.cpu().numpy(), want_.numpy(), "head." + name)
+
+
+def test_embedding_gradient_is_a_position_ordered_sum_without_atomics():
+    """vmlmf_embed_backward: every table row the sum of the dy rows of its positions in ascending order - equal to an fp64
+    scatter-add within rounding, identical bits on every run, zeros where no token points (the call fills the whole matrix),
+    correct with heavy repetition (one token at a third of the positions) and for widths that are not a multiple of 64."""
+    from vmlmf_amd.functional import embedding
+    rng = np.random.Generator(np.random.PCG64(11))
+    for (V, H, T, B) in ((100, 650, 35, 64), (10000, 650, 35, 16), (37, 16, 5, 4), (300, 129, 9, 33)):
+        tok = rng.integers(0, V, size=(T, B))
+        tok[rng.random((T, B)) < 0.33] = V // 2          # one very frequent token
+        tok[0, 0] = V - 1
+        w = torch.tensor(rng.standard_normal((V, H)).astype(np.float32), device=DEV, requires_grad=True)
+        dy = torch.tensor(rng.standard_normal((T, B, H)).astype(np.float32), device=DEV)
+        tt = torch.tensor(tok, device=DEV)
+        grads = []
+        for _ in range(2):
+            w.grad = None
+            x = embedding(w, tt)
+            assert torch.equal(x, w.detach()[tt])
+            x.backward(dy)
+            grads.append(w.grad.clone())
+        assert torch.equal(grads[0], grads[1])
+        ref = np.zeros((V, H))
+        np.add.at(ref, tok.reshape(-1), dy.cpu().numpy().reshape(-1, H).astype(np.float64))
+        assert_grad(grads[0].cpu().numpy(), ref, f"embed.dW V{V} H{H}", rel=1e-5)
+        unused = np.setdiff1d(np.arange(V), tok.reshape(-1))
+        assert unused.size == 0 or not grads[0][torch.tensor(unused, device=DEV)].any()

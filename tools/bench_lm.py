@@ -155,7 +155,10 @@ def stock_nll(scores, y):          # lm_test.py:140-153 as written
     return torch.mean(-torch.log(answerprobs) * batch_size)
 
 
-def run(tag, group, fused):
+def run(tag, group, fused, head=False):
+    """head: Model.loss (projection + loss with the gradient formed in place, tuned GEMM forms, the package's embedding
+    gradient) instead of model(x) -> nll_loss(scores, y)."""
+    import vmlmf_amd
     torch.manual_seed(0)
     model = Model(V, H, 2, 0.0, 0.05, w_rank=32, u_ranks=[32], lstm_type="vmlmf")
     if group:   # the reference's Model cannot build the group layers (constructor quirk): put them in by hand
@@ -168,9 +171,14 @@ def run(tag, group, fused):
 
     def step():
         model.zero_grad(set_to_none=True)
-        scores, _ = model(x, [(h.detach(), c.detach()) for h, c in states])
-        loss = nll_loss(scores, y) if fused else stock_nll(scores, y)
-        loss.backward()
+        st = [(h.detach(), c.detach()) for h, c in states]
+        if head:
+            loss, _ = model.loss(x, y, st)
+            loss.backward(vmlmf_amd.unit_gradient(DEV))
+        else:
+            scores, _ = model(x, st)
+            loss = nll_loss(scores, y) if fused else stock_nll(scores, y)
+            loss.backward()
         if fused:
             optim.clip_sgd_step(model.parameters(), lr=1e-3, max_norm=5.0)
         else:
@@ -187,11 +195,13 @@ def run(tag, group, fused):
         step()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 10 * 1e3
-    print(json.dumps({"config": tag, "B": B, "T": T, "vocab": V, "fused_loss_and_update": fused,
+    print(json.dumps({"config": tag, "B": B, "T": T, "vocab": V, "fused_loss_and_update": fused, "head_in_place": head,
                       "ms_per_step_eager": round(ms, 3), "words_per_s": round(T * B / ms * 1e3)}), flush=True)
 
 
 if __name__ == "__main__":
+    run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, True, head=True)
+    run("E-model: Embed + 2 x MyVMLSTMGroup + Linear + nll", True, True, head=True)
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, True)
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, False)
     run("E-model: Embed + 2 x MyVMLSTMGroup + Linear + nll", True, True)

@@ -1198,6 +1198,29 @@ int vmlmf_nll_backward(int R, int V, const float* scores, const int64_t* y, floa
   return e == hipSuccess ? 0 : fail((int)e, hipGetErrorString(e));
 }
 
+size_t vmlmf_nll_grad_scratch_floats(int R, int V) { return (size_t)nll_grad_workgroups(R < 1 ? 1 : R) * (size_t)(V < 1 ? 1 : V); }
+
+int vmlmf_nll_forward_grad(int R, int V, float* scores, const float* bias, const int64_t* y, float scale, float* loss,
+                           float* rowloss, float* dbias, float* scratch, void* stream) {
+  if (R < 1 || V < 1) return fail(VMLMF_E_BADARG, "nll: R and V must be >= 1");
+  if (!scores || !y || !loss || !rowloss || !scratch) return fail(VMLMF_E_BADARG, "nll: null pointer");
+  const int rc = launch_nll_fwd_grad(R, V, scores, bias, (const long long*)y, scale, loss, rowloss, dbias, scratch, (hipStream_t)stream);
+  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "nll_forward_grad: rows must be 16-byte aligned, a multiple of four and at most 12288 wide");
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
+size_t vmlmf_embed_backward_scratch_bytes(int R, int V) { return embed_bwd_scratch_bytes(R < 1 ? 1 : R, V < 1 ? 1 : V); }
+
+int vmlmf_embed_backward(int R, int H, int V, const int64_t* tokens, const float* dy, float* dweight, void* scratch,
+                         size_t scratch_bytes, void* stream) {
+  if (R < 1 || H < 1 || V < 1) return fail(VMLMF_E_BADARG, "embed: R, H, V must be >= 1");
+  if (!tokens || !dy || !dweight) return fail(VMLMF_E_BADARG, "embed: null pointer");
+  const int rc = launch_embed_bwd(R, H, V, (const long long*)tokens, dy, dweight, scratch, scratch_bytes, (hipStream_t)stream);
+  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "embed_backward: embedding width > 1024");
+  if (rc == -4) return fail(VMLMF_E_WORKSPACE, "embed_backward: scratch smaller than vmlmf_embed_backward_scratch_bytes()");
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
 int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int k = 0; k < NKERN; ++k) {

@@ -157,6 +157,15 @@ hipError_t launch_nll_fwd(int R, int V, const float* scores, const long long* y,
 hipError_t launch_nll_bwd(int R, int V, const float* scores, const long long* y, float scale, const float* lse,
                           const float* dloss, float* dscores, hipStream_t s);
 
+// training form of the loss: loss, the scores' gradient (in place, for d(loss) = 1) and the bias gradient in one pass
+int nll_grad_workgroups(int R);
+int launch_nll_fwd_grad(int R, int V, float* scores, const float* bias, const long long* y, float scale, float* loss,
+                        float* rowloss, float* dbias, float* scratch, hipStream_t s);
+// embedding-table gradient (vmlmf_embed.hip)
+size_t embed_bwd_scratch_bytes(int R, int V);
+int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* dy, float* dW, void* scratch, size_t scratch_bytes,
+                     hipStream_t s);
+
 // ---- wavefront kernels for stacked layers (vmlmf_wave.inc) ----
 // One launch runs every layer of a stack: workgroup = (layer, batch row).  Besides the recurrence's compute waves a
 // workgroup has an "x-team" of as many waves that forms the layer's x-side pre-activations in-kernel (forward) / the

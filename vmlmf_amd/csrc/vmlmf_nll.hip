@@ -120,6 +120,106 @@ __global__ __launch_bounds__(256) void nll_bwd_kernel(int V, float scale, const 
   }
 }
 
+// ---- training form (ABI 9): loss AND the gradient of the scores in ONE pass over the matrix, in place ----------------------
+// The LM head's backward needs dscores = scale (softmax - onehot) and the bias gradient (its column sums); the two-kernel
+// form above reads the scores twice, writes a second 358 MB matrix and leaves the column sums to a third pass.  Here a
+// workgroup walks rows w, w + NWG, ...: a row (plus the bias, which the GEMM in front then need not add) lives in its
+// registers between max, sum and target pick, is written back IN PLACE as its own gradient (for d(loss) = 1; the caller
+// scales otherwise), and every thread keeps the column sums of the columns it owns over all its rows.  One read + one write
+// of the matrix; NWG x V column partials (fixed-order sum in nll_finish_kernel).
+constexpr int NLL_GQ = 12;   // float4 per thread: rows up to 256 * 12 * 4 = 12288 wide (192 VGPRs of row + bias + column sums)
+__global__ __launch_bounds__(256, 2) void nll_grad_kernel(int R, int V, float scale, float* __restrict__ scores,
+                                                          const float* __restrict__ bias, const long long* __restrict__ y,
+                                                          float* __restrict__ rowloss, float* __restrict__ dbpart) {
+  __shared__ float red[4];
+  const int tid = threadIdx.x, nq = V >> 2;
+  float4 bv[NLL_GQ], cs[NLL_GQ];
+#pragma unroll
+  for (int i = 0; i < NLL_GQ; ++i) {
+    const int q = tid + 256 * i;
+    const float4 t = bias != nullptr ? reinterpret_cast<const float4*>(bias)[q < nq ? q : 0] : make_float4(0.f, 0.f, 0.f, 0.f);
+    bv[i] = q < nq ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    cs[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  for (int row = blockIdx.x; row < R; row += gridDim.x) {
+    float* z = scores + (size_t)row * V;
+    float4 v[NLL_GQ];
+#pragma unroll
+    for (int i = 0; i < NLL_GQ; ++i) {   // clamped index: every load unconditional
+      const int q = tid + 256 * i;
+      v[i] = reinterpret_cast<const float4*>(z)[q < nq ? q : 0];
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NLL_GQ; ++i) {
+      const int q = tid + 256 * i;
+      v[i].x += bv[i].x, v[i].y += bv[i].y, v[i].z += bv[i].z, v[i].w += bv[i].w;
+      if (q >= nq) v[i] = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+    }
+    m = block_reduce<true>(m, red);
+    const long long t = y[row];
+    const bool inr = t >= 0 && t < V;
+    const int tc = inr ? (int)t : -1;
+    float s = 0.f, ztm = 0.f;   // ztm: (target's score - m), held by the thread that owns the target's column
+#pragma unroll
+    for (int i = 0; i < NLL_GQ; ++i) {   // keep the exponentials: they are the softmax numerators
+      const int q = tid + 256 * i;
+      if ((tc >> 2) == q) ztm = ((tc & 3) == 0 ? v[i].x : (tc & 3) == 1 ? v[i].y : (tc & 3) == 2 ? v[i].z : v[i].w) - m;
+      v[i].x = __expf(v[i].x - m), v[i].y = __expf(v[i].y - m), v[i].z = __expf(v[i].z - m), v[i].w = __expf(v[i].w - m);
+      s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    s = block_reduce<false>(s, red);
+    const float inv = scale / s;
+#pragma unroll
+    for (int i = 0; i < NLL_GQ; ++i) {
+      const int q = tid + 256 * i;
+      if (q < nq) {
+        if ((tc >> 2) == q) rowloss[row] = __logf(s) - ztm;   // lse - z_t
+        float4 o;
+        o.x = v[i].x * inv - (4 * q + 0 == tc ? scale : 0.f);
+        o.y = v[i].y * inv - (4 * q + 1 == tc ? scale : 0.f);
+        o.z = v[i].z * inv - (4 * q + 2 == tc ? scale : 0.f);
+        o.w = v[i].w * inv - (4 * q + 3 == tc ? scale : 0.f);
+        reinterpret_cast<float4*>(z)[q] = o;
+        cs[i].x += o.x, cs[i].y += o.y, cs[i].z += o.z, cs[i].w += o.w;
+      }
+    }
+    if (!inr && tid == 0) rowloss[row] = NAN;   // a target outside [0, V): NaN loss (the reference's indexing raises)
+  }
+#pragma unroll
+  for (int i = 0; i < NLL_GQ; ++i) {
+    const int q = tid + 256 * i;
+    if (q < nq) reinterpret_cast<float4*>(dbpart + (size_t)blockIdx.x * V)[q] = cs[i];
+  }
+}
+// dbias[v] = sum over the workgroups' column partials (fixed order); block 0 also finishes the loss
+__global__ __launch_bounds__(256) void nll_finish_kernel(int R, int V, int nwg, float scale, const float* __restrict__ rowloss,
+                                                         const float* __restrict__ dbpart, float* __restrict__ dbias,
+                                                         float* __restrict__ loss) {
+  __shared__ float red[4];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < V && dbias != nullptr) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    int w = 0;
+    for (; w + 7 < nwg; w += 8) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = dbpart[(size_t)(w + i) * V + c];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i & 3] += t[i];
+    }
+    for (; w < nwg; ++w) a[0] += dbpart[(size_t)w * V + c];
+    dbias[c] = (a[0] + a[1]) + (a[2] + a[3]);
+  }
+  if (blockIdx.x == 0) {
+    float part = 0.f;
+    for (int r = threadIdx.x; r < R; r += 256) part += rowloss[r];
+    const float total = block_reduce<false>(part, red);
+    if (threadIdx.x == 0) *loss = scale * total;
+  }
+}
+
 bool vec_ok(int V, const float* a, const float* b) {
   return V % 4 == 0 && (reinterpret_cast<uintptr_t>(a) & 15) == 0 && (b == nullptr || (reinterpret_cast<uintptr_t>(b) & 15) == 0);
 }
@@ -145,4 +245,19 @@ hipError_t launch_nll_bwd(int R, int V, const float* scores, const long long* y,
   else
     hipLaunchKernelGGL(nll_bwd_kernel<false>, dim3(R), dim3(256), 0, s, V, scale, scores, y, lse, dloss, dscores);
   return hipGetLastError();
+}
+
+// workgroups of nll_grad_kernel (two per CU: 192 + VGPRs each); the column partials need NWG x V floats of scratch
+int nll_grad_workgroups(int R) { return R < 512 ? R : 512; }
+
+// VMLMF_E_UNSUPPORTED (-3) when the in-register form does not cover the row width
+int launch_nll_fwd_grad(int R, int V, float* scores, const float* bias, const long long* y, float scale, float* loss,
+                        float* rowloss, float* dbias, float* scratch, hipStream_t s) {
+  if (!vec_ok(V, scores, bias) || V > 256 * NLL_GQ * 4) return -3;
+  const int nwg = nll_grad_workgroups(R);
+  hipLaunchKernelGGL(nll_grad_kernel, dim3(nwg), dim3(256), 0, s, R, V, scale, scores, bias, y, rowloss, scratch);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(nll_finish_kernel, dim3((V + 255) / 256), dim3(256), 0, s, R, V, nwg, scale, rowloss, scratch, dbias, loss);
+  return (int)hipGetLastError();
 }

@@ -419,6 +419,8 @@ class LmDataParallel:
         from .functional import nll_loss
         from .optim import clip_sgd_step
         self.model, self.lr, self.max_norm, self.group = model, lr, max_norm, group
+        # the package's own loss: taken inside Model.loss (projection + loss with the scores' gradient formed in place)
+        self._fused_loss = loss_fn is None and hasattr(model, "loss")
         self.loss_fn = loss_fn or nll_loss
         self.update_fn = update_fn or clip_sgd_step
         self.reducer = BucketedGradAllReduce(buckets or lm_buckets(model), op="sum", group=group, transport=transport)
@@ -437,10 +439,15 @@ class LmDataParallel:
     def forward_backward(self, x, y, states):
         self.model.zero_grad(set_to_none=True)
         states = self.model.detach(states)
-        scores, states = self.model(x, states)
-        loss = self.loss_fn(scores, y)
+        if self._fused_loss and x.is_cuda:
+            from .functional import unit_gradient
+            loss, states = self.model.loss(x, y, states)
+            root = unit_gradient(x.device)
+        else:
+            scores, states = self.model(x, states)
+            loss, root = self.loss_fn(scores, y), None
         self.reducer.arm()
-        loss.backward()
+        loss.backward(root)
         self.reducer.wait()
         return loss.detach(), states
 

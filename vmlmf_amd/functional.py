@@ -773,6 +773,198 @@ class LinearNllFn(torch.autograd.Function):
         return dh.view(ctx.hshape), dw, db, None, None
 
 
+# ---- the LM head for TRAINING: projection + loss with the gradient of the scores formed in place -------------------------------
+# (verdict r3 item 5.)  scores = h W^T is one library GEMM (fp32: rocBLAS / hipBLASLt run it at 120-140 TFLOP/s, 0.77-0.9 of the
+# fp32 matrix peak - profiles/r03_lm_head_fusion.jsonl: a hand-written kernel would have to match that to pay); everything
+# between the three GEMMs is this package's: vmlmf_nll_forward_grad adds the bias, takes the loss and overwrites the scores
+# with their own gradient in ONE pass (the bias gradient falls out as column sums), so the backward's two GEMMs read the
+# gradient where the forward left it - no second 358 MB matrix, no separate bias reduction, no backward loss kernel.
+# Which library and which operand layout serves each of the three products best differs by 10-25 % (tools/experiments/
+# gemm_probe.py: dW as dz^T h runs at 96-104 TFLOP/s, as (h^T dz)^T at 119 on rocBLAS); the forms are timed once per shape on the
+# device and the fastest is kept (VMLMF_HEAD_TUNE=0: the first form of each list).
+_HEAD_FORMS = {}
+
+
+def _blas_libs():
+    libs = [None]
+    if hasattr(torch.backends.cuda, "preferred_blas_library"):
+        libs += ["hipblaslt", "cublas"]          # ("cublas" is rocBLAS on ROCm)
+    return libs
+
+
+class _with_blas:
+    def __init__(self, lib):
+        self.lib, self.prev = lib, None
+
+    def __enter__(self):
+        if self.lib is not None:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                self.prev = torch.backends.cuda.preferred_blas_library()
+                torch.backends.cuda.preferred_blas_library(self.lib)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                torch.backends.cuda.preferred_blas_library(self.prev)
+        return False
+
+
+def _head_products():
+    """name -> [(label, fn)] candidate forms; every fn returns a contiguous result."""
+    return {
+        "fwd": [("mm(h, W^T)", lambda h, w: torch.mm(h, w.t()))],
+        "dh": [("mm(dz, W)", lambda dz, w: torch.mm(dz, w))],
+        "dw": [("mm(dz^T, h)", lambda dz, h: torch.mm(dz.t(), h)),
+               ("mm(h^T, dz)^T", lambda dz, h: torch.mm(h.t(), dz).t().contiguous())],
+    }
+
+
+def head_forms(R, H, V, device):
+    """The (library, form) chosen for each of the LM head's three GEMMs at this shape; timed on first use."""
+    import os
+    key = (R, H, V, device.index)
+    hit = _HEAD_FORMS.get(key)
+    if hit is not None:
+        return hit
+    prods = _head_products()
+    tune = os.environ.get("VMLMF_HEAD_TUNE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
+    chosen = {k: (None, v[0][0], v[0][1], None) for k, v in prods.items()}
+    if tune:
+        with torch.no_grad():
+            a = {"fwd": (torch.randn(R, H, device=device), torch.randn(V, H, device=device)),
+                 "dh": (torch.randn(R, V, device=device), torch.randn(V, H, device=device)),
+                 "dw": (torch.randn(R, V, device=device), torch.randn(R, H, device=device))}
+            for name, forms in prods.items():
+                best = None
+                for lib in _blas_libs():
+                    for label, fn in forms:
+                        try:
+                            with _with_blas(lib):
+                                fn(*a[name])
+                                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                                e0.record()
+                                for _ in range(3):
+                                    fn(*a[name])
+                                e1.record()
+                            e1.synchronize()
+                            ms = e0.elapsed_time(e1) / 3
+                        except RuntimeError:
+                            continue
+                        if best is None or ms < best[3]:
+                            best = (lib, label, fn, ms)
+                if best is not None:
+                    chosen[name] = best
+            del a
+    if tune or not torch.cuda.is_current_stream_capturing():
+        _HEAD_FORMS[key] = chosen
+    return chosen
+
+
+def _run_form(form, *args):
+    lib, _, fn, _ = form
+    with _with_blas(lib):
+        return fn(*args)
+
+
+class LmHeadLossFn(torch.autograd.Function):
+    """loss = nll_loss(Linear(h), y) (vmlmf_lm.py:355-358 + lm_test.py:140-153) for training; see the block comment above."""
+
+    @staticmethod
+    def forward(ctx, h, w, b, y):
+        _require_hip(h, "h")
+        _require_hip(w, "fc.w")
+        H = h.shape[-1]
+        h2 = h.reshape(-1, H).contiguous()
+        w = w.contiguous()
+        R, V = h2.shape[0], w.shape[0]
+        forms = head_forms(R, H, V, h.device)
+        scores = _run_form(forms["fwd"], h2, w)                       # (R, V), no bias
+        yrow = y.reshape(-1).contiguous()
+        scale = float(y.size(1)) / float(R)
+        stats = torch.empty(1 + R, device=h.device, dtype=torch.float32)          # loss | rowloss
+        dbias = torch.empty(V, device=h.device, dtype=torch.float32) if b is not None else None
+        lib = _lib.lib()
+        scratch = _workspace(h.device, 4 * lib.vmlmf_nll_grad_scratch_floats(R, V))
+        with _lib.on_device(h.device):
+            _lib.check(lib.vmlmf_nll_forward_grad(R, V, _ptr(scores), _ptr(None if b is None else b.contiguous()), _ptr(yrow), scale,
+                                                  stats.data_ptr(), stats.data_ptr() + 4, _ptr(dbias), scratch.data_ptr(),
+                                                  _lib.raw_stream(h.device)))
+        ctx.save_for_backward(h2, w, scores, *([dbias] if dbias is not None else []))
+        ctx.hshape, ctx.forms, ctx.has_b = h.shape, forms, b is not None
+        return stats[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        h2, w, dz = ctx.saved_tensors[:3]
+        dbias = ctx.saved_tensors[3] if ctx.has_b else None
+        unit = _UNIT.get(dz.device)
+        scaled = not (unit is not None and dloss.data_ptr() == unit.data_ptr())
+        dh = _run_form(ctx.forms["dh"], dz, w) if ctx.needs_input_grad[0] else None
+        dw = _run_form(ctx.forms["dw"], dz, h2) if ctx.needs_input_grad[1] else None
+        db = dbias if (ctx.has_b and ctx.needs_input_grad[2]) else None
+        if scaled:                                   # d(loss) is not the package's constant one: the stored gradient is for 1
+            dh = None if dh is None else dh.mul_(dloss)
+            dw = None if dw is None else dw.mul_(dloss)
+            db = None if db is None else db * dloss
+        return (None if dh is None else dh.view(ctx.hshape)), dw, db, None
+
+
+def lm_head_loss(h, weight, bias, y):
+    """Training form of nll_loss(Linear(h), y): h (T, B, H), weight (V, H), bias (V), y (T, B) int64 -> scalar loss whose
+    backward reads the scores' gradient where the forward left it.  Call loss.backward(vmlmf_amd.unit_gradient(device)) to spare
+    the three scalings a foreign d(loss) tensor costs.  Vocabulary widths the in-register loss does not cover (not a multiple
+    of four, beyond 12288) and CPU tensors take projection + nll_loss."""
+    V = weight.shape[0]
+    if h.is_cuda and h.dtype == torch.float32 and y.dtype == torch.int64 and V % 4 == 0 and V <= 12288:
+        return LmHeadLossFn.apply(h, weight, bias, y)
+    return nll_loss(torch.addmm(bias, h.reshape(-1, h.shape[-1]), weight.t()), y)
+
+
+class EmbedFn(torch.autograd.Function):
+    """x = w[tokens] (Embed, vmlmf_lm.py:46-48) whose backward is the package's deterministic scatter-add (vmlmf_embed_backward:
+    every row of the table's gradient summed in position order, no float atomics, the zero fill in the same pass)."""
+
+    @staticmethod
+    def forward(ctx, w, tokens):
+        ctx.save_for_backward(tokens)
+        ctx.wshape = w.shape
+        return torch.nn.functional.embedding(tokens, w)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (tokens,) = ctx.saved_tensors
+        V, H = ctx.wshape
+        dy2 = dy.reshape(-1, H).contiguous()
+        R = dy2.shape[0]
+        tok = tokens.reshape(-1).contiguous()
+        dw = torch.empty((V, H), device=dy.device, dtype=torch.float32)
+        lib = _lib.lib()
+        nbytes = lib.vmlmf_embed_backward_scratch_bytes(R, V)
+        if torch.cuda.is_current_stream_capturing():
+            scratch = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
+        else:
+            key = ("embed", dy.device.index, _lib.raw_stream(dy.device).value)
+            scratch = _WORKSPACE.get(key)
+            if scratch is None or scratch.numel() < nbytes:
+                scratch = _WORKSPACE[key] = torch.empty(nbytes, device=dy.device, dtype=torch.uint8)
+        with _lib.on_device(dy.device):
+            _lib.check(lib.vmlmf_embed_backward(R, H, V, _ptr(tok), _ptr(dy2), _ptr(dw), scratch.data_ptr(), nbytes,
+                                                _lib.raw_stream(dy.device)))
+        return dw, None
+
+
+def embedding(weight, tokens):
+    """weight[tokens] with the package's backward on HIP fp32 tables up to 1024 wide and 64 MB of position bits; the stock op otherwise."""
+    if (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.shape[1] <= 1024 and tokens.dtype == torch.int64
+            and weight.is_contiguous() and weight.shape[0] * ((tokens.numel() + 31) // 32) * 4 <= (64 << 20)):
+        return EmbedFn.apply(weight, tokens)
+    return weight[tokens]
+
+
 def linear_nll(h, weight, bias, y, chunk_rows=2048, fused=None):
     """loss = nll_loss(Linear(h), y) of the LM loop (vmlmf_lm.py:355-358 + lm_test.py:140-153): h (T, B, H), weight (V, H), bias
     (V), y (T, B) int64.  fused=None: the chunked form without the score tensor when no gradient is needed (evaluation,

@@ -149,7 +149,8 @@ class Embed(nn.Module):
         self.w = nn.Parameter(torch.zeros(vocab_size, embed_size))
 
     def forward(self, x):
-        return self.w[x]
+        from .functional import embedding
+        return embedding(self.w, x)      # the gather is the stock op; the table's gradient is the package's kernel on HIP tensors
 
     def __repr__(self):
         return f"Embedding(vocab: {self.vocab_size}, embedding: {self.embed_size})"
@@ -246,6 +247,20 @@ class Model(nn.Module):
         return y, [(hs[i], cs[i]) for i in range(len(self.rnns))]
 
     def forward(self, x, states):
+        x, states = self.features(x, states)
+        scores = self.fc(x)
+        return scores, states
+
+    def loss(self, x, y, states):
+        """nll_loss(self(x, states)[0], y) of the training loop (lm_test.py:200-202) without ever handing out the scores: the
+        projection's output is overwritten by its own gradient inside the loss (functional.lm_head_loss), which is what the two
+        backward GEMMs read.  Returns (loss, states); same values as the two-call form."""
+        from .functional import lm_head_loss
+        h, states = self.features(x, states)
+        return lm_head_loss(h, self.fc.w, self.fc.b, y), states
+
+    def features(self, x, states):
+        """Everything of forward() in front of the vocabulary projection (vmlmf_lm.py:434-439): (T, B, H) activations, states."""
         x = self.embed(x)
         x = self.dropout(x)
         stacked = self._stack(x, states)
@@ -258,5 +273,4 @@ class Model(nn.Module):
             for i, rnn in enumerate(self.rnns):
                 x, states[i] = rnn(x, states[i])
                 x = self.dropout(x)
-        scores = self.fc(x)
-        return scores, states
+        return x, states
