@@ -233,6 +233,44 @@ def other_configs(iters=100):
     out["timesteps_per_s"] = round(24 / (out["ms_per_step"] * 1e-3), 1)
     out["workload"] = "BASELINE configs[2] in fp32: 2 x MyVMLMFCell(256), rank 24, B 128, T 24, I 77; RNN stack forward + backward, hipGraph replay"
     res = {"C_fp32": out}
+    # the same workload on the bf16-MFMA variant (row-block kernels, bf16 tapes; set_compute_dtype): what configs[2] names.  It is
+    # timed here every round so that the choice of fp32 as configs[2]'s default rests on a driver-timed number
+    try:
+        from vmlmf_amd import set_compute_dtype
+        torch.manual_seed(0)
+        rnn_b = MyLSTM(77, hidden_layer_sizes=[256, 256], batch_first=True, w_rank=24, u_ranks=[24], cell=MyVMLMFCell).cuda()
+        set_compute_dtype(rnn_b, "bf16")
+        xb = torch.randn(128, 24, 77, device="cuda")
+
+        def fbb():
+            rnn_b.zero_grad(set_to_none=True)
+            yb, _ = rnn_b(xb)
+            yb[:, -1].sum().backward()
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                fbb()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        gb = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gb):
+            fbb()
+        for _ in range(10):
+            gb.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            gb.replay()
+        torch.cuda.synchronize()
+        msb = (time.perf_counter() - t0) / iters * 1e3
+        res["C_bf16"] = {"ms_per_step": round(msb, 4), "timesteps_per_s": round(24 / (msb * 1e-3), 1),
+                         "vs_fp32": round(msb / out["ms_per_step"], 2),
+                         "workload": "BASELINE configs[2] as named (bf16 MFMA): the same stack on the row-block bf16 kernels, bf16 tapes, fp32 state; "
+                                     "hipGraph replay.  Slower than fp32 at this batch (8 workgroups x 16 rows): fp32 stays the default"}
+    except Exception as e:   # never at the expense of the line
+        res["C_bf16"] = {"error": f"{type(e).__name__}: {e}"}
     # BASELINE configs[4] on one GPU: two PTB group layers (H 650, ranks 32 / [32, 32]), B 256, T 35 (clustered row-block kernels)
     from vmlmf_amd import MyVMLSTMGroup
     torch.manual_seed(0)

@@ -146,9 +146,12 @@ int vmlmf_seq_forward(const vmlmf_desc *d, const vmlmf_params *p, const float *x
  * `packed` must have been made for the same descriptor (batch and sequence length may differ) and must stay unchanged until the
  * backward that uses it has run; it is the caller's duty to re-pack after ANY change of the parameters.  Not offered for
  * the step-wise / clustered layers (VMLMF_E_UNSUPPORTED): their image carries per-call state.  vmlmf_tune_generation()
- * counts vmlmf_tune() calls: images made under an older generation may have another layout.  The forward and backward calls
- * do NOT verify that an image matches their descriptor or the current generation (the image is device memory and they never
- * synchronise): an image made for another descriptor or generation is used as it is and yields wrong results.
+ * counts vmlmf_tune() calls (and the library's own switch after a failed riding launch): images made under an older
+ * generation may have another layout.  ABI 9: the library keeps, on the host, what every image was packed for (its device
+ * address -> variant, sizes, ranks, kernel family, generation; the last 256 images of the process); a *_packed call with an
+ * address vmlmf_pack_params did not fill, or with an image packed for another descriptor (batch and sequence length apart)
+ * or under another generation, returns VMLMF_E_BADARG and launches nothing.  What it cannot see is a change of the PARAMETER
+ * VALUES since the image was packed: re-packing after an optimizer step stays the caller's duty.
  */
 int vmlmf_pack_bytes(const vmlmf_desc *d, size_t *bytes);
 int vmlmf_pack_params(const vmlmf_desc *d, const vmlmf_params *p, void *packed, void *stream);

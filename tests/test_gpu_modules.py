@@ -733,3 +733,59 @@ def test_embedding_gradient_is_a_position_ordered_sum_without_atomics():
         assert_grad(grads[0].cpu().numpy(), ref, f"embed.dW V{V} H{H}", rel=1e-5)
         unused = np.setdiff1d(np.arange(V), tok.reshape(-1))
         assert unused.size == 0 or not grads[0][torch.tensor(unused, device=DEV)].any()
+
+
+def test_a_packed_image_made_for_something_else_is_refused():
+    """Verdict r3 (hygiene): the geometry header in front of a kept parameter image was written and never checked.  The
+    signature now lives on the host (address -> what the image was packed for): a *_packed call with an image of another
+    descriptor, an address vmlmf_pack_params never filled, or an image from before a vmlmf_tune() call returns VMLMF_E_BADARG
+    and launches nothing; the matching image still works, for any batch / length."""
+    import ctypes
+    from vmlmf_amd import _lib
+    from vmlmf_amd.functional import _params_struct, _ptr
+    lib = _lib.lib()
+    dev = torch.device("cuda", 0)
+    stream = _lib.raw_stream(dev)
+
+    def layer(I, H, rw, ru, B=8, T=5):
+        P = O.make_params(O.V1, I, H, rw, ru, seed=H)
+        names = ["dia_x", "dia_h", "u_x", "v_x", "b_x", "b_h", "u_h", "v_h"]
+        params = [torch.tensor(np.asarray(P[k]), device=DEV) for k in names]
+        desc = _lib.make_desc(_lib.V1_CELL, B, T, I, H, rw, [ru], training=False)
+        return desc, params, _params_struct(params, 1, _lib.V1_CELL)
+
+    def pack(desc, ps):
+        n = ctypes.c_size_t()
+        _lib.check(lib.vmlmf_pack_bytes(ctypes.byref(desc), ctypes.byref(n)))
+        img = torch.empty(n.value, device=DEV, dtype=torch.uint8)
+        _lib.check(lib.vmlmf_pack_params(ctypes.byref(desc), ctypes.byref(ps), _ptr(img), stream))
+        return img
+
+    def forward(desc, ps, img, B, T, I, H):
+        d2 = _lib.make_desc(_lib.V1_CELL, B, T, I, H, desc.w_rank, [desc.u_ranks[0]], training=False)
+        sz = _lib.query(d2)
+        x = torch.randn(B, T, I, device=DEV)
+        y, hT, cT = torch.empty(B, T, H, device=DEV), torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+        ws = torch.empty(sz.workspace_bytes, device=DEV, dtype=torch.uint8)
+        return lib.vmlmf_seq_forward_packed(ctypes.byref(d2), ctypes.byref(ps), _ptr(x), None, None, _ptr(y), _ptr(hT), _ptr(cT), None,
+                                            _ptr(ws), sz.workspace_bytes, stream, _ptr(img)), y
+
+    dA, pA, sA = layer(9, 64, 8, 8)
+    dB, pB, sB = layer(9, 100, 8, 16)
+    imgA, imgB = pack(dA, sA), pack(dB, sB)
+    rc, y1 = forward(dA, sA, imgA, 8, 5, 9, 64)
+    assert rc == 0
+    rc, y2 = forward(dA, sA, imgA, 3, 11, 9, 64)                  # batch and length may differ
+    assert rc == 0 and torch.isfinite(y2).all()
+    rc, _ = forward(dA, sA, imgB, 8, 5, 9, 64)                    # an image packed for the other layer
+    assert rc == _lib.E_BADARG and "another descriptor" in lib.vmlmf_last_error().decode()
+    stray = torch.zeros(imgA.numel(), device=DEV, dtype=torch.uint8)
+    rc, _ = forward(dA, sA, stray, 8, 5, 9, 64)                   # memory vmlmf_pack_params never filled
+    assert rc == _lib.E_BADARG and "not an image" in lib.vmlmf_last_error().decode()
+    _lib.tune("rec3", 6)                                          # any vmlmf_tune() call moves the generation
+    rc, _ = forward(dA, sA, imgA, 8, 5, 9, 64)
+    assert rc == _lib.E_BADARG
+    imgA2 = pack(dA, sA)
+    rc, y3 = forward(dA, sA, imgA2, 8, 5, 9, 64)
+    assert rc == 0
+    torch.cuda.synchronize()

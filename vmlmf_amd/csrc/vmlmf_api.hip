@@ -545,14 +545,52 @@ int vmlmf_query(const vmlmf_desc* d, vmlmf_sizes* out) {
 }
 
 // ---- parameter images kept by the caller (vmlmf_pack_params / *_packed) ----
-// header in front of the image: what geometry it was packed for.  It documents the image (a debugger can read it); it is NOT
-// checked by the forward / backward calls - the image lives in device memory and they never synchronise.  Matching an image
-// with its descriptor and with the vmlmf_tune() generation it was made under is the caller's job (the Python PackCache keys
-// on both; include/vmlmf_hip.h says so).
+// An image is only valid for the geometry and the kernel selection (vmlmf_tune generation) it was packed for, and it lives in
+// device memory, which the forward / backward calls never read back.  So the signature is kept ON THE HOST: vmlmf_pack_params
+// records (device address -> signature) in a small registry, and a *_packed call whose image is unknown, or was packed for
+// another geometry or under another kernel selection, returns VMLMF_E_BADARG instead of running kernels on a foreign layout
+// (verdict r3: the header that used to sit in front of the image was written and never checked).  The registry holds the last
+// PK_REG images per process; an image that fell out has to be packed again.  The 256 bytes in front of the image stay
+// reserved (alignment of the images behind them).
 constexpr int PK_HDR = 64;   // floats
-static void pack_signature(const VGeo& g, const VPack& P, const RbGeo& q, float* sig) {
-  const long long v[8] = {0x564d4c4dLL, P.total, g.rb, g.generic, g.bf, g.NT, (long long)g.KH * 1000 + g.KX, q.total};
-  for (int i = 0; i < 8; ++i) sig[i] = (float)(v[i] % 16777216LL);
+struct PackSig {
+  long long v[10];
+  bool operator==(const PackSig& o) const { return memcmp(v, o.v, sizeof(v)) == 0; }
+};
+static PackSig pack_signature(const VGeo& g, const VPack& P, const RbGeo& q) {
+  PackSig s;
+  const long long v[10] = {g.variant, P.total, g.rb, g.generic * 2 + g.bf, g.NT, (long long)g.KH * 1000 + g.KX, q.total,
+                           (long long)g.I * 100000 + g.H, (long long)g.G * 100000 + g.ru0 * 100 + g.ru1, g_tune_generation};
+  memcpy(s.v, v, sizeof(v));
+  return s;
+}
+constexpr int PK_REG = 256;
+struct PackReg {
+  std::mutex mu;
+  const void* ptr[PK_REG] = {nullptr};
+  PackSig sig[PK_REG];
+  int next = 0;
+  void put(const void* p, const PackSig& s) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < PK_REG; ++i)
+      if (ptr[i] == p) { sig[i] = s; return; }
+    ptr[next] = p, sig[next] = s;
+    next = (next + 1) % PK_REG;
+  }
+  // 0 = matches, 1 = unknown image, 2 = packed for something else
+  int check(const void* p, const PackSig& s) {
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < PK_REG; ++i)
+      if (ptr[i] == p) return sig[i] == s ? 0 : 2;
+    return 1;
+  }
+} g_packreg;
+static int check_packed(const void* packed, const VGeo& g, const VPack& P, const RbGeo& q) {
+  switch (g_packreg.check(packed, pack_signature(g, P, q))) {
+    case 0: return 0;
+    case 1: return fail(VMLMF_E_BADARG, "packed: not an image vmlmf_pack_params made at this address (or it left the registry of the last 256 images: pack it again)");
+  }
+  return fail(VMLMF_E_BADARG, "packed: the image was packed for another descriptor or under another kernel selection (vmlmf_tune): pack it again");
 }
 
 int vmlmf_pack_bytes(const vmlmf_desc* d, size_t* bytes) {
@@ -578,9 +616,7 @@ int vmlmf_pack_params(const vmlmf_desc* d, const vmlmf_params* p, void* packed, 
   const VPack P = vg_pack_layout(g, q.total);
   hipStream_t s = (hipStream_t)stream;
   float* img = (float*)packed + PK_HDR;
-  float sig[PK_HDR] = {0};
-  pack_signature(g, P, q, sig);
-  if ((rc = (int)hipMemcpyAsync(packed, sig, sizeof(sig), hipMemcpyHostToDevice, s)) != 0) return hip_fail(rc, "pack header");
+  g_packreg.put(packed, pack_signature(g, P, q));
   const RefP rp = to_refp(p);
   Scope sc(0, s);
   if ((rc = hip_fail(launch_pack(g, rp, P, img, s), "pack")) != 0) return rc;
@@ -637,6 +673,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   float* pack = g.training ? rs + L.r_pack : ws + L.f_pack;
   if (packed != nullptr) {   // the caller's image (vmlmf_pack_params): nothing is packed here
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
+    if ((rc = check_packed(packed, g, P, q)) != 0) return rc;
     pack = const_cast<float*>((const float*)packed) + PK_HDR;
   }
   float* gx = ws + L.f_gx;
@@ -786,6 +823,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
+    if ((rc = check_packed(packed, g, P, q)) != 0) return rc;
     pack = (const float*)packed + PK_HDR;
   }
   if (g.rb) {
