@@ -115,6 +115,11 @@ const char *vmlmf_last_error(void);
  *                   0: always the stand-alone kernel behind it.  The library sets 0 by itself after a riding worker gave up
  *                   its bounded wait (VMLMF_E_PROTOCOL; a GPU shared with other processes can starve the workers of their
  *                   rows); 1 re-arms
+ *   "inrow"         the backward that forms the weight gradients inside the rows' workgroups (no dpre tape, no weight-gradient
+ *                   launch; layers with the x-fold whose input needs no gradient): -1 (default) automatic - batches beyond the
+ *                   riding workers' range -, 0 never, 1 wherever it covers the layer
+ *   "rb_xfold"      1: clustered layers form the x side of their pre-activations inside the forward recurrence (from x and
+ *                   qx = x U_x) instead of reading the (T, B, 4H) tensor; 0 (default: measured no faster)
  *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)
  */
 int vmlmf_tune(const char *key, int value);

@@ -246,3 +246,35 @@ def test_cluster_exchange_is_bit_stable_under_uneven_load():
         else:
             for k, (u, v) in enumerate(zip(first, got)):
                 assert torch.equal(u, v), f"repetition {it}: tensor {k} differs from the first run (max {float((u - v).abs().max()):.3e})"
+
+
+@pytest.mark.parametrize("case", [(O.V4, 40, 4, 650, 650, 32, [32, 32]), (O.V3, 24, 5, 650, 650, 32, [32]), (O.V1, 18, 3, 20, 600, 8, [8]),
+                                  (O.V3, 16, 3, 400, 400, 12, [20])],
+                         ids=lambda c: "v%d_B%d_T%d_I%d_H%d_r%d" % c[:6])
+def test_x_side_formed_inside_the_clustered_forward(case):
+    """vmlmf_tune("rb_xfold", 1): rb_fwd_kernel<..., XF> forms the x-side pre-activations itself (a third MFMA product from qx
+    and the V_x image, x . ex + b on the accumulator layout) instead of reading what xexp_mfma_kernel writes.  Not the default
+    (measured no faster, vmlmf_rb.hip), kept parity-green: against the fp64 oracle, and bit for bit against... nothing - the two
+    forms sum in different orders - so both are held to the oracle at the suite's tolerance.  Narrow inputs (I < H), x-ranks
+    that are not a multiple of 16, both cluster layouts."""
+    variant, B, T, I, H, rw, ru = case
+    tm = variant in (O.V3, O.V4)
+    rng = np.random.Generator(np.random.PCG64(17 * B + H))
+    P = O.make_params(variant, I, H, rw, ru if variant == O.V4 else ru[0], seed=H + B, scale=0.05 if tm else 0.1)
+    shp = (T, B, I) if tm else (B, T, I)
+    x = (0.5 * rng.standard_normal(shp)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32)
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
+    _lib.tune("rb_cluster", 16)
+    _lib.tune("rb_rows", 16)          # full tiles: the x-fold is only taken with 16 live rows per workgroup
+    try:
+        for xf in (1, 0):
+            _lib.tune("rb_xfold", xf)
+            got = run_hip(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
+            compare_all(got, ref, f"rb.xfold{xf}")
+    finally:
+        _lib.tune("rb_xfold", 0)
+        _lib.tune("rb_rows", 0)

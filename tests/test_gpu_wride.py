@@ -270,7 +270,9 @@ def _har_net(seed=0):
     from vmlmf_amd import MyLSTM, MyVMLMFCell, Net
     torch.manual_seed(seed)
     net = Net(9, layer_sizes=[180], w_rank=16, u_rank=[16], model=MyLSTM, cell=MyVMLMFCell).cuda()
-    x = torch.randn(64, 40, 9, device="cuda")
+    # (the headline length: the rows need ~66 us, far longer than the two looks a worker takes under test_wride_spin = 1 - with 40
+    #  steps a graph replay finished the whole recurrence inside the first nap and nothing gave up)
+    x = torch.randn(64, 128, 9, device="cuda")
     t = torch.randint(0, 18, (64,), device="cuda")
     return net, x, t
 
@@ -325,8 +327,8 @@ def test_nan_gradients_of_a_failed_step_never_reach_the_parameters():
         for p, gh in zip(live, gheld):
             assert torch.equal(torch.nan_to_num(p.grad, nan=7.0), torch.nan_to_num(gh, nan=7.0))    # gradients not scaled either
     finally:
-        _lib.tune("test_wride_spin", 0)
-        _clear_status()
+        _clear_status()                      # (while the test bound is still set: a give-up under the PRODUCTION bound would
+        _lib.tune("test_wride_spin", 0)      #  switch the process to the stand-alone weight-gradient kernel for good)
     step(net, opt), step(ref, ropt)                      # step 2 of the trajectory, as if the failed one had not happened
     for (k, p), q in zip(net.named_parameters(), ref.parameters()):
         assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), k
@@ -344,6 +346,7 @@ def test_graphed_train_step_captures_again_after_a_failed_replay():
     net, x, t = _har_net(1)
     opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.01)
     _clear_status()
+    _lib.tune("wride", 1)                # (whatever ran before in this process: the riding form is armed)
     gstep = vmlmf_amd.GraphedTrainStep(net, vmlmf_amd.cross_entropy, opt, x, t)
     gstep(x, t)
     torch.cuda.synchronize()
@@ -358,6 +361,8 @@ def test_graphed_train_step_captures_again_after_a_failed_replay():
             assert torch.equal(p.detach(), h)            # the failed step's update never happened
         assert opt.skipped_steps() == 1
     finally:
+        # back to the production bound WITHOUT looking at the status word: the failure stays pending for the next call to find
+        # (found under the production bound it also switches the process to the stand-alone kernel - what a real failure does)
         _lib.tune("test_wride_spin", 0)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
@@ -367,15 +372,10 @@ def test_graphed_train_step_captures_again_after_a_failed_replay():
     assert torch.isfinite(loss) and opt.skipped_steps() == 1
     assert any(not torch.equal(p.detach(), h) for p, h in zip(net.parameters(), held))      # this one did update
     assert all(torch.isfinite(p).all() for p in net.parameters())
-    _lib.tune("wride", 0)                                # kernel selection changes, nothing failed: generation moves
-    try:
-        gstep(x, t)
-        assert gstep.recaptures == 3 and gstep.failed_steps == 1
-    finally:
-        _lib.tune("wride", 1)
+    _lib.tune("wride", 1)                                # re-arm (the library switched itself off): the generation moves
     gstep(x, t)
     torch.cuda.synchronize()
-    assert gstep.recaptures == 4 and all(torch.isfinite(p).all() for p in net.parameters())
+    assert gstep.recaptures == 3 and gstep.failed_steps == 1 and all(torch.isfinite(p).all() for p in net.parameters())
     _lib.check_status()
 
 

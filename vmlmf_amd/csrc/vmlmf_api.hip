@@ -684,9 +684,12 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   }
   // narrow-input layers compute the x-projection inside rec_fwd_kernel (VMLMF_XWAVE=0: always the separate launch)
   const bool xwave = g_xwave && vg_xwave_ok(g);
+  // clustered layers with one tile per wave form the x side inside rb_fwd_kernel (from x and qx): only qx is produced here
+  const bool rbx = g.rb && g.generic && rb_xfold_ok(g, q);
+  float* const qxbuf = g.training ? rs + L.r_qx : (g.generic ? ws + L.f_qx : nullptr);
   if (!xwave) {
     Scope sc(1, s);
-    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, g.training ? rs + L.r_qx : (g.generic ? ws + L.f_qx : nullptr), s), "xproj")) != 0)
+    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, qxbuf, s, rbx), "xproj")) != 0)
       return rc;
   }
   if (g.rb) {
@@ -700,6 +703,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
     io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word(s);
+    io.x = x, io.qx = qxbuf, io.EXT = pack + P.EXT, io.BBT = pack + P.BBT, io.xfold = rbx ? 1 : 0;
     {
       Scope sc(2, s);
       if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
@@ -1161,6 +1165,7 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "rec3") g_rec3 = value;
   else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
   else if (k == "inrow") g_inrow = value;
+  else if (k == "rb_xfold") rb_set_xfold(value);
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

@@ -110,7 +110,14 @@ struct RbIo {
   float* xq;        // cluster exchange tiles (S > 1)
   unsigned* flag;   // cluster epoch words + error word
   unsigned* status; // host-visible status word (or NULL)
+  // x-fold (rb_xfold_ok): the forward forms the x-side pre-activations itself from x, qx = x U_x and the V_x image; gx is not read
+  const float *x, *qx, *EXT, *BBT;
+  int xfold;
 };
+// the clustered forward can form the x side of its pre-activations in-kernel (a third MFMA product, K = the padded x rank) instead
+// of reading the (T, B, 4H) tensor xexp_mfma_kernel would write: one tile per wave, fp32
+bool rb_xfold_ok(const VGeo& g, const RbGeo& q);
+void rb_set_xfold(int on);
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
 bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s);
@@ -121,7 +128,7 @@ int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 // instantiation covers the geometry
 int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s);
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
-                 hipStream_t s);
+                 hipStream_t s, bool qx_only = false);   // qx_only: the consumer forms the expansion itself (rb x-fold)
 int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 // third form of the recurrent kernels (vmlmf_rec3.inc): one-group layers, padded hidden rank <= 16, <= 3 waves of units; the

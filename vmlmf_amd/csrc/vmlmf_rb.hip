@@ -48,6 +48,11 @@ __device__ inline float rb_udz(const VGeo& g, const RefP& p, int row, int slot) 
   const int dest = (n / g.Hg - s + g.G) % g.G;
   return dest == j ? ref_uc(g, p, n, rr) : 0.f;
 }
+__device__ inline float rb_vx(const VGeo& g, const RefP& p, int slot, int k, int r) {
+  int n;
+  if (!vg_slot_unit(g, slot, n) || r >= g.KX) return 0.f;
+  return ref_vx(g, p, n, k, r);
+}
 __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int rr) {
   int n;
   if (!vg_slot_unit(g, slot, n) || rr >= g.KH) return 0.f;
@@ -60,13 +65,16 @@ __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int
 //   VA[tv][k][s4]     expand (fwd):   unit c of the tile, gate k     x  rank 4 s4 + kq
 //   VB[tv][k][mv][r]  reduce (bwd):   rank 16 mv + pi(c)             x  (unit 4 kq + r, gate k)
 //   UB[tv][m][r]      expand (bwd):   unit c of the tile             x  row 16 m + 4 r + kq of the padded rank space
+//   VXA[tv][k][s4]    x side (fwd):   unit c of the tile, gate k     x  x-rank 4 s4 + kq   (as VA: contraction step s4 covers the
+//                                     contiguous ranks 4 s4 .. 4 s4 + 3, so a width that is not a multiple of 16 skips its padding)
 // ---------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out) {
   // 32-bit index arithmetic throughout (64-bit divisions by run-time values cost hundreds of cycles each: the first
   // version of this kernel took 290 us at the PTB shape, 0.5 M elements)
   const int NTV = g.G * q.TPGV, KS = g.KH / 4, NP = g.NP, NMT = q.NMT;
   const int nUA = NTV * NMT * 4 * 64, nVA = NTV * 4 * KS * 64, nVB = NTV * 4 * NP * 4 * 64;
-  const int total = 2 * nUA + nVA + nVB;
+  const int KSX = g.KX / 4, nVXA = NTV * 4 * KSX * 64;
+  const int total = 2 * nUA + nVA + nVB + nVXA;
   const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (e >= total) return;
   const int lane = e & 63, c = lane & 15, kq = lane >> 4;
@@ -93,8 +101,14 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
     const int k = j2 & 3, tv = j2 >> 2;
     rb_tile(g, q, tv, grp, sb, n0);
     out[q.VB + le] = rb_vc(g, p, sb + 4 * kq + r, k, 16 * mv + rb_pi(c));
+  } else if ((le -= nVB) >= nUA) {      // VXA
+    le -= nUA;
+    int j = le >> 6;
+    const int j2 = j / KSX, s4 = j - j2 * KSX;
+    const int k = j2 & 3, tv = j2 >> 2;
+    rb_tile(g, q, tv, grp, sb, n0);
+    out[q.VXA + le] = rb_vx(g, p, sb + c, k, 4 * s4 + kq);
   } else {                              // UB
-    le -= nVB;
     int j = le >> 6;
     const int r = j & 3;
     j >>= 2;
@@ -198,12 +212,28 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
   q.VA = take(NTV * 4 * KS * 64);
   q.VB = take(NTV * 4 * g.NP * 4 * 64);
   q.UB = take(NTV * q.NMT * 4 * 64);
+  q.VXA = take(NTV * 4 * (g.KX / 4) * 64);
   q.total = o;
   q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * q.NMT * 256 : 0;
   q.flag_words = S > 1 ? (long long)q.nrb * S + 64 : 0;
   if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G, g.bf != 0)) return false;
   *out = q;
   return true;
+}
+
+// VMLMF_RB_XFOLD=1: the clustered forward forms the x-side pre-activations itself (rb_fwd_kernel<..., XF>).  Built for verdict r3
+// item 3, parity-green (tests/test_gpu_rb.py runs both forms), and NOT the default: measured on MI355X it changes nothing - config E
+// layer 0.945 / 0.961 ms with it, 0.937 / 0.938 without; plain rank-32 layer 0.746 / 0.769 vs 0.743 / 0.750; the LM step 4.63 vs
+// 4.69 ms in its best form, 1.42 vs 1.40 ms at 32 rows per GPU.  The 32 extra MFMAs of a wave-step (0.43 us) and the qx / x loads
+// cost the member what the 41 KB of pre-activations did - those were prefetched a step ahead behind the exchange - and the
+// xexp_mfma_kernel launch it removes (38 us per layer) is what the extra 15 us of rb_fwd_kernel plus noise give back.  The step
+// of these kernels is the cluster exchange (5.4 of 7.5 us), not their memory pipe.
+static bool g_rb_xfold = []() { const char* e = getenv("VMLMF_RB_XFOLD"); return e != nullptr && e[0] == '1'; }();
+void rb_set_xfold(int on) { g_rb_xfold = on != 0; }   // vmlmf_tune("rb_xfold", v)
+bool rb_xfold_ok(const VGeo& g, const RbGeo& q) {
+  // (full 16-row tiles only: with 8 or 4 live rows per workgroup - config E's 32 rows per GPU - the x-side MFMAs cost what they cost
+  //  for 16 rows while the pre-activation loads they replace shrink with the rows: measured 1.40 vs 1.42 ms per LM step at B = 32)
+  return g_rb_xfold && g.rb > 1 && q.S > 1 && q.MT == 1 && q.rbl == 16 && !g.bf && g.KX % 4 == 0 && g.KX <= 32 && g.Bp == g.B;
 }
 
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s) {
