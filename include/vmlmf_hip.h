@@ -118,6 +118,8 @@ const char *vmlmf_last_error(void);
  *   "inrow"         the backward that forms the weight gradients inside the rows' workgroups (no dpre tape, no weight-gradient
  *                   launch; layers with the x-fold whose input needs no gradient): -1 (default) automatic - batches beyond the
  *                   riding workers' range -, 0 never, 1 wherever it covers the layer
+ *   "inrow_rows"    batch rows per workgroup of that backward: 1 (default) or 2 (one set of accumulators for two rows; measured
+ *                   slower than two rounds of one-row workgroups)
  *   "rb_xfold"      1: clustered layers form the x side of their pre-activations inside the forward recurrence (from x and
  *                   qx = x U_x) instead of reading the (T, B, 4H) tensor; 0 (default: measured no faster)
  *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)

@@ -214,6 +214,11 @@ int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 6
 // weight-gradient launch): VMLMF_INROW / vmlmf_tune("inrow", v): 0 = never, 1 = wherever it covers the layer, -1 = automatic
 // (batches beyond the riding workers' range)
 int g_inrow = []() { const char* e = getenv("VMLMF_INROW"); return e ? atoi(e) : -1; }();
+// batch rows per workgroup of that kernel: 1 (default), or 2 = two rows' recurrences side by side with ONE set of accumulators (an
+// MFMA then contracts the two rows of a step).  Built for batches beyond the CU count, parity-green, and measured SLOWER than two
+// rounds of one-row workgroups: B = 512 backward 228 vs 175 us, 384: 226 vs 171, 300: 224 vs 170 (tools/sessions/r04h.sh) - three
+// waves per SIMD at 168 registers with spills, twelve waves at every barrier.  VMLMF_INROW_ROWS / vmlmf_tune("inrow_rows", 2) selects it.
+int g_inrow_rows = []() { const char* e = getenv("VMLMF_INROW_ROWS"); return e ? atoi(e) : 1; }();
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -824,6 +829,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   WRide ride;
   memset(&ride, 0, sizeof(ride));
   bool inrow = false;
+  int inrow_rows = 1;
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -879,6 +885,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   // batches beyond the riding workers' range (up to there the idle CUs form the products for free)
   inrow = g_inrow != 0 && dx == nullptr && rec4_bwd_supported(g) && (g_inrow > 0 || g.B > g_wride_maxb);
   if (inrow) {
+    inrow_rows = (g_inrow_rows == 2 && rec4_bwd_rows(g, 0) == 2) ? 2 : 1;
     const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
     ride.a.x = wh.x, ride.a.y = wh.y, ride.a.h0 = wh.h0, ride.a.Qs = wh.Qs, ride.a.P = wh.wpart;
   } else {
@@ -888,7 +895,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   {
     Scope sc(3, s);
     if (inrow) {
-      if ((rc = hip_fail(launch_rec4_bwd(g, a, s), "rec4_bwd")) != 0) return rc;
+      if ((rc = hip_fail(launch_rec4_bwd(g, a, inrow_rows, s), "rec4_bwd")) != 0) return rc;
     } else if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
       if ((rc = hip_fail(launch_rec3_bwd(g, a, s), "rec3_bwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
@@ -901,7 +908,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? g.nwg : 0)) != 0) return rc;
+  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? (g.B + inrow_rows - 1) / inrow_rows : 0)) != 0) return rc;
   return debug_status(s);
 }
 
@@ -1165,6 +1172,7 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "rec3") g_rec3 = value;
   else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
   else if (k == "inrow") g_inrow = value;
+  else if (k == "inrow_rows") g_inrow_rows = value == 2 ? 2 : 1;
   else if (k == "rb_xfold") rb_set_xfold(value);
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;

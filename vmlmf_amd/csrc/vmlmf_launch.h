@@ -140,7 +140,8 @@ int launch_rec3_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 // fourth form of the backward (vmlmf_rec4.inc): rec3_bwd_kernel's layers with the x-fold; the weight gradients are formed inside
 // the rows' workgroups (a.wr.a: operands and the partial blocks, one per workgroup; a.wr.K = 0), no dpre / dQ is written
 bool rec4_bwd_supported(const VGeo& g);
-int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
+int rec4_bwd_rows(const VGeo& g, int cus);   // batch rows per workgroup (1, or 2 with more rows than CUs): ceil(B / rows) workgroups / partial blocks
+int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, int rows, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL

@@ -40,26 +40,26 @@ __global__ __launch_bounds__(256) void adam_gate_kernel(TensorList t, int count,
   if (threadIdx.x == 0) bad_s = 0;
   __syncthreads();
   unsigned bad = 0;
-  // eight tensors at a time, one element of each per pass: the eight loads of a pass are in flight together (tensor by tensor the
+  // sixteen tensors at a time, one element of each per pass: the loads of a pass are in flight together (tensor by tensor the
   // scan of the HAR net's ten small gradients was ten dependent memory round trips, 6 us)
   const long long stride = (long long)gridDim.x * 256, i0 = (long long)blockIdx.x * 256 + threadIdx.x;
-  for (int t0 = 0; t0 < count; t0 += 8) {
+  for (int t0 = 0; t0 < count; t0 += 16) {
     long long nmax = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < 16; ++j) {
       const long long n = t0 + j < count ? t.n[t0 + j] : 0;
       nmax = n > nmax ? n : nmax;
     }
     for (long long i = i0; i < nmax; i += stride) {
-      unsigned v[8];
+      unsigned v[16];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < 16; ++j) {
         const int tj = t0 + j < count ? t0 + j : t0;
         const long long n = t.n[tj];
         v[j] = reinterpret_cast<const unsigned*>(t.g[tj])[i < n ? i : 0];     // clamped: a repeated element changes nothing
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bad |= ((v[j] & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;   // exponent all ones: Inf or NaN
+      for (int j = 0; j < 16; ++j) bad |= ((v[j] & 0x7f800000u) == 0x7f800000u) ? 1u : 0u;   // exponent all ones: Inf or NaN
     }
   }
   if (bad) atomicOr(&bad_s, 1u);
@@ -219,10 +219,10 @@ int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, fl
   if (exp_avg == nullptr || exp_avg_sq == nullptr || steps == nullptr) return VMLMF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   if (guard != nullptr) {
-    long long total = 0;
-    for (int i = 0; i < tensors->count; ++i) total += tensors->numel[i];
-    long long nb = (total + 1023) / 1024;          // four elements per thread and pass (nb < 65536: the arrivals' half of the ticket)
-    nb = nb < 1 ? 1 : (nb > GUARD_FLAGS ? GUARD_FLAGS : nb);
+    // enough workgroups that the largest tensor is one pass (the HAR net: 45 workgroups, ONE round of loads), at most 1024
+    // (the arrivals' half of the ticket word holds 16 bits)
+    long long nb = (maxn + 255) / 256;
+    nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
     hipLaunchKernelGGL(adam_gate_kernel, dim3((unsigned)nb), dim3(256), 0, s, t, tensors->count, steps, (unsigned*)guard);
   } else {
     hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps);
