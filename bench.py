@@ -709,7 +709,9 @@ def main():
         # with rocprofv3 in separate passes on this same command and committed under profiles/
         traffic, traffic_note, util, util_note = None, None, None, None
         # (rocprof reports the kernels by their own names: the backward recurrence of this shape is rec3_bwd_kernel)
-        prof_names = {"rec_bwd_kernel": ("rec3_bwd_kernel", "rec_bwd_kernel"), "rec_fwd_kernel": ("rec_fwd_kernel", "rec3_fwd_kernel")}
+        inrow = kern.get("wgrad_mfma_kernel", 0.0) == 0.0 and rows_gpu > 64     # rec4_bwd_kernel: weight gradients inside the rows' workgroups
+        prof_names = {"rec_bwd_kernel": (("rec4_bwd_kernel",) if inrow else ()) + ("rec3_bwd_kernel", "rec_bwd_kernel"),
+                      "rec_fwd_kernel": ("rec_fwd_kernel", "rec3_fwd_kernel")}
 
         def prof_entry(kernels):
             for nm in prof_names.get(dom, (dom,)):
@@ -717,7 +719,8 @@ def main():
                     return kernels[nm]
             raise KeyError(dom)
 
-        for name in ("r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        b256 = strong and rows_gpu == 256
+        for name in (("r04_pmc_traffic_b256.json",) if b256 else ()) + ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = prof_entry(pmc["kernels"])["hbm_bytes_per_launch"]
@@ -726,7 +729,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
-            util_file = next(f for f in ("r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json")
+            util_file = next(f for f in ((("r04_pmc_util_b256.json",) if b256 else ()) + ("r04_pmc_util.json", "r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json"))
                              if os.path.exists(os.path.join(ROOT, "profiles", f)))
             u = prof_entry(json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"])["derived"]
             util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
@@ -737,7 +740,7 @@ def main():
         rows = rows_gpu * T                              # sample-timesteps one launch processes
         # 10 H ru per sample-step in either recurrent kernel; a backward launch that carries the weight-gradient workers
         # (no wgrad_mfma_kernel launch in the breakdown pass) also does their products: dpre^T x, dpre^T Q, h^T dQ
-        riding = dom == "rec_bwd_kernel" and kern.get("wgrad_mfma_kernel", 0.0) == 0.0
+        riding = dom == "rec_bwd_kernel" and kern.get("wgrad_mfma_kernel", 0.0) == 0.0     # (riding workers, or the in-row form)
         F_WG = 2 * 4 * H * I + 2 * 4 * H * RU + 2 * H * RU
         # a forward launch whose x-projection wave forms the input side itself (no xproj_kernel launch in the breakdown pass) does
         # the forward's whole algorithmic work, section 8d's F = 2 I rw + 8 H rw + 10 H ru per sample-step
@@ -748,10 +751,11 @@ def main():
         # workgroups of the dominant launch, one per CU (the launch asks for more than half a CU's LDS): the rows' (vmlmf_query)
         # and, when the weight gradients ride, the workers' (launch geometry of vmlmf_api.hip: plan_wride; not a counter)
         nwork = 0
-        if riding:
+        cus = torch.cuda.get_device_properties(dev).multi_processor_count
+        if riding and not inrow:
             wpw = (192 + 128) // 64
             ntg = -(-(192 // 8 + (H + 31) // 32) // wpw)
-            nwork = min(32, (256 - 8 - rows_gpu) // ntg) * ntg
+            nwork = min(32, (cus - 8 - rows_gpu) // ntg) * ntg
         launch_wgs = rows_gpu + nwork
         out = {
             "metric": "RNN timesteps/sec (fwd+bwd) at B=64 T=128 hid=180 r=16; 1/2/4/8 GPU",
@@ -799,11 +803,13 @@ def main():
                          "traffic_unit": "bytes per launch", "traffic_source": traffic_note,
                          "launch_us": round(rec[dom], 2), "us_per_timestep": round(rec[dom] / T, 4),
                          # one batch row per CU: rows_gpu of 256 CUs are busy; the same rate against THEIR share of the peak
-                         "launch_workgroups_one_per_cu": min(launch_wgs, 256),
-                         "frac_of_those_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * min(launch_wgs, 256) / 256.0), 5),
+                         "launch_workgroups_one_per_cu": min(launch_wgs, cus),
+                         "frac_of_those_cus": round(achieved / (F32_MATRIX_PEAK_TFLOPS * min(launch_wgs, cus) / float(cus)), 5),
                          "utilisation": util, "utilisation_source": util_note,
                          "flops_per_launch": flops,
-                         "contains": ("recurrence (10 H ru per sample-step) + the weight-gradient products riding on the launch "
+                         "contains": ("recurrence (10 H ru per sample-step) + the weight-gradient products formed inside the rows' workgroups "
+                                      "(rec4_bwd_kernel: 8 H I + 8 H ru + 2 H ru per sample-step on fp32 MFMA, operands from LDS)") if (riding and inrow) else
+                                     ("recurrence (10 H ru per sample-step) + the weight-gradient products riding on the launch "
                                       "(8 H I + 8 H ru + 2 H ru per sample-step, on otherwise idle CUs)") if riding else
                                      ("the forward's algorithmic work of SURVEY section 8d: input side 2 I rw + 8 H rw (formed by the "
                                       "launch's x-projection wave) + recurrence 10 H ru per sample-step") if x_inside else

@@ -118,6 +118,11 @@ const char *vmlmf_last_error(void);
  *   "inrow"         the backward that forms the weight gradients inside the rows' workgroups (no dpre tape, no weight-gradient
  *                   launch; layers with the x-fold whose input needs no gradient): -1 (default) automatic - batches beyond the
  *                   riding workers' range -, 0 never, 1 wherever it covers the layer
+ *   "adam_guard"    how vmlmf_adam_step_guarded finds non-finite gradients: 1 (default) the health word finish_kernel sets,
+ *                   2 a scan launch over the listed gradients, 0 not at all
+ *   "clear_health"  (any value) clear the gradient-health word: it stays set from a backward that wrote non-finite gradients until a
+ *                   guarded optimizer step consumes it - a caller that handled such a step some other way says so here, or the
+ *                   next guarded step is skipped once
  *   "inrow_rows"    batch rows per workgroup of that backward: 1 (default) or 2 (one set of accumulators for two rows; measured
  *                   slower than two rounds of one-row workgroups)
  *   "rb_xfold"      1: clustered layers form the x side of their pre-activations inside the forward recurrence (from x and
@@ -345,10 +350,16 @@ int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_no
  * host learns of it one call later (VMLMF_E_PROTOCOL) - inside a replayed hipGraph not at all - so the decision is taken on
  * the device:
  *   vmlmf_adam_step_guarded  `guard`: VMLMF_GUARD_WORDS zero-initialised uint32 device words the caller keeps between steps
- *                            (NULL = vmlmf_adam_step).  A gate launch scans every listed gradient; if any value is Inf / NaN
- *                            the whole step is skipped: no step counter ticks, parameters and moments keep their values,
- *                            guard[VMLMF_GUARD_SKIPPED] counts it (guard[VMLMF_GUARD_GO] = 0 for that step).  One call =
- *                            one gate: models of more than VMLMF_MAX_TENSORS tensors are gated per call.
+ *                            (NULL = vmlmf_adam_step).  When the gradients of the step are not finite the whole step is skipped:
+ *                            no step counter ticks, parameters and moments keep their values, guard[VMLMF_GUARD_SKIPPED]
+ *                            counts it (guard[VMLMF_GUARD_GO] = 0 for that step).  How "not finite" is found
+ *                            (vmlmf_tune("adam_guard", m)): m = 1 (default) - the launch that writes a layer's parameter
+ *                            gradients (finish_kernel, inside every backward call of this library) sets a per-device health
+ *                            word when one of them is Inf / NaN, and the tick launch of this call reads and clears it: no extra
+ *                            launch, no extra pass - covers gradients that came out of this library's backward calls on this
+ *                            device since the last guarded step; m = 2 - a gate launch scans every listed gradient (any
+ *                            source; one call = one gate: models of more than VMLMF_MAX_TENSORS tensors are gated per call);
+ *                            m = 0 - no guard.
  *   vmlmf_sgd_clip_step      skips the step (parameters and gradients untouched) when the total norm is not finite; `norm`
  *                            carries the non-finite value back to the caller. */
 #define VMLMF_GUARD_WORDS 72

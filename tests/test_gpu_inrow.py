@@ -141,3 +141,26 @@ def test_automatic_choice_and_the_input_gradient_fallback():
     got, counts = _kernel_counts(lambda: run_hip(variant, P, x, h0, c0, dy, dhT, dcT, need_dx=True))
     assert counts["wgrad_mfma_kernel"] == 1 and counts["dqx_dx_kernel"] == 1, counts
     compare_all(got, run_literal(variant, P, x, h0, c0, dy, dhT, dcT), "auto.dx")
+
+
+@pytest.mark.parametrize("rec3", [0, 7])
+@pytest.mark.parametrize("case", [(O.V1, 64, 40, 9, 180, 16, [16]), (O.V1, 37, 9, 5, 70, 6, [12]), (O.V1, 300, 6, 7, 100, 8, [16]),
+                                  (O.V1, 12, 10, 3, 192, 4, [16])], ids=lambda c: "B%d_T%d_H%d" % (c[1], c[2], c[4]))
+def test_both_selections_of_the_third_kernel_form(case, rec3):
+    """vmlmf_tune("rec3", 0) (rec_fwd_kernel / rec_bwd_kernel everywhere) and 7 (rec3_fwd_kernel / rec3_bwd_kernel wherever
+    they cover the layer) were only ever exercised by the default mask 6.  Both on the standard shapes against the oracle; the two
+    forwards sum in slightly different orders: their outputs agree to rounding."""
+    from vmlmf_amd import _lib
+    variant, B, T, I, H, rw, ru = case
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=5 * B + T)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, dcT)
+    _lib.tune("rec3", rec3)
+    try:
+        got = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    finally:
+        _lib.tune("rec3", 6)
+    compare_all(got, ref, f"rec3={rec3}")
+    base = run_hip(variant, P, x, h0, c0, dy, dhT, dcT)
+    compare_all(base, ref, "rec3=6")
+    for k in ("y", "hT", "cT"):
+        assert np.abs(got[k] - base[k]).max() <= 2e-6 * max(np.abs(base[k]).max(), 1.0), k

@@ -22,6 +22,7 @@ def child(idx, seconds):
     # an optimizer step behind every backward, as a training loop has it: lr = 0 leaves finite parameters where they are (so
     # the comparison with the quiet gradients below stays valid) but would turn them into NaN if a failing step's NaN gradients
     # ever reached the update (0 * NaN); the device-side gate of vmlmf_amd.optim.Adam has to skip exactly those steps
+    _lib.tune("clear_health", 0)
     opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.0)
     before = [p.detach().clone() for p in net.parameters()]
 

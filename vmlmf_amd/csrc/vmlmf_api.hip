@@ -75,6 +75,11 @@ constexpr int MAX_DEV = 16;
 std::atomic<unsigned*> g_status[MAX_DEV];
 std::atomic<bool> g_status_failed[MAX_DEV];   // the allocation itself failed (not: was skipped because of a capture)
 std::mutex g_status_mu;
+// beside it, in DEVICE memory: the gradient-health word.  finish_kernel sets it when a parameter gradient it writes is not
+// finite (the NaN partial products of a launch that gave up a wait); the package's Adam reads it in its tick launch and skips
+// that step, then clears it (vmlmf_optim.hip).  Device memory, because the tick launch reads it in every step.
+std::atomic<unsigned*> g_health[MAX_DEV];
+int g_adam_guard = []() { const char* e = getenv("VMLMF_ADAM_GUARD"); return e ? atoi(e) : 1; }();
 
 // `s`: the stream the caller is about to launch on.  The first call on a device allocates the word; that allocation is not
 // capturable, so a first call made while `s` is being captured returns NULL WITHOUT remembering anything (the launch simply
@@ -96,6 +101,12 @@ unsigned* status_word(hipStream_t s) {
   const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
   void* p = nullptr;
   const bool ok = hipHostMalloc(&p, 64, hipHostMallocMapped) == hipSuccess && p != nullptr;
+  void* hw = nullptr;
+  if (ok && hipMalloc(&hw, 256) == hipSuccess && hw != nullptr) {
+    if (hipMemset(hw, 0, 256) == hipSuccess) g_health[dev].store((unsigned*)hw, std::memory_order_release);
+  } else {
+    (void)hipGetLastError();
+  }
   if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
   if (ok) {
     memset(p, 0, 64);
@@ -105,6 +116,12 @@ unsigned* status_word(hipStream_t s) {
   (void)hipGetLastError();
   g_status_failed[dev].store(true, std::memory_order_release);
   return nullptr;
+}
+unsigned* health_word(hipStream_t s) {   // allocated together with the status word
+  (void)status_word(s);
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  return g_health[dev].load(std::memory_order_acquire);
 }
 // the word if it exists already (host-side readers: never allocates)
 unsigned* status_word_if_any() {
@@ -512,12 +529,19 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
   for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   {
     Scope sc(7, s);
-    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s), "finish")) != 0) return rc;
+    if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s, health_word(s)), "finish")) != 0) return rc;
   }
   return 0;
 }
 
 }  // namespace
+
+unsigned* vmlmf_health_word_if_any() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return nullptr;
+  return g_health[dev].load(std::memory_order_acquire);
+}
+int vmlmf_adam_guard_mode() { return g_adam_guard; }
 
 // error text for the other translation units of the C ABI (vmlmf_comm.cpp)
 int vmlmf_set_error(int code, const std::string& msg) { return fail(code, msg); }
@@ -1122,7 +1146,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     }
     {
       Scope sc(7, s);
-      if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb_top, s), "finish")) != 0) return rc;
+      if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb_top, s, health_word(s)), "finish")) != 0) return rc;
     }
     return 0;
   }
@@ -1172,6 +1196,11 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "rec3") g_rec3 = value;
   else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
   else if (k == "inrow") g_inrow = value;
+  else if (k == "adam_guard") g_adam_guard = value;
+  else if (k == "clear_health") {   // forget a non-finite gradient no guarded optimizer step has consumed (synchronises the device)
+    unsigned* hw = vmlmf_health_word_if_any();
+    if (hw != nullptr && hipMemset(hw, 0, sizeof(unsigned)) != hipSuccess) (void)hipGetLastError();
+  }
   else if (k == "inrow_rows") g_inrow_rows = value == 2 ? 2 : 1;
   else if (k == "rb_xfold") rb_set_xfold(value);
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)

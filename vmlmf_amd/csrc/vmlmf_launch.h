@@ -145,7 +145,12 @@ int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, int rows, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL
-int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s);
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s,
+                  unsigned* health = nullptr);   // health: device word set when a gradient written is not finite (or NULL)
+// the library's per-device gradient-health word (vmlmf_api.hip), what the optimizers' step guard reads; NULL before the first
+// training call on the device
+unsigned* vmlmf_health_word_if_any();
+int vmlmf_adam_guard_mode();   // 1: health word (default), 2: a scan launch over the gradients, 0: none
 
 // classifier head (vmlmf_head.hip)
 int head_max_classes();
@@ -232,7 +237,7 @@ int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
 int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
-                        hipStream_t s);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
+                        hipStream_t s, unsigned* health = nullptr);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

@@ -9,8 +9,13 @@
 
 #include "../../include/vmlmf_hip.h"
 
+// the library's per-device gradient-health word and the guard mode (vmlmf_api.hip)
+unsigned* vmlmf_health_word_if_any();
+int vmlmf_adam_guard_mode();
+
 namespace {
 
+constexpr int GUARD_GO_W = 64, GUARD_SKIPPED_W = 66;   // words of the caller's guard block (VMLMF_GUARD_GO / _SKIPPED)
 struct TensorList {
   float* p[VMLMF_MAX_TENSORS];
   const float* g[VMLMF_MAX_TENSORS];
@@ -24,7 +29,24 @@ __global__ void tick_kernel(TensorList t, int count, float* steps) {
   if ((int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
 }
 
-// Guarded form of the tick (ABI 9): a launch that gave up a bounded wait leaves NaN parameter gradients (vmlmf_hip.h:
+// Guarded tick, default form (ABI 9): finish_kernel - the launch that writes every parameter gradient of a layer - sets the
+// library's gradient-health word when one of them is not finite (the NaN partial products of a launch that gave up a bounded
+// wait, VMLMF_E_PROTOCOL).  The tick reads the word: set -> nothing ticks, guard[GO] = 0 (adam_kernel returns at once), the step
+// is counted as skipped and the word is cleared; clear -> the ordinary tick.  One extra load in a launch that exists anyway.
+__global__ void tick_health_kernel(TensorList t, int count, float* steps, unsigned* guard, unsigned* health) {
+  const unsigned h = health != nullptr ? *health : 0u;
+  const bool go = h == 0u;
+  if (go && (int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
+  if (threadIdx.x == 0) {
+    guard[GUARD_GO_W] = go ? 1u : 0u;
+    if (!go) {
+      guard[GUARD_SKIPPED_W] += 1u;
+      *health = 0u;
+    }
+  }
+}
+
+// Guarded form of the tick, scanning form (vmlmf_tune("adam_guard", 2): gradients that did not come out of this library): a launch that gave up a bounded wait leaves NaN parameter gradients (vmlmf_hip.h:
 // VMLMF_E_PROTOCOL), and the host only learns of it at its next call - inside a replayed hipGraph never.  An optimizer
 // step over such gradients would poison the model for good, so the update is gated ON THE DEVICE: every workgroup scans a
 // slice of every gradient for non-finite values and leaves a flag; the last one to arrive (ticket) decides - all clear: the
@@ -218,7 +240,10 @@ int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, fl
   if (rc != 0) return rc;
   if (exp_avg == nullptr || exp_avg_sq == nullptr || steps == nullptr) return VMLMF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
-  if (guard != nullptr) {
+  const int mode = guard != nullptr ? vmlmf_adam_guard_mode() : 0;
+  if (mode == 1) {
+    hipLaunchKernelGGL(tick_health_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps, (unsigned*)guard, vmlmf_health_word_if_any());
+  } else if (mode == 2) {
     // enough workgroups that the largest tensor is one pass (the HAR net: 45 workgroups, ONE round of loads), at most 1024
     // (the arrivals' half of the ticket word holds 16 bits)
     long long nb = (maxn + 255) / 256;
@@ -228,7 +253,7 @@ int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, fl
     hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps);
   }
   hipLaunchKernelGGL(adam_kernel, dim3(blocks_for(maxn), tensors->count), dim3(256), 0, s, t, exp_avg, exp_avg_sq,
-                     steps, lr, beta1, beta2, eps, weight_decay, (const unsigned*)guard);
+                     steps, lr, beta1, beta2, eps, weight_decay, mode != 0 ? (const unsigned*)guard : nullptr);
   return (int)hipGetLastError();
 }
 

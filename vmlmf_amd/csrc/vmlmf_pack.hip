@@ -645,9 +645,18 @@ __device__ __forceinline__ float* vx_dest(const VGeo& g, const RefG& o, long lon
   return o.v_x + e;
 }
 
+// `health` (device word, or NULL): set when a gradient written here is not finite - a launch that gave up a bounded wait leaves NaN
+// partial products (VMLMF_E_PROTOCOL), and this kernel is where every parameter gradient of a layer is written.  The package's
+// Adam reads the word in its tick launch and skips the step (vmlmf_optim.hip); the compare is free, the atomic never happens in a
+// healthy step.
+__device__ __forceinline__ void finish_put(float* dst, float v, unsigned* health) {
+  dst[0] = v;
+  if (!(fabsf(v) <= 3.4028234e38f) && health != nullptr) atomicOr(health, 1u);
+}
 __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const float* __restrict__ cg, const RefG& o, const HeadBwd& hd,
-                                            const long long nbody) {
+                                            const long long nbody, unsigned* health) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
+  auto put = [&](float* dst, float v) { finish_put(dst, v, health); };
   {
     // classifier gradients (HeadBwd) ride at the end of the grid: dW[c][n] = sum_b dlogits[b][c] hT[b][n], db[c] = sum_b
     // dlogits[b][c], each a fixed-order sum over the batch (four independent chains)
@@ -684,9 +693,9 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       v = add_ror16<1>(v);
       if (live && j16 == 0) {
         if (isb) {
-          if (hd.db != nullptr) hd.db[c] = v;
+          if (hd.db != nullptr) put(&hd.db[c], v);
         } else if (hd.dW != nullptr) {
-          hd.dW[(size_t)c * H + n] = v;
+          put(&hd.dW[(size_t)c * H + n], v);
         }
       }
       return;
@@ -711,7 +720,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       if (lane == 0) {
         if (!g.novm)
           for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
-        o.u_x[eo] = v;
+        put(&o.u_x[eo], v);
       }
       return;
     }
@@ -722,7 +731,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       float v = 0.f;
       for (int m = 0; m < I; ++m) v = fmaf(CG(va_vx(g, k, m), n), ref_ux(g, p, m, r), v);
       if (n < I && !g.novm) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
-      *dst = v;
+      put(dst, v);
       return;
     }
     e += n_ux;   // fall through to the branches below with the offsets they expect
@@ -733,7 +742,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
     float v = I > H ? cg[(size_t)g.NA * NT + (size_t)m * g.KX + r] : CG(va_ux(g, r), m);   // (I > H: reduce_cg_kernel's own block)
     if (!g.novm)
       for (int k = 0; k < 4; ++k) v -= CG(va_ex(g, k), m) * ref_vx(g, p, m, k, r);
-    o.u_x[e] = v;
+    put(&o.u_x[e], v);
     return;
   }
   e -= n_ux;
@@ -743,21 +752,21 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
     float* dst = vx_dest(g, o, e, k, n, r);
     float v = CG(va_vx(g, k, r), n);
     if (n < I && !g.novm) v -= CG(va_ex(g, k), n) * ref_ux(g, p, n, r);
-    *dst = v;
+    put(dst, v);
     return;
   }
   e -= n_vx;
   if (e < n_dx) {
     if (g.novm) return;
     const int m = (int)e;
-    o.dia_x[m] = (CG(va_ex(g, 0), m) + CG(va_ex(g, 1), m)) + (CG(va_ex(g, 2), m) + CG(va_ex(g, 3), m));
+    put(&o.dia_x[m], (CG(va_ex(g, 0), m) + CG(va_ex(g, 1), m)) + (CG(va_ex(g, 2), m) + CG(va_ex(g, 3), m)));
     return;
   }
   e -= n_dx;
   if (e < n_dh) {
     if (g.novm) return;
     const int n = (int)e;
-    o.dia_h[n] = (CG(va_eh(g, 0), n) + CG(va_eh(g, 1), n)) + (CG(va_eh(g, 2), n) + CG(va_eh(g, 3), n));
+    put(&o.dia_h[n], (CG(va_eh(g, 0), n) + CG(va_eh(g, 1), n)) + (CG(va_eh(g, 2), n) + CG(va_eh(g, 3), n)));
     return;
   }
   e -= n_dh;
@@ -765,10 +774,10 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
     const int k = (int)(e / H), n = (int)(e % H);
     const float v = CG(va_b(g, k), n);
     if (g.pergate) {
-      vg_gate(o.bg, k)[n] = v;
+      put(&vg_gate(o.bg, k)[n], v);
     } else {
-      o.b_x[vg_xchunk(g, k) * H + n] = v;
-      o.b_h[vg_hchunk(g, k) * H + n] = v;
+      put(&o.b_x[vg_xchunk(g, k) * H + n], v);
+      put(&o.b_h[vg_hchunk(g, k) * H + n], v);
     }
     return;
   }
@@ -793,7 +802,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       float v = CG(va_uc(g, base + r), n);
       if (s == 0 && !g.novm)
         for (int k = 0; k < 4; ++k) v -= CG(va_eh(g, k), n) * ref_vc(g, p, n, k, r);
-      ou[e] = v;
+      put(&ou[e], v);
       return;
     }
     e -= n_u;
@@ -828,7 +837,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       }
       float v = CG(va_vc(g, k, base + r), n);
       if (s == 0 && !g.novm) v -= CG(va_eh(g, k), n) * ref_uc(g, p, n, r);
-      *dst = v;
+      put(dst, v);
       return;
     }
     e -= n_v;
@@ -836,8 +845,8 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
 }
 
 __global__ void __launch_bounds__(256) finish_kernel(VGeo g, RefP p, const float* __restrict__ cg, RefG o, HeadBwd hd,
-                                                     long long nbody) {
-  finish_body(g, p, cg, o, hd, nbody);
+                                                     long long nbody, unsigned* health) {
+  finish_body(g, p, cg, o, hd, nbody, health);
 }
 struct FinishLayer {
   VGeo g;
@@ -849,11 +858,12 @@ struct FinishLayer {
 };
 struct FinishStack {
   FinishLayer l[WF_MAXL];
+  unsigned* health;
 };
 __global__ void __launch_bounds__(256) finish_stack_kernel(FinishStack S) {   // grid.y = layer (wavefront path; no classifier)
   const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
   if ((long long)blockIdx.x * 256 >= f.nbody && f.hd.C <= 0) return;
-  finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody);
+  finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody, vg_karg_ref<unsigned*>(offsetof(FinishStack, health)));
 }
 
 static long long finish_elements(const VGeo& g) {
@@ -864,10 +874,11 @@ static long long finish_elements(const VGeo& g) {
 }
 
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
-                        hipStream_t s) {
+                        hipStream_t s, unsigned* health) {
   static_assert(sizeof(FinishStack) <= 4096, "kernel-argument segment");
   FinishStack S;
   memset(&S, 0, sizeof(S));
+  S.health = health;
   long long nmax = 0;
   for (int l = 0; l < L; ++l) {
     S.l[l].g = g[l], S.l[l].p = p[l], S.l[l].o = out[l], S.l[l].cg = cgrad[l], S.l[l].nbody = finish_elements(g[l]);
@@ -882,9 +893,9 @@ int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const*
   return (int)hipGetLastError();
 }
 
-int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s) {
+int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s, unsigned* health) {
   const long long nbody = finish_elements(g);
   const long long nhead = hd.C > 0 ? 16 * ((long long)hd.C * g.H + hd.C) : 0;   // sixteen lanes per classifier output
-  hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((nbody + nhead + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out, hd, nbody);
+  hipLaunchKernelGGL(finish_kernel, dim3((unsigned)((nbody + nhead + 255) / 256)), dim3(256), 0, s, g, p, cgrad, out, hd, nbody, health);
   return (int)hipGetLastError();
 }

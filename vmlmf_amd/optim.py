@@ -43,9 +43,11 @@ class Adam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (betas, eps, L2 weight_decay; no amsgrad / maximize), one launch per step and
     parameter group.  state[p] holds 'step', 'exp_avg', 'exp_avg_sq' like the stock optimizer (the moments are
     views of two flat buffers per group).
-    Non-finite gradients never reach the parameters: a gate launch in front of the update scans them on the device and
-    skips the whole step of the group when any is Inf / NaN (a launch that gave up a bounded wait, VMLMF_E_PROTOCOL, leaves NaN
-    gradients, and a replayed hipGraph cannot ask the host); skipped_steps() counts.  guard=False: the unguarded launch."""
+    Non-finite gradients of the VMLMF layers never reach the parameters: the library's backward marks a per-device health word
+    when it writes an Inf / NaN parameter gradient (a launch that gave up a bounded wait, VMLMF_E_PROTOCOL, leaves NaN gradients, and
+    a replayed hipGraph cannot ask the host), this optimizer's tick launch reads it and skips the whole step; skipped_steps()
+    counts.  vmlmf_amd._lib.tune("adam_guard", 2) scans every gradient instead (any source, one more launch); guard=False: the
+    unguarded launch."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, guard=True):
         if lr < 0 or eps < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1 or weight_decay < 0:
