@@ -125,6 +125,9 @@ const char *vmlmf_last_error(void);
  *                   next guarded step is skipped once
  *   "inrow_rows"    batch rows per workgroup of that backward: 1 (default) or 2 (one set of accumulators for two rows; measured
  *                   slower than two rounds of one-row workgroups)
+ *   "rb_wgrad"      1: the clustered backward of one-group layers with padded rank <= 32 forms the weight-gradient products itself,
+ *                   between publishing its partials and waiting for the cluster's; 0 (default: measured no faster): it writes dpre
+ *                   only and the batched weight-gradient kernel forms them
  *   "rb_xfold"      1: clustered layers form the x side of their pre-activations inside the forward recurrence (from x and
  *                   qx = x U_x) instead of reading the (T, B, 4H) tensor; 0 (default: measured no faster)
  *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)

@@ -278,3 +278,34 @@ def test_x_side_formed_inside_the_clustered_forward(case):
     finally:
         _lib.tune("rb_xfold", 0)
         _lib.tune("rb_rows", 0)
+
+
+@pytest.mark.parametrize("case", [(O.V3, 24, 5, 650, 650, 32, [32]), (O.V1, 18, 3, 20, 600, 8, [8]), (O.V3, 16, 4, 400, 400, 12, [20]),
+                                  (O.V1, 33, 2, 300, 520, 16, [24])],
+                         ids=lambda c: "v%d_B%d_T%d_I%d_H%d_r%d" % c[:6])
+def test_weight_gradients_formed_inside_the_clustered_backward(case):
+    """vmlmf_tune("rb_wgrad", 1): rb_bwd_kernel<..., WG> forms dpre^T [qx | Q], h^T dQ and the element sums itself (between a member's
+    publication and its wait for the cluster), only x^T dqx keeps the batched kernel.  Not the default (measured no faster,
+    vmlmf_rb.hip), kept parity-green: every gradient against the fp64 oracle, with 16 and with fewer live rows per workgroup,
+    ragged last tiles, a rank that is not a multiple of 16, zero and given initial states."""
+    variant, B, T, I, H, rw, ru = case
+    tm = variant in (O.V3, O.V4)
+    rng = np.random.Generator(np.random.PCG64(19 * B + H))
+    P = O.make_params(variant, I, H, rw, ru[0], seed=H + B, scale=0.05 if tm else 0.1)
+    shp = (T, B, I) if tm else (B, T, I)
+    x = (0.5 * rng.standard_normal(shp)).astype(np.float32)
+    h0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if B % 2 == 0 else None
+    c0 = (0.3 * rng.standard_normal((B, H))).astype(np.float32) if B % 2 == 0 else None
+    dy = rng.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dhT = rng.standard_normal((B, H)).astype(np.float32)
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
+    _lib.tune("rb_cluster", 16)
+    try:
+        for rows in (16, 0):
+            _lib.tune("rb_rows", rows)
+            _lib.tune("rb_wgrad", 1)
+            got = run_hip(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
+            compare_all(got, ref, f"rb.wgrad.rows{rows}")
+    finally:
+        _lib.tune("rb_wgrad", 0)
+        _lib.tune("rb_rows", 0)

@@ -405,7 +405,12 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   L.b_dQs = o, o += align64(TB * g.G * g.KH);
   L.b_dqx = o, o += align64(TB * g.KX);
   // (one partial block per chunk of rows, or - backward with the weight gradients formed in the rows' workgroups - per workgroup)
-  L.b_wpart = o, o += align64((long long)((!g.generic && !g.rb && rec4_bwd_supported(g) && g.nwg > g.nchunk) ? g.nwg : g.nchunk) * g.PCH);
+  {
+    long long blocks = g.nchunk;
+    if (!g.generic && !g.rb && rec4_bwd_supported(g) && g.nwg > blocks) blocks = g.nwg;
+    if (g.rb > 1 && q.nrb > blocks) blocks = q.nrb;   // rb_bwd_kernel's own partial blocks, one per row block
+    L.b_wpart = o, o += align64(blocks * g.PCH);
+  }
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT + (g.I > g.H ? (long long)g.I * g.KX : 0));   // + dU_x by input when I > H
   L.b_trash = o, o += 64;
   {
@@ -508,19 +513,26 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
 
 static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
                          const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s, const WRide* ride = nullptr,
-                         const int inrow_blocks = 0) {
+                         const int inrow_blocks = 0, const int rbwg_blocks = 0) {
   int rc;
-  const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
+  WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
   const bool rode = ride != nullptr && ride->K > 0;
+  VGeo gw = g;
+  if (rbwg_blocks > 0) {   // only x^T dqx is left to this launch; its chunks are the row blocks' partial blocks
+    wh.only3 = 1;
+    gw.nchunk = rbwg_blocks;
+    gw.RC2 = (int)(((long long)g.T * g.B + rbwg_blocks - 1) / rbwg_blocks);
+  }
   if (!rode && inrow_blocks == 0) {
     Scope sc(5, s);
-    if ((rc = hip_fail(launch_wgrad_h(g, wh, s), "wgrad")) != 0) return rc;
+    if ((rc = hip_fail(launch_wgrad_h(gw, wh, s), "wgrad")) != 0) return rc;
   }
   {
     Scope sc(6, s);
     VGeo gr_ = g;
     if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
     if (inrow_blocks > 0) gr_.nchunk = inrow_blocks;   // one partial block per workgroup of rec4_bwd_kernel
+    if (rbwg_blocks > 0) gr_.nchunk = rbwg_blocks;     // one per row block of rb_bwd_kernel
     if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s), "reduce")) != 0) return rc;
   }
   RefG og;
@@ -854,6 +866,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   memset(&ride, 0, sizeof(ride));
   bool inrow = false;
   int inrow_rows = 1;
+  int rbwg_blocks = 0;   // > 0: rb_bwd_kernel formed the weight gradients itself, one partial block per row block
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -866,6 +879,10 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
     io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
     io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word(s);
+    if (rb_wgrad_ok(g, q)) {   // the weight-gradient products inside the launch, in the shadow of the cluster exchange
+      io.wgrad = 1, rbwg_blocks = q.nrb;
+      io.x = x, io.qx = rs + L.r_qx, io.wy = y, io.wh0 = h0, io.wQs = rs + L.r_Qs, io.wP = ws + L.b_wpart;
+    }
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
@@ -932,7 +949,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? (g.B + inrow_rows - 1) / inrow_rows : 0)) != 0) return rc;
+  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? (g.B + inrow_rows - 1) / inrow_rows : 0, rbwg_blocks)) != 0) return rc;
   return debug_status(s);
 }
 
@@ -1203,6 +1220,7 @@ int vmlmf_tune(const char* key, int value) {
   }
   else if (k == "inrow_rows") g_inrow_rows = value == 2 ? 2 : 1;
   else if (k == "rb_xfold") rb_set_xfold(value);
+  else if (k == "rb_wgrad") rb_set_wgrad(value);
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

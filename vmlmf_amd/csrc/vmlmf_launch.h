@@ -45,6 +45,7 @@ struct XwArgs {
 struct AtbArgs {
   const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
   float* P;
+  int only3, pad;   // only3: the launch carries the x^T dqx tasks alone (the other products were formed inside rb_bwd_kernel)
 };
 // weight-gradient workers riding on rec_bwd_kernel's launch (vmlmf_atb.inc): K workers per task, chunks of S rows (t,b),
 // ntg workgroups per worker index; prog = one progress word per batch row (zero between launches)
@@ -80,6 +81,7 @@ struct WgxArgs {
 struct WghArgs {
   const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
   float* wpart;
+  int only3 = 0;
 };
 
 // buffers of the step-wise path (vmlmf_generic.hip)
@@ -113,7 +115,15 @@ struct RbIo {
   // x-fold (rb_xfold_ok): the forward forms the x-side pre-activations itself from x, qx = x U_x and the V_x image; gx is not read
   const float *x, *qx, *EXT, *BBT;
   int xfold;
+  // weight gradients inside the clustered backward (rb_wgrad_ok): operands of the products and the partial blocks (one per row block)
+  const float *wy, *wh0, *wQs;
+  float* wP;
+  int wgrad;
 };
+// the clustered backward can form dpre^T [qx | Q], h^T dQ and the element sums itself, in the shadow of its cluster exchange
+// (accumulator waves beside the compute waves): one tile per wave, fp32
+bool rb_wgrad_ok(const VGeo& g, const RbGeo& q);
+void rb_set_wgrad(int on);
 // the clustered forward can form the x side of its pre-activations in-kernel (a third MFMA product, K = the padded x rank) instead
 // of reading the (T, B, 4H) tensor xexp_mfma_kernel would write: one tile per wave, fp32
 bool rb_xfold_ok(const VGeo& g, const RbGeo& q);

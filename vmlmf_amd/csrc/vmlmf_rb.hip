@@ -236,6 +236,23 @@ bool rb_xfold_ok(const VGeo& g, const RbGeo& q) {
   return g_rb_xfold && g.rb > 1 && q.S > 1 && q.MT == 1 && q.rbl == 16 && !g.bf && g.KX % 4 == 0 && g.KX <= 32 && g.Bp == g.B;
 }
 
+// VMLMF_RB_WGRAD=1 / vmlmf_tune("rb_wgrad", 1): the clustered backward forms the weight-gradient products itself, between a member's
+// publication of its partials and its wait for the others' (rb_bwd_kernel<..., WG>).  Built on the estimate that this time is idle
+// (5.4 of 7.6 us per step are the exchange), parity-green (tests/test_gpu_rb.py), and NOT the default - measured (tools/sessions/r04j.sh,
+// plain rank-32 PTB layer, same box, interleaved): layer forward + backward 0.717 / 0.721 ms with it against 0.735 / 0.746 (the
+// 120 us wgrad_mfma_kernel launch leaves, the backward launch grows by ~100 us), the LM step 4.66 / 4.69 vs 4.66 / 4.69 ms (nothing),
+// and at 32 rows per GPU 1.55 vs 1.43 ms (the products cost what they cost for 16 rows).  The wait is not idle for the wave that has
+// to issue the 64 MFMAs (0.85 us) and 26 more loads per step through the same memory pipe the gather needs.
+static bool g_rb_wgrad = []() { const char* e = getenv("VMLMF_RB_WGRAD"); return e != nullptr && e[0] == '1'; }();
+void rb_set_wgrad(int on) { g_rb_wgrad = on != 0; }
+// One-group layers with a padded rank of at most 32 (the plain PTB layer): 472 registers of the 512 a wave alone on its SIMD has.
+// The two-group flat layer of configs[4] (64 + 64 ranks: 160 accumulator registers beside 312 of recurrence state) does not fit -
+// the compiler spills 164 registers per lane into scratch, i.e. into the one memory pipe the exchange is waiting on - so it keeps
+// the batched weight-gradient kernel.
+bool rb_wgrad_ok(const VGeo& g, const RbGeo& q) {
+  return g_rb_wgrad && g.rb > 1 && q.S > 1 && q.MT == 1 && !g.bf && g.G == 1 && g.KH <= 32 && g.KX <= 32 && g.Bp == g.B;
+}
+
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s) {
   if (q.total >= (1LL << 30)) return -3;
   const long long blocks = (q.total + 255) / 256;
