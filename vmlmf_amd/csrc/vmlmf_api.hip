@@ -235,6 +235,9 @@ int g_inrow = []() { const char* e = getenv("VMLMF_INROW"); return e ? atoi(e) :
 // MFMA then contracts the two rows of a step).  Built for batches beyond the CU count, parity-green, and measured SLOWER than two
 // rounds of one-row workgroups: B = 512 backward 228 vs 175 us, 384: 226 vs 171, 300: 224 vs 170 (tools/sessions/r04h.sh) - three
 // waves per SIMD at 168 registers with spills, twelve waves at every barrier.  VMLMF_INROW_ROWS / vmlmf_tune("inrow_rows", 2) selects it.
+// wgrad_ring_kernel for the weight gradients of large layers: -1 automatic (the step-wise / clustered layers), 0 never, 1 wherever
+// it applies (VMLMF_WRING / vmlmf_tune("wring", v))
+int g_wring = []() { const char* e = getenv("VMLMF_WRING"); return e ? atoi(e) : -1; }();
 int g_inrow_rows = []() { const char* e = getenv("VMLMF_INROW_ROWS"); return e ? atoi(e) : 1; }();
 
 // ---- geometry ----
@@ -523,13 +526,19 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
     gw.nchunk = rbwg_blocks;
     gw.RC2 = (int)(((long long)g.T * g.B + rbwg_blocks - 1) / rbwg_blocks);
   }
+  int ring_nc[3] = {0, 0, 0};
   if (!rode && inrow_blocks == 0) {
     Scope sc(5, s);
-    if ((rc = hip_fail(launch_wgrad_h(gw, wh, s), "wgrad")) != 0) return rc;
+    // large layers: operands through an LDS ring, long chunks (vmlmf_wgrad_ring.hip); -1: where it was measured faster
+    const bool ring = rbwg_blocks == 0 && g_wring != 0 && wgrad_ring_ok(g) && (g_wring > 0 || (g.generic && (long long)g.T * g.B >= 2048));
+    if (ring) {
+      if ((rc = hip_fail(launch_wgrad_ring(gw, wh, device_cus(), ring_nc, s), "wgrad (ring)")) != 0) return rc;
+    } else if ((rc = hip_fail(launch_wgrad_h(gw, wh, s), "wgrad")) != 0) return rc;
   }
   {
     Scope sc(6, s);
     VGeo gr_ = g;
+    if (ring_nc[0] > 0) gr_.wc[0] = ring_nc[0], gr_.wc[1] = ring_nc[1], gr_.wc[2] = ring_nc[2];
     if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
     if (inrow_blocks > 0) gr_.nchunk = inrow_blocks;   // one partial block per workgroup of rec4_bwd_kernel
     if (rbwg_blocks > 0) gr_.nchunk = rbwg_blocks;     // one per row block of rb_bwd_kernel
@@ -1221,6 +1230,7 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "inrow_rows") g_inrow_rows = value == 2 ? 2 : 1;
   else if (k == "rb_xfold") rb_set_xfold(value);
   else if (k == "rb_wgrad") rb_set_wgrad(value);
+  else if (k == "wring") g_wring = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

@@ -154,6 +154,8 @@ int rec4_bwd_rows(const VGeo& g, int cus);   // batch rows per workgroup (1, or 
 int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, int rows, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
+bool wgrad_ring_ok(const VGeo& g);   // vmlmf_wgrad_ring.hip: the same products for large layers, operands through an LDS ring
+int launch_wgrad_ring(const VGeo& g, const WghArgs& a, int cus, int nc_out[3], hipStream_t s);
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s,
                   unsigned* health = nullptr);   // health: device word set when a gradient written is not finite (or NULL)

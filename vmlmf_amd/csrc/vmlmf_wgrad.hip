@@ -175,10 +175,19 @@ __device__ __forceinline__ float reduce_cg_sum(const float* __restrict__ Pall, c
 
 __device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long e, const float total, float* __restrict__ cgrad);
 
+// blocks that hold element e: all of them, or (wgrad_ring_kernel: each product has its own chunking) the count of e's region
+__device__ __forceinline__ int reduce_cg_count(const VGeo& g, const long long e) {
+  if (g.wc[0] == 0) return g.nchunk;
+  const int GK = g.G * g.KH, MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
+  const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (g.KX + 31) / 32 * 32;
+  const long long o2 = (long long)g.NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p, oe = o3 + (long long)MT3 * 32 * NB3p;
+  return e < o2 ? g.wc[0] : (e < o3 ? g.wc[1] : (e < oe ? g.wc[2] : g.wc[0]));
+}
+
 __device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= g.PCH) return;
-  reduce_cg_scatter(g, e, reduce_cg_sum(Pall, g.PCH, e, 0, g.nchunk), cgrad);
+  reduce_cg_scatter(g, e, reduce_cg_sum(Pall, g.PCH, e, 0, reduce_cg_count(g, e)), cgrad);
 }
 
 // The same sum when there are many blocks (one per workgroup of rec4_bwd_kernel: up to the batch size): as one thread per
