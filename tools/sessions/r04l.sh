@@ -2,7 +2,8 @@
 # r04l: wgrad_ring_kernel, second form (compile-time LDS strides, mask-free main loop): parity, kernel time, layer times
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r04l; mkdir -p $O
-timeout 900 python -m pytest tests/test_gpu_wring.py -x -q -m gpu > $O/tests_wring.txt 2>&1; echo "wring tests rc=$?"; grep -E "passed|failed" $O/tests_wring.txt | tail -2; grep -E "^(FAILED|ERROR)|^E  " $O/tests_wring.txt | head -30
+timeout 240 python -m pytest tests/test_gpu_wring.py -x -q -m gpu > $O/tests_wring.txt 2>&1; rc=$?; echo "wring tests rc=$rc"; grep -E "passed|failed" $O/tests_wring.txt | tail -2; grep -E "^(FAILED|ERROR)|^E  " $O/tests_wring.txt | head -30
+[ $rc = 0 ] || exit 1
 kstats() { python3 - "$1" <<'EOF'
 import sqlite3, glob, sys
 db = glob.glob(sys.argv[1] + '/*.db')[0]
