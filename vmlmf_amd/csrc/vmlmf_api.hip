@@ -381,11 +381,12 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   const long long TS = (long long)g.T * g.Bp * g.NT;   // (t, padded row, thread slot)
   long long o = 0;
   L.r_pack = o, o += align64(P.total);
-  // (16 spare rows behind qx, Q, dQ, dqx: wgrad_ring_kernel's last stage fetches whole 16-row pieces)
-  L.r_qx = o, o += align64((TB + 16) * g.KX);
+  // (16 spare rows behind qx, Q, dQ, dqx of the layers wgrad_ring_kernel may take: its last stage fetches whole 16-row pieces)
+  const long long TBp = TB + (g.NT >= 256 ? 16 : 0);
+  L.r_qx = o, o += align64(TBp * g.KX);
   L.r_gates = o, o += align64(TS * 4);
   L.r_cs = o, o += align64(TS + (long long)g.Bp * g.NT);   // slice 0 = c0, slice t+1 = c_t
-  L.r_Qs = o, o += align64((TB + 16) * g.G * g.KH);
+  L.r_Qs = o, o += align64(TBp * g.G * g.KH);
   L.r_prog = o, o += align64((long long)g.B * WR_PROG_STRIDE);   // progress words of the backward rows (zero between launches: cleared by the forward kernel)
   L.r_total = o;
   o = 0;
@@ -406,8 +407,8 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   L.f_total = o;
   o = 0;
   L.b_dpre = o, o += align64(TS * 4);
-  L.b_dQs = o, o += align64((TB + 16) * g.G * g.KH);
-  L.b_dqx = o, o += align64((TB + 16) * g.KX);
+  L.b_dQs = o, o += align64(TBp * g.G * g.KH);
+  L.b_dqx = o, o += align64(TBp * g.KX);
   // (one partial block per chunk of rows, or - backward with the weight gradients formed in the rows' workgroups - per workgroup)
   {
     long long blocks = g.nchunk;
