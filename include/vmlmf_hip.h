@@ -132,7 +132,7 @@ const char *vmlmf_last_error(void);
  *                   qx = x U_x) instead of reading the (T, B, 4H) tensor; 0 (default: measured no faster)
  *   "wring"         the batched weight-gradient products of large layers (thread slots >= 256, fp32 tapes, time-major contiguous x / y)
  *                   with their operands streamed through an LDS ring (wgrad_ring_kernel): -1 (default) for the layers of the
- *                   step-wise / clustered recurrences with >= 2048 rows, 0 never, 1 wherever the kernel takes the layer
+ *                   step-wise / clustered recurrences with >= 1024 rows, 0 never, 1 wherever the kernel takes the layer
  *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)
  */
 int vmlmf_tune(const char *key, int value);

@@ -14,7 +14,7 @@ import torch
 from vmlmf_amd import Model, MyVMLSTMGroup, nll_loss, optim
 
 DEV = "cuda"
-B = int(sys.argv[1]) if len(sys.argv) > 1 and __name__ == "__main__" else 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() and __name__ == "__main__" else 256
 T, H, V = 35, 650, 10000
 RW, RU = 32, [32, 32]
 # algorithmic flops per sample-timestep and layer, forward: 2 I rw + 8 H rw + 10 H sum(ru); fwd + bwd = 3 F
@@ -201,6 +201,8 @@ def run(tag, group, fused, head=False):
 
 if __name__ == "__main__":
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, True, head=True)
+    if "--only-head" in sys.argv:   # (for a profile of the shipped step alone)
+        sys.exit(0)
     run("E-model: Embed + 2 x MyVMLSTMGroup + Linear + nll", True, True, head=True)
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, True)
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, False)

@@ -8,6 +8,8 @@ import torch
 from vmlmf_amd import MyVMLSTM, MyVMLSTMGroup
 torch.manual_seed(0)
 H, B, T = 650, 256, 35
+if "--batch" in sys.argv:
+    B = int(sys.argv[sys.argv.index("--batch") + 1])
 if "--v3" in sys.argv:
     l = MyVMLSTM(H, H, w_rank=32, u_ranks=32).cuda()
 else:

@@ -532,7 +532,7 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
   if (!rode && inrow_blocks == 0) {
     Scope sc(5, s);
     // large layers: operands through an LDS ring, long chunks (vmlmf_wgrad_ring.hip); -1: where it was measured faster
-    const bool ring = rbwg_blocks == 0 && g_wring != 0 && wgrad_ring_ok(g) && (g_wring > 0 || (g.generic && (long long)g.T * g.B >= 2048));
+    const bool ring = rbwg_blocks == 0 && g_wring != 0 && wgrad_ring_ok(g) && (g_wring > 0 || (g.generic && (long long)g.T * g.B >= 1024));
     if (ring) {
       if ((rc = hip_fail(launch_wgrad_ring(gw, wh, device_cus(), ring_nc, s), "wgrad (ring)")) != 0) return rc;
     } else if ((rc = hip_fail(launch_wgrad_h(gw, wh, s), "wgrad")) != 0) return rc;
@@ -540,11 +540,11 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
   {
     Scope sc(6, s);
     VGeo gr_ = g;
-    if (ring_nc[0] > 0) gr_.wc[0] = ring_nc[0], gr_.wc[1] = ring_nc[1], gr_.wc[2] = ring_nc[2];
     if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
     if (inrow_blocks > 0) gr_.nchunk = inrow_blocks;   // one partial block per workgroup of rec4_bwd_kernel
     if (rbwg_blocks > 0) gr_.nchunk = rbwg_blocks;     // one per row block of rb_bwd_kernel
-    if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s), "reduce")) != 0) return rc;
+    if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s,
+                                     ReduceCounts{{ring_nc[0], ring_nc[1], ring_nc[2]}}), "reduce")) != 0) return rc;
   }
   RefG og;
   og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;

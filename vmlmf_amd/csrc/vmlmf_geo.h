@@ -28,7 +28,6 @@ struct VGeo {
   int RC2;    // (t,b) rows per wgrad chunk
   int nchunk; // wgrad chunks (grid.y)
   long long PCH;  // floats of partial products per chunk (wgrad_mfma_kernel)
-  int wc[3];      // wgrad_ring_kernel: partial blocks that hold the C1 (+ E) / C2 / C3 region (0: nchunk blocks hold every region)
   int NA;     // accumulators per thread in wgrad = 5 KX + 5 KH + 12
   long long sxT, sxB, syT, syB;  // element strides of x/dx and y/dy
   int time_major, training;

@@ -156,7 +156,13 @@ int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 bool wgrad_ring_ok(const VGeo& g);   // vmlmf_wgrad_ring.hip: the same products for large layers, operands through an LDS ring
 int launch_wgrad_ring(const VGeo& g, const WghArgs& a, int cus, int nc_out[3], hipStream_t s);
-int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s);   // prog: words to clear, or NULL
+// partial blocks that hold the C1 (+ E) / C2 / C3 region of the chunk layout (wgrad_ring_kernel chunks each product on its own);
+// c[0] == 0: g.nchunk blocks hold every region.  (A kernel argument of the reduction alone: VGeo is every kernel's first argument.)
+struct ReduceCounts {
+  int c[3];
+};
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s,
+                  ReduceCounts wc = ReduceCounts{{0, 0, 0}});   // prog: words to clear, or NULL
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s,
                   unsigned* health = nullptr);   // health: device word set when a gradient written is not finite (or NULL)
 // the library's per-device gradient-health word (vmlmf_api.hip), what the optimizers' step guard reads; NULL before the first

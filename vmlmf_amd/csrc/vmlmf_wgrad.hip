@@ -176,18 +176,19 @@ __device__ __forceinline__ float reduce_cg_sum(const float* __restrict__ Pall, c
 __device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long e, const float total, float* __restrict__ cgrad);
 
 // blocks that hold element e: all of them, or (wgrad_ring_kernel: each product has its own chunking) the count of e's region
-__device__ __forceinline__ int reduce_cg_count(const VGeo& g, const long long e) {
-  if (g.wc[0] == 0) return g.nchunk;
+__device__ __forceinline__ int reduce_cg_count(const VGeo& g, const ReduceCounts& wc, const long long e) {
+  if (wc.c[0] == 0) return g.nchunk;
   const int GK = g.G * g.KH, MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
   const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (g.KX + 31) / 32 * 32;
   const long long o2 = (long long)g.NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p, oe = o3 + (long long)MT3 * 32 * NB3p;
-  return e < o2 ? g.wc[0] : (e < o3 ? g.wc[1] : (e < oe ? g.wc[2] : g.wc[0]));
+  return e < o2 ? wc.c[0] : (e < o3 ? wc.c[1] : (e < oe ? wc.c[2] : wc.c[0]));
 }
 
-__device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad) {
+__device__ __forceinline__ void reduce_cg_body(const VGeo& g, const float* __restrict__ Pall, float* __restrict__ cgrad,
+                                               const ReduceCounts& wc = ReduceCounts{{0, 0, 0}}) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= g.PCH) return;
-  reduce_cg_scatter(g, e, reduce_cg_sum(Pall, g.PCH, e, 0, reduce_cg_count(g, e)), cgrad);
+  reduce_cg_scatter(g, e, reduce_cg_sum(Pall, g.PCH, e, 0, reduce_cg_count(g, wc, e)), cgrad);
 }
 
 // The same sum when there are many blocks (one per workgroup of rec4_bwd_kernel: up to the batch size): as one thread per
@@ -254,11 +255,11 @@ __device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long
 }
 
 __global__ void __launch_bounds__(256) reduce_cg_kernel(VGeo g, const float* __restrict__ Pall,
-                                                        float* __restrict__ cgrad, unsigned* __restrict__ prog) {
+                                                        float* __restrict__ cgrad, unsigned* __restrict__ prog, ReduceCounts wc) {
   // after a launch with riding workers: the rows' progress words back to zero (nothing reads them any more)
   if (prog != nullptr && blockIdx.x == 0)
     for (int b = threadIdx.x; b < g.B; b += 256) prog[(size_t)b * WR_PROG_STRIDE] = 0u;
-  reduce_cg_body(g, Pall, cgrad);
+  reduce_cg_body(g, Pall, cgrad, wc);
 }
 struct ReduceStack {
   VGeo g[WF_MAXL];
@@ -336,12 +337,12 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   return (int)hipGetLastError();
 }
 
-int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s) {
-  if (g.nchunk > 96 && prog == nullptr) {
+int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s, ReduceCounts wc) {
+  if (g.nchunk > 96 && prog == nullptr && wc.c[0] == 0) {
     hipLaunchKernelGGL(reduce_cg_many_kernel, dim3((unsigned)((g.PCH + 31) / 32)), dim3(256), 0, s, g, wpart, cgrad);
     return (int)hipGetLastError();
   }
-  hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad, prog);
+  hipLaunchKernelGGL(reduce_cg_kernel, dim3((unsigned)((g.PCH + 255) / 256)), dim3(256), 0, s, g, wpart, cgrad, prog, wc);
   return (int)hipGetLastError();
 }
 

@@ -313,7 +313,7 @@ bool wgrad_ring_ok(const VGeo& g) {
          (g.G * g.KH) % 4 == 0 && g.sxT == (long long)g.B * g.sxB && g.syT == (long long)g.B * g.syB && g.KX <= 32 && g.G * g.KH <= 128;
 }
 
-// chunk counts per mode (nc[3] -> g.wc for the reduce): workgroups of about equal MFMA time, one per CU
+// chunk counts per mode (nc_out[3] -> launch_reduce's ReduceCounts): workgroups of about equal MFMA time, one per CU
 int launch_wgrad_ring(const VGeo& g, const WghArgs& w, int cus, int nc_out[3], hipStream_t s) {
   RingArgs q;
   memset(&q, 0, sizeof(q));
