@@ -155,3 +155,21 @@ def test_stack_query_host_logic():
     assert query(2, 8, 5, 20, 64, 8, 8, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED            # unequal hidden sizes
     assert query(2, 8, 5, 20, 64, 8, 8, I_upper=48)[0] == _lib.E_SHAPE                # layer 1 does not read layer 0's width
     assert b"stack" in lib.vmlmf_last_error()
+
+
+def test_every_documented_kernel_switch_is_accepted():
+    """The keys the header documents for vmlmf_tune are the keys the library takes (host-only: the switches are plain
+    process-wide settings), each call moves the generation GraphedTrainStep watches, an unknown key is VMLMF_E_BADARG."""
+    text = open(os.path.join(ROOT, "include", "vmlmf_hip.h")).read()
+    block = text[text.index("Kernel-selection switches"):text.index("int vmlmf_tune(")]
+    keys = re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)
+    assert {"rb", "wride", "inrow", "wring", "adam_guard", "rb_wgrad", "rb_xfold"} <= set(keys), keys
+    defaults = {"rb": -1, "rb_min_batch": 0, "rb_cluster": 0, "rb_rows": 0, "rec3": 6, "wride": 1, "inrow": -1, "adam_guard": 1,
+                "clear_health": 0, "inrow_rows": 1, "rb_wgrad": 0, "rb_xfold": 0, "wring": -1, "test_wride_spin": 0}
+    lib = _lib.lib()
+    for k in keys:
+        assert k in defaults, f"header documents {k}: add its default here"
+        g0 = lib.vmlmf_tune_generation()
+        assert lib.vmlmf_tune(k.encode(), defaults[k]) == 0, (k, lib.vmlmf_last_error())
+        assert lib.vmlmf_tune_generation() == g0 + 1
+    assert lib.vmlmf_tune(b"no_such_switch", 1) == _lib.E_BADARG
