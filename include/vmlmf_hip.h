@@ -325,6 +325,10 @@ size_t vmlmf_embed_backward_scratch_bytes(int R, int V);
 int vmlmf_embed_backward(int R, int H, int V, const int64_t *tokens, const float *dy, float *dweight, void *scratch,
                          size_t scratch_bytes, void *stream);
 
+/* dst (cols x rows, dense) = src (rows x cols, dense)^T, fp32, out of place.  The LM head's weight gradient dW = dz^T h is fastest as
+ * the library GEMM that yields dW^T; this turns it into the (V, H) tensor fc.w.grad is (vmlmf_amd/functional.py: LmHeadLossFn). */
+int vmlmf_transpose(int rows, int cols, const float *src, float *dst, void *stream);
+
 /*
  * Optimizer steps of the reference's two training loops, one launch over every parameter tensor.
  * vmlmf_tensor_list carries up to VMLMF_MAX_TENSORS (param, grad, numel, state_offset, step_index) entries; larger

@@ -735,6 +735,20 @@ def test_embedding_gradient_is_a_position_ordered_sum_without_atomics():
         assert unused.size == 0 or not grads[0][torch.tensor(unused, device=DEV)].any()
 
 
+def test_transpose_is_exact_for_ragged_shapes():
+    """vmlmf_transpose (the LM head's dW^T -> dW): bit-equal to torch's strided copy, shapes that are not multiples of the 64 x 64
+    tile, the PTB head's own (650, 10000), single rows and columns; the same buffer twice is refused."""
+    from vmlmf_amd import _lib
+    from vmlmf_amd.functional import transposed
+    g = torch.Generator(device=DEV).manual_seed(5)
+    for rows, cols in ((650, 10000), (1, 7), (7, 1), (64, 64), (65, 63), (129, 1000), (3, 300)):
+        m = torch.randn(rows, cols, device=DEV, generator=g)
+        t = transposed(m)
+        assert t.shape == (cols, rows) and t.is_contiguous() and torch.equal(t, m.t().contiguous()), (rows, cols)
+    m = torch.randn(8, 8, device=DEV)
+    assert _lib.lib().vmlmf_transpose(8, 8, m.data_ptr(), m.data_ptr(), None) == _lib.E_BADARG
+
+
 def test_a_packed_image_made_for_something_else_is_refused():
     """Verdict r3 (hygiene): the geometry header in front of a kept parameter image was written and never checked.  The
     signature now lives on the host (address -> what the image was packed for): a *_packed call with an image of another

@@ -113,6 +113,7 @@ SYMBOLS = {
     "vmlmf_nll_forward_grad": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_embed_backward_scratch_bytes": (_sz, [_i, _i]),
     "vmlmf_embed_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vmlmf_transpose": (_i, [_i, _i, _vp, _vp, _vp]),
     "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "vmlmf_adam_step_guarded": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,

@@ -1331,6 +1331,13 @@ int vmlmf_embed_backward(int R, int H, int V, const int64_t* tokens, const float
   return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
 }
 
+int vmlmf_transpose(int rows, int cols, const float* src, float* dst, void* stream) {
+  if (rows < 1 || cols < 1) return fail(VMLMF_E_BADARG, "transpose: rows, cols must be >= 1");
+  if (!src || !dst || src == dst) return fail(VMLMF_E_BADARG, "transpose: two distinct buffers");
+  const int rc = launch_transpose(rows, cols, src, dst, (hipStream_t)stream);
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
 int vmlmf_profile_read(float* usec_sum, int32_t* count, int reset) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   for (int k = 0; k < NKERN; ++k) {

@@ -80,3 +80,29 @@ int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* 
   hipLaunchKernelGGL(embed_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, s, R, H, V, words, (const unsigned*)scratch, dy, dW);
   return (int)hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------
+// dst (cols x rows) = src (rows x cols)^T, fp32, through 64 x 64 LDS tiles (both sides in whole 256-byte row segments).  The LM
+// head's weight gradient is fastest as the library GEMM that yields dW^T (H x V); the strided copy that turned it into dW took
+// 43 us for 26 MB (tools/sessions/r04p.sh) - this takes the bytes' time.
+__global__ void __launch_bounds__(256) transpose_kernel(int rows, int cols, const float* __restrict__ src, float* __restrict__ dst) {
+  __shared__ float tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + 4 * i][tx] = src[(size_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (r < rows && c < cols) dst[(size_t)c * rows + r] = tile[tx][ty + 4 * i];
+  }
+}
+
+int launch_transpose(int rows, int cols, const float* src, float* dst, hipStream_t s) {
+  hipLaunchKernelGGL(transpose_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, rows, cols, src, dst);
+  return (int)hipGetLastError();
+}

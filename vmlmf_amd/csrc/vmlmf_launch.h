@@ -194,6 +194,7 @@ int launch_nll_fwd_grad(int R, int V, float* scores, const float* bias, const lo
                         float* rowloss, float* dbias, float* scratch, hipStream_t s);
 // embedding-table gradient (vmlmf_embed.hip)
 size_t embed_bwd_scratch_bytes(int R, int V);
+int launch_transpose(int rows, int cols, const float* src, float* dst, hipStream_t s);   // dst (cols x rows) = src^T
 int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* dy, float* dW, void* scratch, size_t scratch_bytes,
                      hipStream_t s);
 
