@@ -193,24 +193,37 @@ __global__ __launch_bounds__(256, 2) void nll_grad_kernel(int R, int V, float sc
     if (q < nq) reinterpret_cast<float4*>(dbpart + (size_t)blockIdx.x * V)[q] = cs[i];
   }
 }
-// dbias[v] = sum over the workgroups' column partials (fixed order); block 0 also finishes the loss
+// dbias[v] = sum over the workgroups' column partials (fixed order); block 0 also finishes the loss.  A workgroup takes 32
+// columns, its eight 32-lane groups an eighth of the partial rows each (eight loads in flight), the eight sums meet in LDS in
+// group order.  (One thread per column walking all 512 partial rows was a chain of 64 round trips on 40 workgroups: 34 us.)
 __global__ __launch_bounds__(256) void nll_finish_kernel(int R, int V, int nwg, float scale, const float* __restrict__ rowloss,
                                                          const float* __restrict__ dbpart, float* __restrict__ dbias,
                                                          float* __restrict__ loss) {
   __shared__ float red[4];
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < V && dbias != nullptr) {
+  __shared__ float col[8][32];
+  const int li = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + li, cc = c < V ? c : V - 1;
+  if (dbias != nullptr) {
+    const int per = (nwg + 7) / 8;
+    const int w0 = grp * per < nwg ? grp * per : nwg, w1 = w0 + per < nwg ? w0 + per : nwg;
     float a[4] = {0.f, 0.f, 0.f, 0.f};
-    int w = 0;
-    for (; w + 7 < nwg; w += 8) {
+    int w = w0;
+    for (; w + 7 < w1; w += 8) {
       float t[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) t[i] = dbpart[(size_t)(w + i) * V + c];
+      for (int i = 0; i < 8; ++i) t[i] = dbpart[(size_t)(w + i) * V + cc];
 #pragma unroll
       for (int i = 0; i < 8; ++i) a[i & 3] += t[i];
     }
-    for (; w < nwg; ++w) a[0] += dbpart[(size_t)w * V + c];
-    dbias[c] = (a[0] + a[1]) + (a[2] + a[3]);
+    for (; w < w1; ++w) a[0] += dbpart[(size_t)w * V + cc];
+    col[grp][li] = (a[0] + a[1]) + (a[2] + a[3]);
+    __syncthreads();
+    if (grp == 0 && c < V) {
+      float total = col[0][li];
+#pragma unroll
+      for (int q = 1; q < 8; ++q) total += col[q][li];
+      dbias[c] = total;
+    }
   }
   if (blockIdx.x == 0) {
     float part = 0.f;
@@ -258,6 +271,6 @@ int launch_nll_fwd_grad(int R, int V, float* scores, const float* bias, const lo
   hipLaunchKernelGGL(nll_grad_kernel, dim3(nwg), dim3(256), 0, s, R, V, scale, scores, bias, y, rowloss, scratch);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(nll_finish_kernel, dim3((V + 255) / 256), dim3(256), 0, s, R, V, nwg, scale, rowloss, scratch, dbias, loss);
+  hipLaunchKernelGGL(nll_finish_kernel, dim3((V + 31) / 32), dim3(256), 0, s, R, V, nwg, scale, rowloss, scratch, dbias, loss);
   return (int)hipGetLastError();
 }
