@@ -747,10 +747,11 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   if (g.rb) {
     if (packed == nullptr) {
       Scope sc(0, s);
-      if ((rc = hip_fail(launch_rb_pack(g, q, rp, pack + P.RB, s), "rb_pack")) != 0) return rc;
+      if ((rc = hip_fail(launch_rb_pack(g, q, rp, pack + P.RB, s, reinterpret_cast<unsigned*>(ws + L.f_flag)), "rb_pack")) != 0) return rc;
     }
     RbIo io;
     memset(&io, 0, sizeof(io));
+    io.flags_zeroed = packed == nullptr ? 1 : 0;
     io.gx = gx, io.EH = pack + P.EH, io.h0 = h0, io.c0 = c0, io.img = pack + P.RB, io.y = y, io.hT = hT, io.cT = cT;
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;

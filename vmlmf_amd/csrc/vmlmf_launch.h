@@ -119,6 +119,7 @@ struct RbIo {
   const float *wy, *wh0, *wQs;
   float* wP;
   int wgrad;
+  int flags_zeroed;   // forward: rb_pack_kernel of this call has zeroed the epoch words (no memset node)
 };
 // the clustered backward can form dpre^T [qx | Q], h^T dQ and the element sums itself, in the shadow of its cluster exchange
 // (accumulator waves beside the compute waves): one tile per wave, fp32
@@ -130,7 +131,7 @@ bool rb_xfold_ok(const VGeo& g, const RbGeo& q);
 void rb_set_xfold(int on);
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
 bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
-int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s);
+int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags = nullptr);
 int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 

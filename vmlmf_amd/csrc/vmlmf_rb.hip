@@ -68,7 +68,11 @@ __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int
 //   VXA[tv][k][s4]    x side (fwd):   unit c of the tile, gate k     x  x-rank 4 s4 + kq   (as VA: contraction step s4 covers the
 //                                     contiguous ranks 4 s4 .. 4 s4 + 3, so a width that is not a multiple of 16 skips its padding)
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out) {
+// `flags` (or NULL): the cluster's epoch words of the forward launch behind this one, zeroed here instead of by a memset node of
+// their own (a 5 us launch for 1 KB)
+__global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out, unsigned* __restrict__ flags) {
+  if (flags != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < (int)q.flag_words; i += 256) flags[i] = 0u;
   // 32-bit index arithmetic throughout (64-bit divisions by run-time values cost hundreds of cycles each: the first
   // version of this kernel took 290 us at the PTB shape, 0.5 M elements)
   const int NTV = g.G * q.TPGV, KS = g.KH / 4, NP = g.NP, NMT = q.NMT;
@@ -120,7 +124,10 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
 
 // dpre of the slots no tile covers (wholly padded 16-slot tiles behind a group's last unit) must read as zero in the
 // batched kernels that contract over slots (dqx = dpre V_x); rb_bwd_kernel never writes them.
-__global__ void __launch_bounds__(256) rb_zero_pad_kernel(VGeo g, RbGeo q, float* __restrict__ dpre) {
+// (block 0 also zeroes the backward launch's epoch words: no memset node)
+__global__ void __launch_bounds__(256) rb_zero_pad_kernel(VGeo g, RbGeo q, float* __restrict__ dpre, unsigned* __restrict__ flags) {
+  if (flags != nullptr && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < (int)q.flag_words; i += 256) flags[i] = 0u;
   const size_t row = blockIdx.x;   // (t, b)
   const int per = 64 * g.W - 16 * q.TPGV;   // uncovered slots per group
   for (int i = threadIdx.x; i < g.G * per; i += 256) {
@@ -253,10 +260,10 @@ bool rb_wgrad_ok(const VGeo& g, const RbGeo& q) {
   return g_rb_wgrad && g.rb > 1 && q.S > 1 && q.MT == 1 && !g.bf && g.G == 1 && g.KH <= 32 && g.KX <= 32 && g.Bp == g.B;
 }
 
-int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s) {
+int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags) {
   if (q.total >= (1LL << 30)) return -3;
   const long long blocks = (q.total + 255) / 256;
-  hipLaunchKernelGGL(rb_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, q, p, img);
+  hipLaunchKernelGGL(rb_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, q, p, img, q.S > 1 ? zero_flags : nullptr);
   return (int)hipGetLastError();
 }
 
@@ -268,7 +275,7 @@ static int rb_dispatch(const VGeo& g, const RbGeo& q, const RbIo& io, bool fwd, 
 }
 
 int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s) {
-  if (q.S > 1) {
+  if (q.S > 1 && !io.flags_zeroed) {
     const hipError_t e = hipMemsetAsync(io.flag, 0, sizeof(unsigned) * (size_t)q.flag_words, s);
     if (e != hipSuccess) return (int)e;
   }
@@ -276,12 +283,13 @@ int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s) 
 }
 
 int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s) {
-  if (q.S > 1) {
+  const bool pad = 64 * g.W - 16 * q.TPGV > 0;
+  if (q.S > 1 && !pad) {
     const hipError_t e = hipMemsetAsync(io.flag, 0, sizeof(unsigned) * (size_t)q.flag_words, s);
     if (e != hipSuccess) return (int)e;
   }
-  if (64 * g.W - 16 * q.TPGV > 0) {
-    hipLaunchKernelGGL(rb_zero_pad_kernel, dim3((unsigned)(g.T * g.B)), dim3(256), 0, s, g, q, io.dpre);
+  if (pad) {
+    hipLaunchKernelGGL(rb_zero_pad_kernel, dim3((unsigned)(g.T * g.B)), dim3(256), 0, s, g, q, io.dpre, q.S > 1 ? io.flag : nullptr);
     const int rc = (int)hipGetLastError();
     if (rc != 0) return rc;
   }
