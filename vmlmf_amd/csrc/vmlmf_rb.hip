@@ -222,7 +222,7 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
   q.VXA = take(NTV * 4 * (g.KX / 4) * 64);
   q.total = o;
   q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * q.NMT * 256 : 0;
-  q.flag_words = S > 1 ? (long long)q.nrb * S + 64 : 0;
+  q.flag_words = S > 1 ? (long long)q.nrb * S * 32 + 64 : 0;   // (vmlmf_rb.inc: RB_FLAG_STRIDE)
   if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G, g.bf != 0)) return false;
   *out = q;
   return true;
