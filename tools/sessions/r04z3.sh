@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r04z3; mkdir -p $O
 cp vmlmf_amd/lib/libvmlmf_hip.so /tmp/base.so
-for v in base F G H; do
+for v in ${VARS:-base F G H}; do
   if [ $v = base ]; then cp /tmp/base.so vmlmf_amd/lib/libvmlmf_hip.so; else cp vmlmf_amd/lib/rbvar$v.so vmlmf_amd/lib/libvmlmf_hip.so; fi
   timeout 600 python -m pytest tests/test_gpu_rb.py -x -q -m gpu > $O/tests_$v.txt 2>&1; echo "$v tests rc=$? $(grep -E 'passed|failed' $O/tests_$v.txt | tail -1)"
   for rep in 1 2; do
