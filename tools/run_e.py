@@ -20,6 +20,10 @@ st = (torch.zeros(B, H, device="cuda"), torch.zeros(B, H, device="cuda"))
 
 
 def step():
+    if "--infer" in sys.argv:   # forward only, no tapes (torch.no_grad): the recurrent kernel without its tape stores
+        with torch.no_grad():
+            l(x, st)
+        return
     l.zero_grad(set_to_none=True)
     y, _ = l(x, st)
     y.sum().backward()
