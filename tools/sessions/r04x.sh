@@ -1,7 +1,7 @@
 #!/bin/bash
 # r04x: kernel split of a config E layer at 32 rows per GPU (the 8-GPU point of configs[4])
 cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out/r04x; mkdir -p $O
+O=gpurun_out/r04x2; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for v in "" "--v3"; do
 timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$O/p -o e -- python3 $GRAFT_REPO_ROOT/tools/run_e.py --nograph --batch 32 $v > /dev/null 2>&1
