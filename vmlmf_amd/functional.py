@@ -844,13 +844,17 @@ def head_forms(R, H, V, device):
     tune = os.environ.get("VMLMF_HEAD_TUNE", "1") != "0" and not torch.cuda.is_current_stream_capturing()
     chosen = {k: (None, v[0][0], v[0][1], None) for k, v in prods.items()}
     if tune:
+        # with the user's TunableOp on (PYTORCH_TUNABLEOP_ENABLED=1) the solutions of both libraries are candidates of every call:
+        # no preferred-library switch, under which the other library's tuned solutions are not found again
+        tunable = getattr(torch.cuda, "tunable", None)
+        libs = [None] if (tunable is not None and tunable.is_enabled()) else _blas_libs()
         with torch.no_grad():
             a = {"fwd": (torch.randn(R, H, device=device), torch.randn(V, H, device=device)),
                  "dh": (torch.randn(R, V, device=device), torch.randn(V, H, device=device)),
                  "dw": (torch.randn(R, V, device=device), torch.randn(R, H, device=device))}
             for name, forms in prods.items():
                 best = None
-                for lib in _blas_libs():
+                for lib in libs:
                     for label, fn in forms:
                         try:
                             with _with_blas(lib):
