@@ -234,7 +234,7 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
 // 4.69 ms in its best form, 1.42 vs 1.40 ms at 32 rows per GPU.  The 32 extra MFMAs of a wave-step (0.43 us) and the qx / x loads
 // cost the member what the 41 KB of pre-activations did - those were prefetched a step ahead behind the exchange - and the
 // xexp_mfma_kernel launch it removes (38 us per layer) is what the extra 15 us of rb_fwd_kernel plus noise give back.  The step
-// of these kernels is the cluster exchange (5.4 of 7.5 us), not their memory pipe.
+// of these kernels is the cluster exchange (5.4 of 7.5 us in round 2; 6.2 - 6.9 us per step since round 4), not their memory pipe.
 static bool g_rb_xfold = []() { const char* e = getenv("VMLMF_RB_XFOLD"); return e != nullptr && e[0] == '1'; }();
 void rb_set_xfold(int on) { g_rb_xfold = on != 0; }   // vmlmf_tune("rb_xfold", v)
 bool rb_xfold_ok(const VGeo& g, const RbGeo& q) {
