@@ -217,8 +217,11 @@ def test_clip_sgd_step_matches_the_lm_loop():
     """clip_grad_norm_ + `param -= lr * grad` (lm_test.py:203-209), clipping active and inactive."""
     import vmlmf_amd
     g = torch.Generator().manual_seed(3)
-    for max_norm, scale in ((0.25, 1.0), (1e3, 1.0)):
-        mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in [(650, 32), (2600,), (1, 650)]]
+    # (shapes: 16-byte accesses with and without a tail of n % 4 elements; one tensor of more than 2^20 elements - the norm's
+    # partial sums then run on 1024-thread workgroups)
+    for max_norm, scale, shapes in ((0.25, 1.0, [(650, 32), (2600,), (1, 650)]), (1e3, 1.0, [(650, 32), (2600,), (1, 650)]),
+                                    (0.25, 1.0, [(7, 3), (1100, 1000), (5,)]), (1e4, 1.0, [(7, 3), (1100, 1000), (5,)])):
+        mine = [torch.nn.Parameter(torch.randn(*s, generator=g).cuda()) for s in shapes]
         ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
         for a, b in zip(mine, ref):
             gr = scale * torch.randn(*a.shape, generator=g).cuda()
