@@ -299,6 +299,31 @@ def other_configs(iters=100):
     ms = (time.perf_counter() - t0) / 20 * 1e3
     res["E_1gpu"] = {"ms_per_step": round(ms, 4), "timesteps_per_s": round(35 / (ms * 1e-3), 1),
                      "workload": "BASELINE configs[4] on one GPU: 2 x MyVMLSTMGroup(650), ranks 32 / [32, 32], B 256, T 35; layers forward + backward, eager launches"}
+    # ... and what one GPU of an 8-GPU node gets of it (32 rows): the same layers, the clustered kernels with 4 live rows per workgroup
+    try:
+        xe32 = 0.05 * torch.randn(35, 32, 650, device="cuda")
+        st32 = [(torch.zeros(32, 650, device="cuda"), torch.zeros(32, 650, device="cuda")) for _ in layers]
+
+        def fbe32():
+            for l in layers:
+                l.zero_grad(set_to_none=True)
+            h = xe32
+            for l, st in zip(layers, st32):
+                h, _ = l(h, st)
+            h.sum().backward()
+
+        for _ in range(3):
+            fbe32()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            fbe32()
+        torch.cuda.synchronize()
+        ms32 = (time.perf_counter() - t0) / 20 * 1e3
+        res["E_32rows"] = {"ms_per_step": round(ms32, 4), "timesteps_per_s": round(35 / (ms32 * 1e-3), 1),
+                           "workload": "the same two layers at 32 rows (configs[4]'s share of one GPU on an 8-GPU node), eager launches"}
+    except Exception as e:   # never at the expense of the line
+        res["E_32rows"] = {"error": f"{type(e).__name__}: {e}"}
     return res
 
 
