@@ -338,6 +338,9 @@ def main():
     ap.add_argument("--graph-collective", action="store_true", help="capture the gradient all-reduce inside the hipGraph too")
     ap.add_argument("--force-collective", action="store_true", help="run the RCCL gradient all-reduce even with one rank")
     ap.add_argument("--torch-loss", action="store_true", help="torch.nn.functional.cross_entropy instead of vmlmf_amd.cross_entropy")
+    ap.add_argument("--separate-loss", action="store_true",
+                    help="criterion(net(x), target) as two calls (vmlmf_amd.cross_entropy: a launch of its own) instead of Net.loss, "
+                         "where the criterion rides on the forward recurrence's launch")
     ap.add_argument("--repack", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--keep-images", action="store_true",
                     help="value = the step with kept parameter images (no pack_kernel while the parameters are unchanged: "
@@ -449,10 +452,14 @@ def main():
     # gradient its forward kernel already wrote when it is handed this tensor; same values either way
     one = vmlmf_amd.unit_gradient(dev)
 
+    fused_loss = not (args.torch_loss or args.separate_loss)
+
     def fwd_bwd():
         net.zero_grad(set_to_none=True)
-        out = net(x)
-        loss = criterion(out, tgt)
+        if fused_loss:
+            loss = net.loss(x, tgt)          # = criterion(net(x), tgt), the criterion inside the forward launch (train.py:61-63)
+        else:
+            loss = criterion(net(x), tgt)
         loss.backward(one)
         return loss
 
@@ -616,7 +623,7 @@ def main():
 
             def fb_other():
                 net.zero_grad(set_to_none=True)
-                lo = criterion(net(xo), to)
+                lo = net.loss(xo, to) if fused_loss else criterion(net(xo), to)
                 lo.backward(one)
                 return lo
 
@@ -815,7 +822,9 @@ def main():
                        "launch": launch_mode,
                        "parameter_images": "kept while the parameters are unchanged (--keep-images)" if args.keep_images else
                                            "packed inside every step (what a training loop sees)",
-                       "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else "vmlmf_amd.cross_entropy"},
+                       "criterion": "torch.nn.functional.cross_entropy" if args.torch_loss else
+                                    ("vmlmf_amd.cross_entropy" if args.separate_loss else
+                                     "vmlmf_amd.Net.loss (cross-entropy riding on the forward launch, C ABI vmlmf_ce)")},
             "eager_ms_per_step": round(dt_eager / args.steps * 1e3, 4),
             "sample_timesteps_per_s": round(value * B_PER_GPU, 1),
             "step_flops": rows * F_STEP * world,

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 9
+#define VMLMF_ABI_VERSION 10
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -123,13 +123,6 @@ const char *vmlmf_last_error(void);
  *   "clear_health"  (any value) clear the gradient-health word: it stays set from a backward that wrote non-finite gradients until a
  *                   guarded optimizer step consumes it - a caller that handled such a step some other way says so here, or the
  *                   next guarded step is skipped once
- *   "inrow_rows"    batch rows per workgroup of that backward: 1 (default) or 2 (one set of accumulators for two rows; measured
- *                   slower than two rounds of one-row workgroups)
- *   "rb_wgrad"      1: the clustered backward of one-group layers with padded rank <= 32 forms the weight-gradient products itself,
- *                   between publishing its partials and waiting for the cluster's; 0 (default: measured no faster): it writes dpre
- *                   only and the batched weight-gradient kernel forms them
- *   "rb_xfold"      1: clustered layers form the x side of their pre-activations inside the forward recurrence (from x and
- *                   qx = x U_x) instead of reading the (T, B, 4H) tensor; 0 (default: measured no faster)
  *   "wring"         the batched weight-gradient products of large layers (thread slots >= 256, fp32 tapes, time-major contiguous x / y)
  *                   with their operands streamed through an LDS ring (wgrad_ring_kernel): -1 (default) for the layers of the
  *                   step-wise / clustered recurrences with >= 1024 rows, 0 never, 1 wherever the kernel takes the layer
@@ -202,9 +195,26 @@ typedef struct vmlmf_head {
   const float *dlogits;
   float *dweight, *dbias;
 } vmlmf_head;
+/* ABI 10: the criterion of the reference's loop (nn.CrossEntropyLoss() with default arguments on Net's output, V/src/train_test/
+ * train.py:58-65) riding on the same forward launch as the classifier: the logits of a batch row never leave the workgroup that
+ * formed them before the row's log-sum-exp, loss term and d(loss)/d(logits) = (softmax - onehot) / N exist; the mean over the N
+ * rows whose target is not ignore_index is a fixed-order sum by the last workgroup to finish (run-to-run identical, no float
+ * atomics).  Forward only, together with `head`; values as vmlmf_ce_forward's on the same logits (the mean's summation order
+ * differs).  On the layer families whose classifier is a launch of its own (row-block, step-wise) the criterion is one too. */
+typedef struct vmlmf_ce {
+  const int64_t *target;     /* (B) class indices; an index outside [0, classes) poisons the loss with NaN               */
+  int64_t ignore_index;
+  float *loss, *nvalid;      /* 1, 1                                                                                       */
+  float *lse;                /* (B)                                                                                        */
+  float *dlogits_unit;       /* (B, classes) gradient of the logits for d(loss) = 1, or NULL                               */
+  float *rowloss;            /* (B) scratch: the rows' loss terms                                                          */
+  uint32_t *ticket;          /* ONE word that is zero before the first launch; every launch leaves it zero.  Launches that
+                              * share a word must be ordered on one stream                                                 */
+} vmlmf_ce;
 typedef struct vmlmf_extra {
   const void *packed;        /* kept parameter images (vmlmf_pack_params) or NULL */
   const vmlmf_head *head;    /* classifier on the final hidden state or NULL      */
+  const vmlmf_ce *ce;        /* ABI 10: cross-entropy on that classifier's logits (forward calls; needs `head`) or NULL */
 } vmlmf_extra;
 int vmlmf_seq_forward_ex(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
                          const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,

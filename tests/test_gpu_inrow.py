@@ -90,20 +90,14 @@ def test_in_row_weight_gradients_vs_oracle(case, inrow):
 @pytest.mark.parametrize("case", [(O.V1, 300, 6, 7, 100, 8, [16], True), (O.V1, 259, 5, 9, 180, 16, [16], True), (O.V1, 7, 4, 8, 64, 8, [8], False),
                                   (O.V1, 64, 9, 9, 180, 16, [16], True)],
                          ids=lambda c: "B%d_T%d_H%d" % (c[1], c[2], c[4]))
-def test_two_rows_per_workgroup_vs_oracle(case, inrow):
-    """vmlmf_tune("inrow_rows", 2): two rows' recurrences side by side in one workgroup, one set of accumulators, an MFMA
-    contracts the two ROWS of a step (not the default: measured slower than two rounds of one-row workgroups, vmlmf_api.hip).
-    Odd batches mask the last workgroup's second row."""
-    from vmlmf_amd import _lib
+def test_batches_beyond_the_cu_count_vs_oracle(case, inrow):
+    """Batches with more rows than the chip has CUs (workgroups queue up), odd batches, a batch below the riding range forced onto
+    the in-row form: one backward launch, no weight-gradient launch, every gradient against the oracle."""
     variant, B, T, I, H, rw, ru, states = case
     P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=3 * B + T, states=states)
-    _lib.tune("inrow_rows", 2)
-    try:
-        got, counts = _kernel_counts(lambda: run_hip(variant, P, x, h0, c0, dy, dhT, dcT, need_dx=False))
-    finally:
-        _lib.tune("inrow_rows", 1)
+    got, counts = _kernel_counts(lambda: run_hip(variant, P, x, h0, c0, dy, dhT, dcT, need_dx=False))
     assert counts["rec_bwd_kernel"] == 1 and counts["wgrad_mfma_kernel"] == 0, counts
-    compare_all(got, run_literal(variant, P, x, h0, c0, dy, dhT, dcT), "inrow.rows2")
+    compare_all(got, run_literal(variant, P, x, h0, c0, dy, dhT, dcT), "inrow.large")
 
 
 @pytest.mark.parametrize("which", ["dy", "dhT", "dcT", "dy+dcT"])

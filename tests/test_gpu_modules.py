@@ -806,3 +806,62 @@ def test_a_packed_image_made_for_something_else_is_refused():
     rc, y3 = forward(dA, sA, imgA2, 8, 5, 9, 64)
     assert rc == 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("layers,B,T,C,ignored", [([180], 64, 16, 18, 0), ([180], 64, 128, 18, 5), ([24], 1, 3, 18, 0), ([64], 300, 4, 18, 17),
+                                                  ([24, 40], 7, 5, 18, 2), ([600], 5, 3, 18, 0)])
+def test_criterion_riding_on_the_forward_launch_equals_the_two_lines(layers, B, T, C, ignored):
+    """Net.loss(x, target) = criterion(net(x), target) of train.py:61-63 as one call (C ABI 10, vmlmf_ce): on the VALU recurrent
+    kernels the row's log-sum-exp, loss term and d(loss)/d(logits) come out of the forward recurrence's epilogue, the mean is the
+    last workgroup's fixed-order sum.  Same loss (to the summation order of the mean), same logits bit for bit, same gradients as
+    the package's criterion on the logits - with ignored rows, a single row, more rows than CUs, and on the families whose head is a
+    launch of its own (two-layer wavefront stack, H = 600 step-wise / clustered layer: there the criterion is a launch too)."""
+    import copy
+    import vmlmf_amd
+    torch.manual_seed(11)
+    a = Net(9, layer_sizes=layers, w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    b = copy.deepcopy(a)
+    x = torch.randn(B, T, 9, device=DEV)
+    t = torch.randint(0, C, (B,), device=DEV)
+    if ignored:
+        t[torch.randperm(B, device=DEV)[:min(ignored, B - 1)]] = -100
+    for rep in range(2):                                  # (twice: the ticket word must be back at zero)
+        a.zero_grad(set_to_none=True)
+        la, za = a.loss(x, t, return_logits=True)
+        la.backward(vmlmf_amd.unit_gradient(DEV))
+    zb = b(x)
+    lb = vmlmf_amd.cross_entropy(zb, t)
+    lb.backward()
+    assert torch.equal(za.reshape(zb.shape), zb)
+    assert abs(float(la) - float(lb)) <= 2e-6 * max(1.0, abs(float(lb))), (float(la), float(lb))
+    ref = torch.nn.functional.cross_entropy(zb.detach().double().cpu(), t.cpu())
+    assert abs(float(la) - float(ref)) <= 2e-6 * max(1.0, abs(float(ref)))
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None, k
+            continue
+        assert_grad(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), k, rel=2e-5)
+
+
+def test_criterion_riding_scales_with_a_foreign_loss_gradient_and_runs_without_grad():
+    """d(loss) that is not the package's constant one scales the stored gradient; a logits gradient from elsewhere adds to it;
+    under torch.no_grad() the call returns the loss of the inference kernels; an out-of-range target poisons the loss."""
+    import copy
+    import vmlmf_amd
+    torch.manual_seed(12)
+    a = Net(9, layer_sizes=[64], w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    b = copy.deepcopy(a)
+    x = torch.randn(10, 6, 9, device=DEV)
+    t = torch.randint(0, 18, (10,), device=DEV)
+    la, za = a.loss(x, t, return_logits=True)
+    (3.0 * la + za.square().sum()).backward()
+    zb = b(x)
+    (3.0 * torch.nn.functional.cross_entropy(zb, t) + zb.square().sum()).backward()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if pb.grad is not None:
+            assert_grad(pa.grad.cpu().numpy(), pb.grad.cpu().numpy(), k, rel=2e-5)
+    with torch.no_grad():
+        l0 = a.loss(x, t)
+    assert abs(float(l0) - float(la)) <= 1e-6
+    t[3] = 18
+    assert torch.isnan(a.loss(x, t))

@@ -251,12 +251,9 @@ def test_cluster_exchange_is_bit_stable_under_uneven_load():
 @pytest.mark.parametrize("case", [(O.V4, 40, 4, 650, 650, 32, [32, 32]), (O.V3, 24, 5, 650, 650, 32, [32]), (O.V1, 18, 3, 20, 600, 8, [8]),
                                   (O.V3, 16, 3, 400, 400, 12, [20])],
                          ids=lambda c: "v%d_B%d_T%d_I%d_H%d_r%d" % c[:6])
-def test_x_side_formed_inside_the_clustered_forward(case):
-    """vmlmf_tune("rb_xfold", 1): rb_fwd_kernel<..., XF> forms the x-side pre-activations itself (a third MFMA product from qx
-    and the V_x image, x . ex + b on the accumulator layout) instead of reading what xexp_mfma_kernel writes.  Not the default
-    (measured no faster, vmlmf_rb.hip), kept parity-green: against the fp64 oracle, and bit for bit against... nothing - the two
-    forms sum in different orders - so both are held to the oracle at the suite's tolerance.  Narrow inputs (I < H), x-ranks
-    that are not a multiple of 16, both cluster layouts."""
+def test_clusters_of_sixteen_with_full_tiles_vs_oracle(case):
+    """Clusters of sixteen workgroups with all 16 rows of a tile live, on layers with narrow inputs (I < H), x-ranks that are not a
+    multiple of 16, both cluster layouts (two groups flat, one group), given initial states: against the oracle."""
     variant, B, T, I, H, rw, ru = case
     tm = variant in (O.V3, O.V4)
     rng = np.random.Generator(np.random.PCG64(17 * B + H))
@@ -269,25 +266,21 @@ def test_x_side_formed_inside_the_clustered_forward(case):
     dhT = rng.standard_normal((B, H)).astype(np.float32)
     ref = run_literal(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
     _lib.tune("rb_cluster", 16)
-    _lib.tune("rb_rows", 16)          # full tiles: the x-fold is only taken with 16 live rows per workgroup
+    _lib.tune("rb_rows", 16)
     try:
-        for xf in (1, 0):
-            _lib.tune("rb_xfold", xf)
-            got = run_hip(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
-            compare_all(got, ref, f"rb.xfold{xf}")
+        got = run_hip(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
+        compare_all(got, ref, "rb.cluster16.rows16")
     finally:
-        _lib.tune("rb_xfold", 0)
+        _lib.tune("rb_cluster", 0)
         _lib.tune("rb_rows", 0)
 
 
 @pytest.mark.parametrize("case", [(O.V3, 24, 5, 650, 650, 32, [32]), (O.V1, 18, 3, 20, 600, 8, [8]), (O.V3, 16, 4, 400, 400, 12, [20]),
                                   (O.V1, 33, 2, 300, 520, 16, [24])],
                          ids=lambda c: "v%d_B%d_T%d_I%d_H%d_r%d" % c[:6])
-def test_weight_gradients_formed_inside_the_clustered_backward(case):
-    """vmlmf_tune("rb_wgrad", 1): rb_bwd_kernel<..., WG> forms dpre^T [qx | Q], h^T dQ and the element sums itself (between a member's
-    publication and its wait for the cluster), only x^T dqx keeps the batched kernel.  Not the default (measured no faster,
-    vmlmf_rb.hip), kept parity-green: every gradient against the fp64 oracle, with 16 and with fewer live rows per workgroup,
-    ragged last tiles, a rank that is not a multiple of 16, zero and given initial states."""
+def test_clustered_layers_weight_gradients_vs_oracle(case):
+    """One-group clustered layers: every gradient against the oracle with 16 and with fewer live rows per workgroup, ragged last
+    tiles, a rank that is not a multiple of 16, zero and given initial states."""
     variant, B, T, I, H, rw, ru = case
     tm = variant in (O.V3, O.V4)
     rng = np.random.Generator(np.random.PCG64(19 * B + H))
@@ -303,9 +296,8 @@ def test_weight_gradients_formed_inside_the_clustered_backward(case):
     try:
         for rows in (16, 0):
             _lib.tune("rb_rows", rows)
-            _lib.tune("rb_wgrad", 1)
             got = run_hip(variant, P, x, h0, c0, dy, dhT, None, time_major=tm)
-            compare_all(got, ref, f"rb.wgrad.rows{rows}")
+            compare_all(got, ref, f"rb.cluster16.rows{rows}")
     finally:
-        _lib.tune("rb_wgrad", 0)
+        _lib.tune("rb_cluster", 0)
         _lib.tune("rb_rows", 0)

@@ -21,17 +21,17 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 DEMANGLE = shutil.which("c++filt") or "c++filt"
 
 # kernel (demangled prefix) -> (max VGPRs, max scratch_load / scratch_store INSTRUCTIONS in its code: the metadata's
-# private_segment_fixed_size also counts stack objects no instruction touches).  Config A = rec_fwd_kernel<16,1,false,256,3,0,true> (forward, with
-# the x-projection wave: its callee-saved registers are the scratch) and rec3_bwd_kernel<16,0,1> (backward with the riding
+# private_segment_fixed_size also counts stack objects no instruction touches).  Config A = rec_fwd_kernel<16,1,false,256,3,true> (forward, with
+# the x-projection wave: its callee-saved registers are the scratch) and rec3_bwd_kernel<16,1> (backward with the riding
 # workers); the values are what round 3 shipped with a margin of one allocation granule (8 registers).
 BUDGET = {
-    "void rec_fwd_kernel<16, 1, false, 256, 3, 0, true>(": (256, 0),     # (its x-projection wave is a callee of its own: below)
-    "void rec_fwd_kernel<16, 1, false, 256, 3, 0, false>(": (128, 0),
-    "void rec3_bwd_kernel<16, 0, 0>(": (136, 0),
-    "void rec3_bwd_kernel<16, 0, 1>(": (136, 0),
-    "void rec3_bwd_kernel<16, 0, 2>(": (136, 0),
-    "void rec3_bwd_kernel<8, 0, 0>(": (136, 0),
-    "void rec_bwd_kernel<16, 1, false, 256, 3, 0, 0>(": (128, 0),
+    "void rec_fwd_kernel<16, 1, false, 256, 3, true>(": (256, 0),     # (its x-projection wave is a callee of its own: below)
+    "void rec_fwd_kernel<16, 1, false, 256, 3, false>(": (128, 0),
+    "void rec3_bwd_kernel<16, 0>(": (136, 0),
+    "void rec3_bwd_kernel<16, 1>(": (136, 0),
+    "void rec3_bwd_kernel<16, 2>(": (136, 0),
+    "void rec3_bwd_kernel<8, 0>(": (136, 0),
+    "void rec_bwd_kernel<16, 1, false, 256, 3, 0>(": (128, 0),
     "void wf_fwd_kernel<24, 4, 1, 256>(": (168, 0),
     "void wf_bwd_kernel<24, 4, 1, 256>(": (168, 0),
 }

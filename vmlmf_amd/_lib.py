@@ -18,7 +18,7 @@ NKERNELS = 12
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 9
+ABI_VERSION = 10
 GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
@@ -49,8 +49,14 @@ class Head(ctypes.Structure):
                 ("dbias", ctypes.c_void_p)]
 
 
+class Ce(ctypes.Structure):
+    """vmlmf_ce (ABI 10): the cross-entropy criterion riding on the classifier's logits in the forward launch."""
+    _fields_ = [("target", ctypes.c_void_p), ("ignore_index", ctypes.c_int64), ("loss", ctypes.c_void_p), ("nvalid", ctypes.c_void_p),
+                ("lse", ctypes.c_void_p), ("dlogits_unit", ctypes.c_void_p), ("rowloss", ctypes.c_void_p), ("ticket", ctypes.c_void_p)]
+
+
 class Extra(ctypes.Structure):
-    _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head))]
+    _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head)), ("ce", ctypes.POINTER(Ce))]
 
 
 class StackLayer(ctypes.Structure):

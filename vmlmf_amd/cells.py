@@ -64,10 +64,10 @@ class MyVMLMFCell(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
-        """Whole-sequence evaluation: (y, hT, cT)."""
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None, target=None, ignore_index=-100):
+        """Whole-sequence evaluation: (y, hT, cT) (+ logits with a classifier `head`, + loss with a `target` for it)."""
         return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
-                              **self.kernel_cfg())
+                              target=target, ignore_index=ignore_index, **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
         """One step: x (B, I), (h, c) each (B, H) -> (h_next, c_next).  T = 1 of the same kernels."""
@@ -119,9 +119,9 @@ class MyVMLMFCellg2(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=list(self.u_ranks), g=self.g,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None, target=None, ignore_index=-100):
         return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
-                              **self.kernel_cfg())
+                              target=target, ignore_index=ignore_index, **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
         (h, c) = hidden_states
@@ -219,13 +219,13 @@ class MyLSTMCell(nn.Module):
         return dict(variant=self.variant, w_rank=self.w_rank, u_ranks=[self.u_ranks], g=1,
                     dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
 
-    def sequence(self, x, h0=None, c0=None, time_major=False, head=None):
+    def sequence(self, x, h0=None, c0=None, time_major=False, head=None, target=None, ignore_index=-100):
         """Whole-sequence evaluation on the HIP kernels (low-rank mode only): (y, hT, cT)."""
         if not self.low_rank:
             raise RuntimeError("vmlmf_amd: MyLSTMCell.sequence needs w_rank and u_ranks (the vanilla cell is "
                                "not on the HIP path)")
         return vmlmf_sequence(x=x, h0=h0, c0=c0, params=self.kernel_params(), time_major=time_major, head=head,
-                              **self.kernel_cfg())
+                              target=target, ignore_index=ignore_index, **self.kernel_cfg())
 
     def forward(self, x, hidden_states):
         (h, c) = hidden_states
@@ -276,10 +276,11 @@ class MyLSTM(nn.Module):
             in_size = hidden_size
         self.rnncells = nn.ModuleList(cells)
 
-    def run_layers(self, x, head=None):
+    def run_layers(self, x, head=None, target=None, ignore_index=-100):
         """(output sequence of the last layer, [final h of every layer]); with `head` = (weight, bias) of a classifier on the
-        last layer's final hidden state also its logits (None when the last layer cannot carry it)."""
-        hiddens, logits = [], None
+        last layer's final hidden state also its logits (None when the last layer cannot carry it); with a `target` for that
+        classifier also the mean cross-entropy of the logits (None when the launch that formed them could not carry it)."""
+        hiddens, logits, loss = [], None, None
         # every layer in one wavefront launch per direction when the stack is covered (same cell type and sizes above the
         # first layer; include/vmlmf_hip.h: vmlmf_stack_*); a classifier rides on the top layer's workgroups
         cells = list(self.rnncells)
@@ -293,11 +294,17 @@ class MyLSTM(nn.Module):
                 out = None if kept else vmlmf_stack(x=x, layer_params=[c.kernel_params() for c in cells],
                                                     time_major=not self.batch_first, head=head, **cfg)
                 if out is not None:
-                    return (out[0], out[1], out[3]) if head is not None else (out[0], out[1])
+                    if head is not None:
+                        return (out[0], out[1], out[3]) + ((None,) if target is not None else ())
+                    return out[0], out[1]
         for i, cell in enumerate(self.rnncells):
             fused = hasattr(cell, "sequence") and (not isinstance(cell, MyLSTMCell) or (cell.low_rank and x.is_cuda))
             if fused and head is not None and i == len(self.rnncells) - 1:
-                x, h, _, logits = cell.sequence(x, None, None, time_major=not self.batch_first, head=head)
+                if target is not None:
+                    x, h, _, logits, loss = cell.sequence(x, None, None, time_major=not self.batch_first, head=head, target=target,
+                                                          ignore_index=ignore_index)
+                else:
+                    x, h, _, logits = cell.sequence(x, None, None, time_major=not self.batch_first, head=head)
             elif fused:
                 x, h, _ = cell.sequence(x, None, None, time_major=not self.batch_first)
             else:
@@ -311,7 +318,7 @@ class MyLSTM(nn.Module):
                 x = torch.stack(outs, self.time_index)
             hiddens.append(h)
         if head is not None:
-            return x, hiddens, logits
+            return (x, hiddens, logits) + ((loss,) if target is not None else ())
         return x, hiddens
 
     def forward(self, x):
@@ -355,3 +362,26 @@ class Net(nn.Module):
             y, _ = self.rnn(x)
             last = y[:, -1]
         return head_linear(last, self.lin.weight, self.lin.bias).squeeze(1)
+
+    def loss(self, x, target, ignore_index=-100, return_logits=False):
+        """criterion(self(x), target) for criterion = nn.CrossEntropyLoss(ignore_index=...) with its other arguments at their
+        defaults - the pair of lines `output = model(data); loss = criterion(output, target)` of the reference's loop
+        (V/src/train_test/train.py:61-63) as ONE call, so that the criterion can ride on the launch that forms the logits: a batch
+        row's logits, log-sum-exp, loss term and d(loss)/d(logits) come out of the forward recurrence's epilogue, and the backward
+        needs no criterion launch either.  Same values as the two lines (the mean's summation order differs); wherever the classifier
+        cannot ride (CPU tensors, other dtypes, more than 32 classes, stacks on the wavefront launches) it IS the two lines."""
+        ride = (isinstance(self.rnn, MyLSTM) and self.rnn.batch_first and x.is_cuda and x.dtype == torch.float32
+                and self.lin.weight.shape[0] <= _lib.HEAD_MAX_CLASSES and self.lin.weight.dtype == torch.float32
+                and target.dtype == torch.int64 and target.dim() == 1)
+        if ride:
+            _, _, logits, loss = self.rnn.run_layers(x, head=(self.lin.weight, self.lin.bias), target=target, ignore_index=ignore_index)
+            if logits is not None and loss is not None:
+                return (loss, logits) if return_logits else loss
+            if logits is not None:
+                from .functional import cross_entropy
+                loss = cross_entropy(logits.squeeze(1), target, ignore_index)
+                return (loss, logits) if return_logits else loss
+        from .functional import cross_entropy
+        logits = self.forward(x)
+        loss = cross_entropy(logits, target, ignore_index)
+        return (loss, logits) if return_logits else loss

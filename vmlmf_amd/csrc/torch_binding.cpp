@@ -98,8 +98,12 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
   static variable_list forward(AutogradContext* ctx, Tensor x, c10::optional<Tensor> h0o, c10::optional<Tensor> c0o,
                                at::TensorList params_in, int64_t variant, int64_t g, int64_t w_rank,
                                std::vector<int64_t> u_ranks, bool time_major, bool training, int64_t dtype,
-                               c10::optional<Tensor> packed_o, c10::optional<Tensor> head_w_o, c10::optional<Tensor> head_b_o) {
+                               c10::optional<Tensor> packed_o, c10::optional<Tensor> head_w_o, c10::optional<Tensor> head_b_o,
+                               c10::optional<Tensor> target_o, int64_t ignore_index, c10::optional<Tensor> unit_o,
+                               c10::optional<Tensor> ticket_o) {
     // head_w / head_b: a classifier riding on the layer's final hidden state (Net.lin): its logits are the 4th output
+    // target (+ the package's unit-gradient tensor and ticket word): the criterion on those logits riding too (vmlmf_ce): its
+    // loss is the 5th output, the logits' gradient for d(loss) = 1 is kept for the backward
     Tensor head_w = head_w_o.has_value() ? head_w_o->contiguous() : Tensor();
     Tensor head_b = head_b_o.has_value() ? head_b_o->contiguous() : Tensor();
     if (head_w.defined()) require_hip_f32(head_w, "head weight");
@@ -135,7 +139,21 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       hd.classes = (int)head_w.size(0), hd.weight = head_w.data_ptr<float>(), hd.bias = cptr(head_b), hd.logits = logits.data_ptr<float>();
     }
     vmlmf_extra ex;
-    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = head_w.defined() ? &hd : nullptr;
+    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = head_w.defined() ? &hd : nullptr, ex.ce = nullptr;
+    Tensor stats, dz_unit, target;
+    vmlmf_ce ce;
+    memset(&ce, 0, sizeof(ce));
+    if (target_o.has_value()) {
+      TORCH_CHECK(head_w.defined() && ticket_o.has_value(), "vmlmf_amd: a criterion rides on the classifier's logits (head)");
+      target = target_o->contiguous();
+      TORCH_CHECK(target.scalar_type() == at::kLong && target.dim() == 1 && target.size(0) == B, "vmlmf_amd: target must be (B,) int64");
+      stats = at::empty({2 + 2 * B}, x.options());   // loss | nvalid | lse[B] | rowloss[B]
+      if (training) dz_unit = at::empty_like(logits);
+      float* sp = stats.data_ptr<float>();
+      ce.target = target.data_ptr<int64_t>(), ce.ignore_index = ignore_index, ce.loss = sp, ce.nvalid = sp + 1, ce.lse = sp + 2;
+      ce.rowloss = sp + 2 + B, ce.dlogits_unit = mptr(dz_unit), ce.ticket = (uint32_t*)ticket_o->data_ptr();
+      ex.ce = &ce;
+    }
     check(vmlmf_seq_forward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),
                                cT.data_ptr<float>(), training ? reserve.data_ptr() : nullptr, ws.data_ptr(), sz.workspace_bytes,
                                stream_of(x), &ex));
@@ -149,6 +167,9 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       if (head_w.defined()) saved.push_back(head_w);
       ctx->saved_data["head"] = head_w.defined();
       ctx->saved_data["head_b"] = head_b.defined();
+      if (dz_unit.defined()) saved.push_back(dz_unit);
+      ctx->saved_data["ce"] = dz_unit.defined();
+      ctx->saved_data["unit"] = (unit_o.has_value() && unit_o->defined()) ? (int64_t)(uintptr_t)unit_o->data_ptr() : (int64_t)0;
       ctx->save_for_backward(saved);
       ctx->saved_data["np"] = (int64_t)params.size();
       ctx->saved_data["h0"] = h0.defined();
@@ -156,7 +177,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       ctx->saved_data["cfg"] = std::vector<int64_t>{variant, g, w_rank, time_major ? 1 : 0, B, T, I, H, dtype};
       ctx->saved_data["ur"] = u_ranks;
     }
-    return {y, hT, cT, logits};
+    return {y, hT, cT, logits, stats.defined() ? stats.select(0, 0) : at::empty({0}, x.options())};
   }
 
   static variable_list backward(AutogradContext* ctx, variable_list gout) {
@@ -175,6 +196,14 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     Tensor head_w = ctx->saved_data["head"].toBool() ? saved[k++] : Tensor();
     const bool has_head_b = ctx->saved_data["head_b"].toBool();
     Tensor dlogits = (head_w.defined() && gout.size() > 3 && gout[3].defined()) ? gout[3].contiguous() : Tensor();
+    if (ctx->saved_data["ce"].toBool() && gout.size() > 4 && gout[4].defined()) {
+      // the criterion's share of d(logits): what the forward launch wrote for d(loss) = 1 - as it is when the incoming gradient
+      // IS the package's constant one, scaled otherwise
+      Tensor dz = saved[k++];
+      const int64_t unit = ctx->saved_data["unit"].toInt();
+      if (!(unit != 0 && (int64_t)(uintptr_t)gout[4].data_ptr() == unit)) dz = dz * gout[4];
+      dlogits = dlogits.defined() ? dlogits + dz : dz;
+    }
     Tensor dy = gout[0].defined() ? gout[0].contiguous() : Tensor();
     Tensor dhT = gout[1].defined() ? gout[1].contiguous() : Tensor();
     Tensor dcT = gout[2].defined() ? gout[2].contiguous() : Tensor();
@@ -215,7 +244,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
     }
     vmlmf_extra ex;
-    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = dlogits.defined() ? &hd : nullptr;
+    ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = dlogits.defined() ? &hd : nullptr, ex.ce = nullptr;
     check(vmlmf_seq_backward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(),
                                 cptr(dy), cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(),
                                 sz.workspace_bytes, stream_of(x), &ex));
@@ -224,6 +253,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
     for (int i = 0; i < 8; ++i) out.push_back(Tensor());   // the integer configuration and the kept parameter images
     out.push_back(dW);                                     // head weight, head bias
     out.push_back(db);
+    for (int i = 0; i < 4; ++i) out.push_back(Tensor());   // target, ignore_index, unit, ticket
     return out;
   }
 };
@@ -239,8 +269,26 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> sequence(const Tensor& x, const c10::
   for (const auto& p : params) training = training || p.requires_grad();
   training = training || (head_w.has_value() && head_w->requires_grad()) || (head_b.has_value() && head_b->requires_grad());
   training = training && at::GradMode::is_enabled();
-  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed, head_w, head_b);
+  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed, head_w, head_b,
+                          c10::optional<Tensor>(), (int64_t)-100, c10::optional<Tensor>(), c10::optional<Tensor>());
   return {out[0], out[1], out[2], out[3]};
+}
+
+// the same layer with the criterion of the reference's loop riding on its classifier (vmlmf_ce): y, hT, cT, logits, loss
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> sequence_loss(const Tensor& x, const c10::optional<Tensor>& h0,
+                                                                 const c10::optional<Tensor>& c0, at::TensorList params, int64_t variant,
+                                                                 int64_t g, int64_t w_rank, at::IntArrayRef u_ranks, bool time_major,
+                                                                 int64_t dtype, const c10::optional<Tensor>& packed, const Tensor& head_w,
+                                                                 const c10::optional<Tensor>& head_b, const Tensor& target,
+                                                                 int64_t ignore_index, const Tensor& unit, const Tensor& ticket) {
+  bool training = x.requires_grad() || (h0.has_value() && h0->requires_grad()) || (c0.has_value() && c0->requires_grad());
+  for (const auto& p : params) training = training || p.requires_grad();
+  training = training || head_w.requires_grad() || (head_b.has_value() && head_b->requires_grad());
+  training = training && at::GradMode::is_enabled();
+  auto out = SeqFn::apply(x, h0, c0, params, variant, g, w_rank, u_ranks.vec(), time_major, training, dtype, packed,
+                          c10::optional<Tensor>(head_w), head_b, c10::optional<Tensor>(target), ignore_index, c10::optional<Tensor>(unit),
+                          c10::optional<Tensor>(ticket));
+  return {out[0], out[1], out[2], out[3], out[4]};
 }
 
 // ---- stacked layers: one wavefront launch per direction (C ABI 7: vmlmf_stack_*) ------------------------------------
@@ -482,6 +530,7 @@ Tensor cross_entropy(const Tensor& logits, const Tensor& target, int64_t ignore_
 
 TORCH_LIBRARY(vmlmf, m) {
   m.def("sequence(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("sequence_loss(Tensor x, Tensor? h0, Tensor? c0, Tensor[] params, int variant, int g, int w_rank, int[] u_ranks, bool time_major, int dtype, Tensor? packed, Tensor head_w, Tensor? head_b, Tensor target, int ignore_index, Tensor unit, Tensor ticket) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
   m.def("stack(Tensor x, Tensor[] params, int L, int variant, int w_rank, int[] u_ranks, int g, bool time_major, Tensor? head_w, Tensor? head_b) -> (Tensor, Tensor, Tensor, Tensor)");
   m.def("head_linear(Tensor h, Tensor weight, Tensor? bias) -> Tensor");
   m.def("cross_entropy(Tensor logits, Tensor target, int ignore_index, Tensor unit) -> Tensor");
@@ -490,6 +539,7 @@ TORCH_LIBRARY(vmlmf, m) {
 // registered for every dispatch key that reaches them: the functions build their own autograd nodes
 TORCH_LIBRARY_IMPL(vmlmf, CompositeImplicitAutograd, m) {
   m.impl("sequence", sequence);
+  m.impl("sequence_loss", sequence_loss);
   m.impl("stack", stack);
   m.impl("head_linear", head_linear);
   m.impl("cross_entropy", cross_entropy);

@@ -193,12 +193,6 @@ const int g_wride_k = env_pos("VMLMF_WRIDE_K", 32);
 const int g_wride_maxb = env_pos("VMLMF_WRIDE_MAXB", 64);   // round 3, rec3_bwd_kernel rows (61 us alone): ride on / off at H = 180, T = 128: B 32 0.158 / 0.165 ms, 64 0.160 / 0.173, 72 0.185 / 0.178, 80 0.187 / 0.177, 96 0.192 / 0.181 (the faster rows outrun the workers once fewer than ~180 CUs are left for them; round 2, slower rows: rode up to 96)
 const int g_wride_lag = env_pos("VMLMF_WRIDE_LAG", 3);
 const int g_wride_rc = env_pos("VMLMF_WRIDE_RC", 32);
-// experiments (bits): 1 = the workers leave at once, 2 = a progress word every step
-#ifdef VMLMF_EXPERIMENTS   // (builds with -DVMLMF_EXPERIMENTS only: a switch that yields wrong results is not in the product library)
-const int g_wride_dry = env_pos("VMLMF_WRIDE_DRY", 0);
-#else
-const int g_wride_dry = 0;
-#endif
 // looks a riding worker takes at the progress words before it gives up; vmlmf_tune("test_wride_spin", n) shortens it so that
 // tests can provoke the failure path (NaN gradients + VMLMF_E_PROTOCOL) on purpose
 int g_cus[MAX_DEV] = {0};   // compute units of the device (hipDeviceProp_t::multiProcessorCount), looked up once
@@ -231,14 +225,9 @@ int g_rec3 = []() { const char* e = getenv("VMLMF_REC3"); return e ? atoi(e) : 6
 // weight-gradient launch): VMLMF_INROW / vmlmf_tune("inrow", v): 0 = never, 1 = wherever it covers the layer, -1 = automatic
 // (batches beyond the riding workers' range)
 int g_inrow = []() { const char* e = getenv("VMLMF_INROW"); return e ? atoi(e) : -1; }();
-// batch rows per workgroup of that kernel: 1 (default), or 2 = two rows' recurrences side by side with ONE set of accumulators (an
-// MFMA then contracts the two rows of a step).  Built for batches beyond the CU count, parity-green, and measured SLOWER than two
-// rounds of one-row workgroups: B = 512 backward 228 vs 175 us, 384: 226 vs 171, 300: 224 vs 170 (tools/sessions/r04h.sh) - three
-// waves per SIMD at 168 registers with spills, twelve waves at every barrier.  VMLMF_INROW_ROWS / vmlmf_tune("inrow_rows", 2) selects it.
 // wgrad_ring_kernel for the weight gradients of large layers: -1 automatic (the step-wise / clustered layers), 0 never, 1 wherever
 // it applies (VMLMF_WRING / vmlmf_tune("wring", v))
 int g_wring = []() { const char* e = getenv("VMLMF_WRING"); return e ? atoi(e) : -1; }();
-int g_inrow_rows = []() { const char* e = getenv("VMLMF_INROW_ROWS"); return e ? atoi(e) : 1; }();
 
 // ---- geometry ----
 int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
@@ -413,7 +402,6 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   {
     long long blocks = g.nchunk;
     if (!g.generic && !g.rb && rec4_bwd_supported(g) && g.nwg > blocks) blocks = g.nwg;
-    if (g.rb > 1 && q.nrb > blocks) blocks = q.nrb;   // rb_bwd_kernel's own partial blocks, one per row block
     L.b_wpart = o, o += align64(blocks * g.PCH);
   }
   L.b_cgrad = o, o += align64((long long)g.NA * g.NT + (g.I > g.H ? (long long)g.I * g.KX : 0));   // + dU_x by input when I > H
@@ -506,43 +494,33 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
   if (K < 4) return;
   w->K = K;
   w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
-  w->dry = g_wride_dry;
   w->spin = (unsigned)g_wride_spin;
   w->status = status_word(s);
-  if (g_wride_dry & 1) {   // a timing experiment must not pass for a result
-    static bool told = false;
-    if (!told) fprintf(stderr, "vmlmf: VMLMF_WRIDE_DRY=1 - the weight-gradient workers leave at once, parameter gradients are NOT computed\n");
-    told = true;
-  }
 }
 
 static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
                          const float* h0, const float* rs, float* ws, const HeadBwd& hb, hipStream_t s, const WRide* ride = nullptr,
-                         const int inrow_blocks = 0, const int rbwg_blocks = 0) {
+                         const int inrow_blocks = 0) {
   int rc;
-  WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
+  const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
   const bool rode = ride != nullptr && ride->K > 0;
-  VGeo gw = g;
-  if (rbwg_blocks > 0) {   // only x^T dqx is left to this launch; its chunks are the row blocks' partial blocks
-    wh.only3 = 1;
-    gw.nchunk = rbwg_blocks;
-    gw.RC2 = (int)(((long long)g.T * g.B + rbwg_blocks - 1) / rbwg_blocks);
-  }
   int ring_nc[3] = {0, 0, 0};
   if (!rode && inrow_blocks == 0) {
     Scope sc(5, s);
     // large layers: operands through an LDS ring, long chunks (vmlmf_wgrad_ring.hip); -1: where it was measured faster
-    const bool ring = rbwg_blocks == 0 && g_wring != 0 && wgrad_ring_ok(g) && (g_wring > 0 || (g.generic && (long long)g.T * g.B >= 1024));
-    if (ring) {
-      if ((rc = hip_fail(launch_wgrad_ring(gw, wh, device_cus(), ring_nc, s), "wgrad (ring)")) != 0) return rc;
-    } else if ((rc = hip_fail(launch_wgrad_h(gw, wh, s), "wgrad")) != 0) return rc;
+    const bool ring = g_wring != 0 && wgrad_ring_ok(g) && (g_wring > 0 || (g.generic && (long long)g.T * g.B >= 1024));
+    int rr = ring ? launch_wgrad_ring(g, wh, device_cus(), ring_nc, s) : -3;
+    if (rr == -3) {   // not taken, or no instantiation / no LDS for it on this device: the stand-alone products, one chunking for all
+      ring_nc[0] = ring_nc[1] = ring_nc[2] = 0;
+      rr = launch_wgrad_h(g, wh, s);
+    }
+    if ((rc = hip_fail(rr, "wgrad")) != 0) return rc;
   }
   {
     Scope sc(6, s);
     VGeo gr_ = g;
     if (rode) gr_.nchunk = ride->K;   // one partial block per worker index; the progress words go back to zero here
     if (inrow_blocks > 0) gr_.nchunk = inrow_blocks;   // one partial block per workgroup of rec4_bwd_kernel
-    if (rbwg_blocks > 0) gr_.nchunk = rbwg_blocks;     // one per row block of rb_bwd_kernel
     if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s,
                                      ReduceCounts{{ring_nc[0], ring_nc[1], ring_nc[2]}}), "reduce")) != 0) return rc;
   }
@@ -686,7 +664,7 @@ int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const f
                              const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                              size_t workspace_bytes, void* stream, const void* packed) {
   vmlmf_extra ex;
-  ex.packed = packed, ex.head = nullptr;
+  ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_forward_ex(d, p, x, h0, c0, y, hT, cT, reserve, workspace, workspace_bytes, stream, &ex);
 }
 
@@ -715,6 +693,19 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   // their recurrence (same values up to summation order)
   const bool head_inside = head != nullptr && !g.rb && !g.generic;
   if (head != nullptr && !head_inside && hT == nullptr) return fail(VMLMF_E_BADARG, "head on this layer needs the hT output");
+  const vmlmf_ce* ce = ex != nullptr ? ex->ce : nullptr;
+  if (ce != nullptr) {
+    if (head == nullptr) return fail(VMLMF_E_BADARG, "ce: the criterion rides on the classifier's logits (extra.head)");
+    if (!ce->target || !ce->loss || !ce->nvalid || !ce->lse || !ce->rowloss || !ce->ticket) return fail(VMLMF_E_BADARG, "ce: null pointer");
+  }
+  // the criterion behind a classifier that is a launch of its own: a launch too (same values up to the mean's summation order)
+  auto ce_after = [&]() -> int {
+    if (ce == nullptr) return 0;
+    Scope sc(10, (hipStream_t)stream);
+    const hipError_t e = launch_ce_fwd(g.B, head->classes, head->logits, (const long long*)ce->target, (long long)ce->ignore_index, ce->loss,
+                                       ce->lse, ce->nvalid, ce->dlogits_unit, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail((int)e, "ce_fwd");
+  };
   const VPack P = vg_pack_layout(g, q.total);
   const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.f_total * sizeof(float))
@@ -736,12 +727,10 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   }
   // narrow-input layers compute the x-projection inside rec_fwd_kernel (VMLMF_XWAVE=0: always the separate launch)
   const bool xwave = g_xwave && vg_xwave_ok(g);
-  // clustered layers with one tile per wave form the x side inside rb_fwd_kernel (from x and qx): only qx is produced here
-  const bool rbx = g.rb && g.generic && rb_xfold_ok(g, q);
   float* const qxbuf = g.training ? rs + L.r_qx : (g.generic ? ws + L.f_qx : nullptr);
   if (!xwave) {
     Scope sc(1, s);
-    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, qxbuf, s, rbx), "xproj")) != 0)
+    if ((rc = hip_fail(launch_xproj(g, P, pack, x, gx, qxbuf, s), "xproj")) != 0)
       return rc;
   }
   if (g.rb) {
@@ -756,7 +745,6 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
     io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word(s);
-    io.x = x, io.qx = qxbuf, io.EXT = pack + P.EXT, io.BBT = pack + P.BBT, io.xfold = rbx ? 1 : 0;
     {
       Scope sc(2, s);
       if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
@@ -766,7 +754,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
       const hipError_t e = launch_head_fwd(g.B, g.H, head->classes, hT, g.H, head->weight, head->bias, head->logits, s);
       if (e != hipSuccess) return hip_fail((int)e, "head_fwd");
     }
-    return 0;
+    return ce_after();
   }
   if (g.generic) {
     GenericBuf w;
@@ -791,7 +779,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
       const hipError_t e = launch_head_fwd(g.B, g.H, head->classes, hT, g.H, head->weight, head->bias, head->logits, s);
       if (e != hipSuccess) return hip_fail((int)e, "head_fwd");
     }
-    return 0;
+    return ce_after();
   }
   FwdArgs a;
   a.gx = gx, a.VE = pack + P.VE, a.UR = pack + P.UR, a.EH = pack + P.EH, a.h0 = h0, a.c0 = c0;
@@ -803,6 +791,11 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   xw.x = x, xw.UXP = pack + P.UXP, xw.WXD = pack + P.WXD, xw.BBT = pack + P.BBT;
   memset(&xw.hd, 0, sizeof(xw.hd));
   if (head_inside) xw.hd.W = head->weight, xw.hd.bias = head->bias, xw.hd.logits = head->logits, xw.hd.C = head->classes;
+  memset(&xw.ce, 0, sizeof(xw.ce));
+  if (head_inside && ce != nullptr && g.R == 1) {   // one batch row per workgroup: the row's terms are workgroup-local
+    xw.ce.tgt = (const long long*)ce->target, xw.ce.ignore = (long long)ce->ignore_index, xw.ce.loss = ce->loss, xw.ce.nvalid = ce->nvalid;
+    xw.ce.lse = ce->lse, xw.ce.dz = ce->dlogits_unit, xw.ce.rowloss = ce->rowloss, xw.ce.ticket = ce->ticket;
+  }
   a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
   a.prog = g.training ? reinterpret_cast<unsigned*>(rs + L.r_prog) : nullptr;
   {
@@ -828,7 +821,7 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
                               const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
                               const void* packed) {
   vmlmf_extra ex;
-  ex.packed = packed, ex.head = nullptr;
+  ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_backward_ex(d, p, x, h0, c0, y, reserve, dy, dhT, dcT, dx, dh0, dc0, gr, workspace, workspace_bytes, stream, &ex);
 }
 
@@ -877,8 +870,6 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   WRide ride;
   memset(&ride, 0, sizeof(ride));
   bool inrow = false;
-  int inrow_rows = 1;
-  int rbwg_blocks = 0;   // > 0: rb_bwd_kernel formed the weight gradients itself, one partial block per row block
   const float* pack = rs + L.r_pack;
   if (packed != nullptr) {   // the image the matching forward was given
     if (g.generic) return fail(VMLMF_E_UNSUPPORTED, "kept parameter images: not for the step-wise / clustered layers");
@@ -891,10 +882,6 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
     io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
     io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word(s);
-    if (rb_wgrad_ok(g, q)) {   // the weight-gradient products inside the launch, in the shadow of the cluster exchange
-      io.wgrad = 1, rbwg_blocks = q.nrb;
-      io.x = x, io.qx = rs + L.r_qx, io.wy = y, io.wh0 = h0, io.wQs = rs + L.r_Qs, io.wP = ws + L.b_wpart;
-    }
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
@@ -938,7 +925,6 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   // batches beyond the riding workers' range (up to there the idle CUs form the products for free)
   inrow = g_inrow != 0 && dx == nullptr && rec4_bwd_supported(g) && (g_inrow > 0 || g.B > g_wride_maxb);
   if (inrow) {
-    inrow_rows = (g_inrow_rows == 2 && rec4_bwd_rows(g, 0) == 2) ? 2 : 1;
     const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
     ride.a.x = wh.x, ride.a.y = wh.y, ride.a.h0 = wh.h0, ride.a.Qs = wh.Qs, ride.a.P = wh.wpart;
   } else {
@@ -948,7 +934,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   {
     Scope sc(3, s);
     if (inrow) {
-      if ((rc = hip_fail(launch_rec4_bwd(g, a, inrow_rows, s), "rec4_bwd")) != 0) return rc;
+      if ((rc = hip_fail(launch_rec4_bwd(g, a, s), "rec4_bwd")) != 0) return rc;
     } else if ((g_rec3 & 2) && rec3_bwd_supported(g)) {
       if ((rc = hip_fail(launch_rec3_bwd(g, a, s), "rec3_bwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_bwd(g, a, s), "rec_bwd")) != 0) return rc;
@@ -961,7 +947,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     if ((rc = hip_fail(launch_wgrad_x(g, wx, s), "dqx_dx")) != 0) return rc;
   }
   }  // persistent path
-  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? (g.B + inrow_rows - 1) / inrow_rows : 0, rbwg_blocks)) != 0) return rc;
+  if ((rc = backward_tail(g, L, p, gr, x, y, h0, rs, ws, hb, s, &ride, inrow ? g.B : 0)) != 0) return rc;
   return debug_status(s);
 }
 
@@ -1230,9 +1216,6 @@ int vmlmf_tune(const char* key, int value) {
     unsigned* hw = vmlmf_health_word_if_any();
     if (hw != nullptr && hipMemset(hw, 0, sizeof(unsigned)) != hipSuccess) (void)hipGetLastError();
   }
-  else if (k == "inrow_rows") g_inrow_rows = value == 2 ? 2 : 1;
-  else if (k == "rb_xfold") rb_set_xfold(value);
-  else if (k == "rb_wgrad") rb_set_wgrad(value);
   else if (k == "wring") g_wring = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;

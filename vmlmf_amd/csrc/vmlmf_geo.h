@@ -48,7 +48,6 @@ struct RbGeo {
   int mlist[2][5];              // per group: the M-tiles of the padded rank space its units couple to
   unsigned tgcode;              // four bits per M-tile m: 1 + the one group whose units feed it in the forward reduce, 0: several / all
   long long UA, VA, VB, UB, total;   // float offsets of the A-operand images inside the RB region of PACK
-  long long VXA;                     // x-side expansion image (V_x as A operand: rb_fwd_kernel's x-fold), inside the same region
   long long xq_floats, flag_words;   // cluster exchange scratch (S > 1)
 };
 

@@ -3,14 +3,10 @@
 #include <hip/hip_runtime.h>
 #include "vmlmf_device.h"
 
-// launch bounds of rec_fwd_kernel / rec_bwd_kernel.  (VMLMF_STW7, probe builds only: the storer as wave NW + 4, i.e. on the SIMD
-// of the loader / x-projection wave instead of compute wave 0's; measured in tools/microbench/rec_probe.hip: -1.5 us with the
-// loader, +1.8 us with the x-projection wave - not shipped.)
-#ifdef VMLMF_STW7
-#define VG_REC_BOUNDS 512
-#else
+// launch bounds of rec_fwd_kernel / rec_bwd_kernel.  (The storer as wave NW + 4, i.e. on the SIMD of the loader / x-projection
+// wave instead of compute wave 0's: -1.5 us with the loader, +1.8 us with the x-projection wave, not shipped -
+// tools/experiments/ablation_switches.patch, -DVMLMF_STW7.)
 #define VG_REC_BOUNDS (MAXT + 128)
-#endif
 
 // Classifier riding on a layer (Net.lin on the final hidden state, vmlmf.py:345,353-355): logits in the epilogue of the
 // forward recurrence, d(hT) = dlogits W in the prologue of the backward one, dW / db among finish_kernel's outputs.  C = 0: none.
@@ -37,15 +33,27 @@ struct FwdArgs {
 };
 // second argument block of rec_fwd_kernel: what its x-projection wave needs (only that wave reads it, straight
 // from the kernel-argument segment, so it costs the recurrent waves no registers)
+// Cross-entropy of the riding classifier's logits (nn.CrossEntropyLoss of the reference's loop, train.py:58-65) in the same
+// epilogue: every workgroup owns one batch row, so lse, the row's loss term and d(loss)/d(logits) = (softmax - onehot) / N are
+// row-local; the mean is a fixed-order sum by the LAST workgroup to arrive at a ticket counter (no float atomics).  tgt = NULL: none.
+struct CeFwd {
+  const long long* tgt;   // (B) class indices
+  long long ignore;       // rows with this target contribute nothing
+  float *loss, *nvalid;   // 1, 1: mean over the counted rows; their number N
+  float *lse, *dz;        // (B), (B,C): row statistics; gradient of the logits for d(loss) = 1
+  float* rowloss;         // (B) the rows' loss terms (what the last workgroup sums)
+  unsigned* ticket;       // one word, zero between launches (the last workgroup puts it back)
+};
 struct XwArgs {
   const float *x, *UXP, *WXD, *BBT;
   HeadFwd hd;   // read from the kernel-argument segment by the epilogue only
+  CeFwd ce;     // the same
 };
 // operands of the weight-gradient products (vmlmf_atb.inc)
 struct AtbArgs {
   const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
   float* P;
-  int only3, pad;   // only3: the launch carries the x^T dqx tasks alone (the other products were formed inside rb_bwd_kernel)
+  int pad0, pad;
 };
 // weight-gradient workers riding on rec_bwd_kernel's launch (vmlmf_atb.inc): K workers per task, chunks of S rows (t,b),
 // ntg workgroups per worker index; prog = one progress word per batch row (zero between launches)
@@ -61,8 +69,7 @@ struct WRide {
   AtbArgs a;
   unsigned* prog;
   int K, S, ntg, tasks;
-  int lag, dry;   // lag: segments a progress word trails the stores it covers; dry (VMLMF_EXPERIMENTS builds only): the workers leave
-                  // at once (timing experiments); dry bit 1: a progress word every segment instead of every other one
+  int lag, pad;   // lag: segments a progress word trails the stores it covers (a word is published every other segment)
   unsigned spin;  // looks at the progress words before a worker gives up (WR_SPIN; vmlmf_tune("test_wride_spin") shortens it)
   unsigned* status;   // host-visible status word (vmlmf_api.hip): VMLMF_ST_WRIDE is stored there when a worker gives up
 };
@@ -81,7 +88,6 @@ struct WgxArgs {
 struct WghArgs {
   const float *dpre, *x, *y, *h0, *qx, *dqx, *Qs, *dQs;
   float* wpart;
-  int only3 = 0;
 };
 
 // buffers of the step-wise path (vmlmf_generic.hip)
@@ -112,23 +118,8 @@ struct RbIo {
   float* xq;        // cluster exchange tiles (S > 1)
   unsigned* flag;   // cluster epoch words + error word
   unsigned* status; // host-visible status word (or NULL)
-  // x-fold (rb_xfold_ok): the forward forms the x-side pre-activations itself from x, qx = x U_x and the V_x image; gx is not read
-  const float *x, *qx, *EXT, *BBT;
-  int xfold;
-  // weight gradients inside the clustered backward (rb_wgrad_ok): operands of the products and the partial blocks (one per row block)
-  const float *wy, *wh0, *wQs;
-  float* wP;
-  int wgrad;
   int flags_zeroed;   // forward: rb_pack_kernel of this call has zeroed the epoch words (no memset node)
 };
-// the clustered backward can form dpre^T [qx | Q], h^T dQ and the element sums itself, in the shadow of its cluster exchange
-// (accumulator waves beside the compute waves): one tile per wave, fp32
-bool rb_wgrad_ok(const VGeo& g, const RbGeo& q);
-void rb_set_wgrad(int on);
-// the clustered forward can form the x side of its pre-activations in-kernel (a third MFMA product, K = the padded x rank) instead
-// of reading the (T, B, 4H) tensor xexp_mfma_kernel would write: one tile per wave, fp32
-bool rb_xfold_ok(const VGeo& g, const RbGeo& q);
-void rb_set_xfold(int on);
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
 bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags = nullptr);
@@ -139,7 +130,7 @@ int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 // instantiation covers the geometry
 int launch_pack(const VGeo& g, const RefP& p, const VPack& L, float* pack, hipStream_t s);
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
-                 hipStream_t s, bool qx_only = false);   // qx_only: the consumer forms the expansion itself (rb x-fold)
+                 hipStream_t s);
 int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 // third form of the recurrent kernels (vmlmf_rec3.inc): one-group layers, padded hidden rank <= 16, <= 3 waves of units; the
@@ -151,8 +142,7 @@ int launch_rec3_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 // fourth form of the backward (vmlmf_rec4.inc): rec3_bwd_kernel's layers with the x-fold; the weight gradients are formed inside
 // the rows' workgroups (a.wr.a: operands and the partial blocks, one per workgroup; a.wr.K = 0), no dpre / dQ is written
 bool rec4_bwd_supported(const VGeo& g);
-int rec4_bwd_rows(const VGeo& g, int cus);   // batch rows per workgroup (1, or 2 with more rows than CUs): ceil(B / rows) workgroups / partial blocks
-int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, int rows, hipStream_t s);
+int launch_rec4_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 int launch_wgrad_x(const VGeo& g, const WgxArgs& a, hipStream_t s);
 int launch_wgrad_h(const VGeo& g, const WghArgs& a, hipStream_t s);
 bool wgrad_ring_ok(const VGeo& g);   // vmlmf_wgrad_ring.hip: the same products for large layers, operands through an LDS ring

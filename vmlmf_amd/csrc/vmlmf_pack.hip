@@ -569,7 +569,7 @@ __global__ void __launch_bounds__(256) xexp_mfma_kernel(VGeo g, const float* __r
 }
 
 int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* x, float* gx, float* qx,
-                 hipStream_t s, bool qx_only) {
+                 hipStream_t s) {
   const int TBp = g.T * g.Bp;
   // rows per workgroup: 4 for short sequences of rows (config C, 3072 rows: 0.2390 ms per step against 0.2426 with 8 and
   // 0.2565 with 16), 8 otherwise (8192 rows: 15.5 us against 19.1 with 4); VMLMF_XR = 4 / 8 / 16 overrides (A/B runs)
@@ -597,7 +597,7 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
   static const bool xexp_on = []() { const char* e = getenv("VMLMF_XEXP"); return e == nullptr || e[0] != '0'; }();
   const bool xexp = xexp_on && g.generic && !g.bf && g.Bp == g.B && qx != nullptr;
   float* const gx_final = gx;
-  if (xexp || qx_only) gx = nullptr;
+  if (xexp) gx = nullptr;
   if (xexp && g.time_major && g.I >= 256 && g.KX % 16 == 0) {   // qx as a skinny MFMA product (rows of x contiguous in (t, b) order)
     const int rc = generic_qx(g, x, uxp, qx, s);
     if (rc != 0) return rc;
@@ -611,7 +611,7 @@ int launch_xproj(const VGeo& g, const VPack& L, const float* pack, const float* 
       return -3;
   }
 #undef VX_CASE
-  if (xexp && !qx_only) {
+  if (xexp) {
     const hipError_t e0 = hipGetLastError();
     if (e0 != hipSuccess) return (int)e0;
     const dim3 grid2((unsigned)(((long long)g.T * g.B + 63) / 64 * (4 * g.NT / 64)));

@@ -48,11 +48,6 @@ __device__ inline float rb_udz(const VGeo& g, const RefP& p, int row, int slot) 
   const int dest = (n / g.Hg - s + g.G) % g.G;
   return dest == j ? ref_uc(g, p, n, rr) : 0.f;
 }
-__device__ inline float rb_vx(const VGeo& g, const RefP& p, int slot, int k, int r) {
-  int n;
-  if (!vg_slot_unit(g, slot, n) || r >= g.KX) return 0.f;
-  return ref_vx(g, p, n, k, r);
-}
 __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int rr) {
   int n;
   if (!vg_slot_unit(g, slot, n) || rr >= g.KH) return 0.f;
@@ -65,8 +60,6 @@ __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int
 //   VA[tv][k][s4]     expand (fwd):   unit c of the tile, gate k     x  rank 4 s4 + kq
 //   VB[tv][k][mv][r]  reduce (bwd):   rank 16 mv + pi(c)             x  (unit 4 kq + r, gate k)
 //   UB[tv][m][r]      expand (bwd):   unit c of the tile             x  row 16 m + 4 r + kq of the padded rank space
-//   VXA[tv][k][s4]    x side (fwd):   unit c of the tile, gate k     x  x-rank 4 s4 + kq   (as VA: contraction step s4 covers the
-//                                     contiguous ranks 4 s4 .. 4 s4 + 3, so a width that is not a multiple of 16 skips its padding)
 // ---------------------------------------------------------------------------------------------------
 // `flags` (or NULL): the cluster's epoch words of the forward launch behind this one, zeroed here instead of by a memset node of
 // their own (a 5 us launch for 1 KB)
@@ -77,8 +70,7 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
   // version of this kernel took 290 us at the PTB shape, 0.5 M elements)
   const int NTV = g.G * q.TPGV, KS = g.KH / 4, NP = g.NP, NMT = q.NMT;
   const int nUA = NTV * NMT * 4 * 64, nVA = NTV * 4 * KS * 64, nVB = NTV * 4 * NP * 4 * 64;
-  const int KSX = g.KX / 4, nVXA = NTV * 4 * KSX * 64;
-  const int total = 2 * nUA + nVA + nVB + nVXA;
+  const int total = 2 * nUA + nVA + nVB;
   const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
   if (e >= total) return;
   const int lane = e & 63, c = lane & 15, kq = lane >> 4;
@@ -105,14 +97,8 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
     const int k = j2 & 3, tv = j2 >> 2;
     rb_tile(g, q, tv, grp, sb, n0);
     out[q.VB + le] = rb_vc(g, p, sb + 4 * kq + r, k, 16 * mv + rb_pi(c));
-  } else if ((le -= nVB) >= nUA) {      // VXA
-    le -= nUA;
-    int j = le >> 6;
-    const int j2 = j / KSX, s4 = j - j2 * KSX;
-    const int k = j2 & 3, tv = j2 >> 2;
-    rb_tile(g, q, tv, grp, sb, n0);
-    out[q.VXA + le] = rb_vx(g, p, sb + c, k, 4 * s4 + kq);
   } else {                              // UB
+    le -= nVB;
     int j = le >> 6;
     const int r = j & 3;
     j >>= 2;
@@ -219,45 +205,12 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
   q.VA = take(NTV * 4 * KS * 64);
   q.VB = take(NTV * 4 * g.NP * 4 * 64);
   q.UB = take(NTV * q.NMT * 4 * 64);
-  q.VXA = take(NTV * 4 * (g.KX / 4) * 64);
   q.total = o;
   q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * q.NMT * 256 : 0;
   q.flag_words = S > 1 ? (long long)q.nrb * S * 32 + 64 : 0;   // (vmlmf_rb.inc: RB_FLAG_STRIDE)
   if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G, g.bf != 0)) return false;
   *out = q;
   return true;
-}
-
-// VMLMF_RB_XFOLD=1: the clustered forward forms the x-side pre-activations itself (rb_fwd_kernel<..., XF>).  Built for verdict r3
-// item 3, parity-green (tests/test_gpu_rb.py runs both forms), and NOT the default: measured on MI355X it changes nothing - config E
-// layer 0.945 / 0.961 ms with it, 0.937 / 0.938 without; plain rank-32 layer 0.746 / 0.769 vs 0.743 / 0.750; the LM step 4.63 vs
-// 4.69 ms in its best form, 1.42 vs 1.40 ms at 32 rows per GPU.  The 32 extra MFMAs of a wave-step (0.43 us) and the qx / x loads
-// cost the member what the 41 KB of pre-activations did - those were prefetched a step ahead behind the exchange - and the
-// xexp_mfma_kernel launch it removes (38 us per layer) is what the extra 15 us of rb_fwd_kernel plus noise give back.  The step
-// of these kernels is the cluster exchange (5.4 of 7.5 us in round 2; 6.2 - 6.9 us per step since round 4), not their memory pipe.
-static bool g_rb_xfold = []() { const char* e = getenv("VMLMF_RB_XFOLD"); return e != nullptr && e[0] == '1'; }();
-void rb_set_xfold(int on) { g_rb_xfold = on != 0; }   // vmlmf_tune("rb_xfold", v)
-bool rb_xfold_ok(const VGeo& g, const RbGeo& q) {
-  // (full 16-row tiles only: with 8 or 4 live rows per workgroup - config E's 32 rows per GPU - the x-side MFMAs cost what they cost
-  //  for 16 rows while the pre-activation loads they replace shrink with the rows: measured 1.40 vs 1.42 ms per LM step at B = 32)
-  return g_rb_xfold && g.rb > 1 && q.S > 1 && q.MT == 1 && q.rbl == 16 && !g.bf && g.KX % 4 == 0 && g.KX <= 32 && g.Bp == g.B;
-}
-
-// VMLMF_RB_WGRAD=1 / vmlmf_tune("rb_wgrad", 1): the clustered backward forms the weight-gradient products itself, between a member's
-// publication of its partials and its wait for the others' (rb_bwd_kernel<..., WG>).  Built on the estimate that this time is idle
-// (5.4 of 7.6 us per step are the exchange), parity-green (tests/test_gpu_rb.py), and NOT the default - measured (tools/sessions/r04j.sh,
-// plain rank-32 PTB layer, same box, interleaved): layer forward + backward 0.717 / 0.721 ms with it against 0.735 / 0.746 (the
-// 120 us wgrad_mfma_kernel launch leaves, the backward launch grows by ~100 us), the LM step 4.66 / 4.69 vs 4.66 / 4.69 ms (nothing),
-// and at 32 rows per GPU 1.55 vs 1.43 ms (the products cost what they cost for 16 rows).  The wait is not idle for the wave that has
-// to issue the 64 MFMAs (0.85 us) and 26 more loads per step through the same memory pipe the gather needs.
-static bool g_rb_wgrad = []() { const char* e = getenv("VMLMF_RB_WGRAD"); return e != nullptr && e[0] == '1'; }();
-void rb_set_wgrad(int on) { g_rb_wgrad = on != 0; }
-// One-group layers with a padded rank of at most 32 (the plain PTB layer): 472 registers of the 512 a wave alone on its SIMD has.
-// The two-group flat layer of configs[4] (64 + 64 ranks: 160 accumulator registers beside 312 of recurrence state) does not fit -
-// the compiler spills 164 registers per lane into scratch, i.e. into the one memory pipe the exchange is waiting on - so it keeps
-// the batched weight-gradient kernel.
-bool rb_wgrad_ok(const VGeo& g, const RbGeo& q) {
-  return g_rb_wgrad && g.rb > 1 && q.S > 1 && q.MT == 1 && !g.bf && g.G == 1 && g.KH <= 32 && g.KX <= 32 && g.Bp == g.B;
 }
 
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags) {

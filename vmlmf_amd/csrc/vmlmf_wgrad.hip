@@ -126,11 +126,6 @@ __device__ __forceinline__ void wgrad_body(const VGeo& g, const AtbArgs& a) {
   const int MT1 = g.NT / 8, MT2 = (g.H + 31) / 32, MT3 = g.foldx ? 0 : (g.I + 31) / 32;
   constexpr int NBTM = NBT1 > NBT2 ? NBT1 : NBT2;
   float* comb = reinterpret_cast<float*>(smem4) + (size_t)slot * (NS - 1) * (16 * NBTM + 3) * 64;
-  if (a.only3) {   // the x^T dqx tasks alone (wave-uniform)
-    if (task < MT3) atb_task<3, 1, NS>(g, a, task, blockIdx.y, lane, half, comb);
-    else if (NS > 1) __syncthreads();
-    return;
-  }
   // every wave of the workgroup takes the same number of barriers: tasks past the end run an empty mode
   if (task < MT1)
     atb_task<1, NBT1, NS>(g, a, task, blockIdx.y, lane, half, comb);
@@ -298,9 +293,8 @@ int launch_wgrad_h(const VGeo& g, const WghArgs& w, hipStream_t s) {
   AtbArgs a;
   a.dpre = w.dpre, a.x = w.x, a.y = w.y, a.h0 = w.h0, a.qx = w.qx, a.dqx = w.dqx, a.Qs = w.Qs, a.dQs = w.dQs;
   a.P = w.wpart;
-  a.only3 = w.only3, a.pad = 0;
-  const int tasks = w.only3 ? (g.foldx ? 0 : (g.I + 31) / 32) : g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
-  if (tasks == 0) return 0;
+  a.pad0 = 0, a.pad = 0;
+  const int tasks = g.NT / 8 + (g.H + 31) / 32 + (g.foldx ? 0 : (g.I + 31) / 32);
   const int GK = g.G * g.KH, n1 = (g.KX + g.KH + 31) / 32, n2 = (GK + 31) / 32;   // mode 1: [qx | own vector] per (slot block, gate) task
   const dim3 grid((tasks + 3) / 4, g.nchunk);
   // two waves per task while the hand-over buffer stays small (four measured slower at the headline shape:
@@ -357,7 +351,7 @@ int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s) 
     AtbArgs& a = S.a[l];
     a.dpre = w[l].dpre, a.x = w[l].x, a.y = w[l].y, a.h0 = w[l].h0, a.qx = w[l].qx, a.dqx = w[l].dqx, a.Qs = w[l].Qs, a.dQs = w[l].dQs;
     a.P = w[l].wpart;
-    a.only3 = 0, a.pad = 0;
+    a.pad0 = 0, a.pad = 0;
     const int t = g[l].NT / 8 + (g[l].H + 31) / 32 + (g[l].foldx ? 0 : (g[l].I + 31) / 32);
     tasks = t > tasks ? t : tasks;
     if (g[l].nchunk != g[0].nchunk || g[l].KX != g[0].KX || g[l].KH != g[0].KH || g[l].G != g[0].G || g[l].flat != g[0].flat) return -3;

@@ -22,13 +22,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-// (diagnosis builds only, tools/sessions/r04m.sh: -DWR_ABL=1 no LDS reads / MFMAs, 2 no DMA inside the loop, 3 LDS reads without
-// MFMAs, 4 MFMAs on constant operands, 5 no waits / barriers, 6 / 7 / 8 only the workgroups of mode 1 / 2 / 3 work, 9 MFMAs on
-// constant operands and no DMA, 10 only the A rows are fetched, 11 barriers without the wait for the DMA, 13 every stage fetches the
-// chunk's first rows again (cache hits); results are wrong by construction)
-#ifndef WR_ABL
-#define WR_ABL 0
-#endif
+// (the diagnosis builds behind the numbers of docs/design/wgrad_ring.md - no LDS reads, no DMA, constant operands, ...:
+//  tools/experiments/ablation_switches.patch, -DWR_ABL=n)
 constexpr int WR_KR = 16;       // rows per stage
 constexpr int WR_NSTG = 4;      // ring slots
 constexpr int WR_AW = 256;      // A columns per workgroup
@@ -69,8 +64,7 @@ __device__ __forceinline__ void dma4s(const void* sbase, unsigned voff, unsigned
 }
 template <int N>
 __device__ __forceinline__ void wait_stage_and_meet() {   // all but the N youngest DMA pieces of this wave have landed; then the barrier
-  if constexpr (WR_ABL == 11) asm volatile("s_barrier" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
 // QS: floats between two rows of the Q / dQ stage image (32, 64 or 128: the smallest that holds G * KH).  Every LDS row stride is a
@@ -89,7 +83,7 @@ __device__ __forceinline__ void ring_run(const VGeo& g, const AtbArgs& a, const 
   // ---- this wave's share of a stage's DMA pieces (the same number NJ for every wave: counted waits)
   // mode 1: A rows wave, wave + 8 | h rows wave, wave + 8 | x rows wave, wave + 8 | two pieces of the rank-space rows (Q, then qx)
   // modes 2, 3: A rows 2 wave, 2 wave + 1 as four 64-column pieces each | one piece of the B rows
-  constexpr int NJ = MODE == 1 ? (WR_ABL == 10 ? 2 : 8) : 9;
+  constexpr int NJ = MODE == 1 ? 8 : 9;
   constexpr int NQP = QS / 16;                                // pieces (256 floats) of 16 Q rows
   const int s0 = tile * 64;                                   // mode 1: first thread slot of the tile
   const int grp1 = MODE == 1 ? s0 / (64 * g.W) : 0;
@@ -119,14 +113,13 @@ __device__ __forceinline__ void ring_run(const VGeo& g, const AtbArgs& a, const 
   // read up to 15 rows past theirs in the last stage of the last chunk (vmlmf_api.hip's layout keeps 16 spare rows behind each) -
   // masked at use either way.
   auto issue = [&](const int st, const int slot) __attribute__((always_inline)) {
-    const int r0 = (WR_ABL == 13 || st >= nst_i) ? row0 : row0 + st * WR_KR;   // (past the last stage: any rows)
+    const int r0 = st >= nst_i ? row0 : row0 + st * WR_KR;   // (past the last stage: any rows)
     const unsigned sb = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)slot * (WR_STAGE * 4));
     if constexpr (MODE == 1) {
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const int i = wave + 8 * j, r = r0 + i < TB ? r0 + i : TB - 1;
         dma16s(a.dpre + (size_t)r * NT4 + tile * WR_AW, vo_a, sb + (unsigned)(i * WR_AW) * 4);
-        if constexpr (WR_ABL == 10) continue;
         dma4s(hrow(r), vo_h, sb + (unsigned)(WR_H + i * 64) * 4);
         dma4s(a.x + (size_t)r * g.sxB, vo_x, sb + (unsigned)(WR_X + i * 64) * 4);
         // rank-space rows: pieces 0 .. NQP - 1 are Q, the next two qx; a wave without a piece of its own repeats piece 0
@@ -184,14 +177,6 @@ __device__ __forceinline__ void ring_run(const VGeo& g, const AtbArgs& a, const 
   auto compute = [&](const float* S, const int r0, auto special) __attribute__((always_inline)) {
     constexpr bool SP = decltype(special)::value;   // a stage with rows past the chunk's end, or rows of t = 0 without h0
     float av[8], hv[8], xv[8], bv[8][NB];
-    if constexpr (WR_ABL == 4 || WR_ABL == 9) {
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        av[u] = (float)lane, hv[u] = 1.f, xv[u] = 2.f;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) bv[u][j] = (float)(lane + j);
-      }
-    } else
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       av[u] = S[aoff + u * 2 * WR_AW];
@@ -213,10 +198,7 @@ __device__ __forceinline__ void ring_run(const VGeo& g, const AtbArgs& a, const 
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        if constexpr (WR_ABL == 3) e_b += bv[u][j];
-        else acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
-      }
+      for (int j = 0; j < NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u][j], acc[j], 0, 0, 0);
       if (MODE == 1) {
         e_h = fmaf(av[u], hv[u], e_h);
         e_x = fmaf(av[u], xv[u], e_x);
@@ -233,9 +215,9 @@ __device__ __forceinline__ void ring_run(const VGeo& g, const AtbArgs& a, const 
   int nhead = (MODE == 3 || row0 >= Bnoh) ? 0 : (Bnoh - row0 + WR_KR - 1) / WR_KR;
   nhead = nhead < nst ? nhead : nst;
   auto stage = [&](const int st, auto special) __attribute__((always_inline)) {
-    if constexpr (WR_ABL != 5) wait_stage_and_meet<NJ * (WR_NSTG - 2)>();
-    if constexpr (WR_ABL != 2 && WR_ABL != 9) issue(st + WR_NSTG - 1, (st + WR_NSTG - 1) % WR_NSTG);
-    if constexpr (WR_ABL != 1) compute(smem + (size_t)(st % WR_NSTG) * WR_STAGE, row0 + st * WR_KR, special);
+    wait_stage_and_meet<NJ * (WR_NSTG - 2)>();
+    issue(st + WR_NSTG - 1, (st + WR_NSTG - 1) % WR_NSTG);
+    compute(smem + (size_t)(st % WR_NSTG) * WR_STAGE, row0 + st * WR_KR, special);
   };
 #pragma unroll
   for (int st = 0; st < WR_NSTG - 1; ++st) issue(st, st);
@@ -295,9 +277,6 @@ __global__ void __launch_bounds__(512) wgrad_ring_kernel(VGeo g, RingArgs q) {
   const int row0 = chunk * q.rc[mode - 1];
   const int row1 = row0 + q.rc[mode - 1] < TB ? row0 + q.rc[mode - 1] : TB;
   constexpr int QS = NB2 == 1 ? 32 : (NB2 == 2 ? 64 : 128);
-  if constexpr (WR_ABL >= 6 && WR_ABL <= 8) {
-    if (mode != WR_ABL - 5) return;
-  }
   if (mode == 1) ring_run<1, NB1, QS>(g, q.a, tile, chunk, row0, row1, smem);
   else if (mode == 2) ring_run<2, NB2, QS>(g, q.a, tile, chunk, row0, row1, smem);
   else ring_run<3, 1, QS>(g, q.a, tile, chunk, row0, row1, smem);
@@ -341,11 +320,11 @@ int launch_wgrad_ring(const VGeo& g, const WghArgs& w, int cus, int nc_out[3], h
   const size_t lds = sizeof(float) * (size_t)WR_NSTG * WR_STAGE;
 #define WR_CASE(A, Bv)                                                                                                   \
   if (n1 == A && n2 == Bv) {                                                                                             \
-    static bool attr = false;                                                                                            \
-    if (!attr) {                                                                                                         \
-      if (hipFuncSetAttribute((const void*)wgrad_ring_kernel<A, Bv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
-        return -3;                                                                                                       \
-      attr = true;                                                                                                       \
+    /* (set on every launch, as rec4_bwd_launch_kh does: HIP keeps the attribute per device, a process-wide flag would skip   \
+       it on the second GPU of a process) */                                                                             \
+    if (hipFuncSetAttribute((const void*)wgrad_ring_kernel<A, Bv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) { \
+      (void)hipGetLastError();                                                                                           \
+      return -3;                                                                                                         \
     }                                                                                                                    \
     hipLaunchKernelGGL((wgrad_ring_kernel<A, Bv>), dim3(first), dim3(512), lds, s, g, q);                                \
     return (int)hipGetLastError();                                                                                       \

@@ -163,11 +163,24 @@ def _require_hip(t, what):
         raise RuntimeError(f"vmlmf_amd: {what} must be float32, got {t.dtype}")
 
 
+_TICKET = {}
+
+
+def ce_ticket(device):
+    """The ticket word of the criterion that rides on the forward launch (include/vmlmf_hip.h: vmlmf_ce.ticket): one zeroed
+    int32 per device, allocated once; every launch leaves it zero, and the launches of a device are ordered on its current stream."""
+    t = _TICKET.get(device)
+    if t is None:
+        t = _TICKET[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t
+
+
 class VmlmfSeqFn(torch.autograd.Function):
-    """y, hT, cT = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major, dtype)."""
+    """y, hT, cT, logits, loss = f(x, h0, c0, *params) for one layer.  cfg = (variant, g, w_rank, u_ranks, time_major, dtype).
+    target (with a head): mean cross-entropy of the logits against it as the fifth output (vmlmf_ce: inside the same launch)."""
 
     @staticmethod
-    def forward(ctx, cfg, packed, x, h0, c0, head_w, head_b, *params):
+    def forward(ctx, cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -205,6 +218,21 @@ class VmlmfSeqFn(torch.autograd.Function):
         ex = _lib.Extra()
         ex.packed = None if packed is None else packed.data_ptr()
         ex.head = ctypes.pointer(hd) if hw is not None else None
+        # the criterion on those logits: loss | nvalid | lse[B] | rowloss[B] in one allocation, the unit gradient of the logits beside it
+        stats = dz_unit = None
+        ce = _lib.Ce()
+        if target is not None:
+            if hw is None:
+                raise RuntimeError("vmlmf_amd: a criterion rides on the classifier's logits (head)")
+            tg = target.contiguous()
+            stats = torch.empty(2 + 2 * B, device=dev, dtype=torch.float32)
+            dz_unit = torch.empty_like(logits) if training else None
+            base = stats.data_ptr()
+            ce.target, ce.ignore_index = tg.data_ptr(), int(ignore_index)
+            ce.loss, ce.nvalid, ce.lse, ce.rowloss = base, base + 4, base + 8, base + 8 + 4 * B
+            ce.dlogits_unit = None if dz_unit is None else dz_unit.data_ptr()
+            ce.ticket = ce_ticket(dev).data_ptr()
+            ex.ce = ctypes.pointer(ce)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_seq_forward_ex(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
@@ -213,13 +241,16 @@ class VmlmfSeqFn(torch.autograd.Function):
             ctx.cfg, ctx.desc, ctx.sizes = cfg, desc, sizes
             ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
             ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
+            ctx.has_ce = dz_unit is not None
             ctx.save_for_backward(x, y, reserve, *params, *([h0c] if h0 is not None else []),
-                                  *([c0c] if c0 is not None else []), *([hw] if hw is not None else []))
+                                  *([c0c] if c0 is not None else []), *([hw] if hw is not None else []),
+                                  *([dz_unit] if dz_unit is not None else []))
             ctx.nparams = len(params)
-        return y, hT, cT, logits
+        loss = stats[0] if stats is not None else torch.empty((0,), device=dev, dtype=torch.float32)
+        return y, hT, cT, logits, loss
 
     @staticmethod
-    def backward(ctx, dy, dhT, dcT, dlogits):
+    def backward(ctx, dy, dhT, dcT, dlogits, dloss):
         variant, g, w_rank, u_ranks, time_major, _ = ctx.cfg
         saved = ctx.saved_tensors
         x, y, reserve = saved[0], saved[1], saved[2]
@@ -228,12 +259,20 @@ class VmlmfSeqFn(torch.autograd.Function):
         h0 = rest.pop(0) if ctx.has_h0 else None
         c0 = rest.pop(0) if ctx.has_c0 else None
         hw = rest.pop(0) if ctx.has_head else None
+        if ctx.has_ce and dloss is not None:
+            # the criterion's share of d(logits): what the forward launch wrote for d(loss) = 1 - as it is when the incoming
+            # gradient IS the package's constant one (vmlmf_amd.unit_gradient), scaled otherwise
+            dz = rest.pop(0)
+            unit = _UNIT.get(dz.device)
+            if not (unit is not None and dloss.data_ptr() == unit.data_ptr()):
+                dz = dz * dloss
+            dlogits = dz if dlogits is None else dlogits + dz
         dev = x.device
         desc, sizes = ctx.desc, ctx.sizes
         dy = None if dy is None else dy.contiguous()
         dhT = None if dhT is None else dhT.contiguous()
         dcT = None if dcT is None else dcT.contiguous()
-        need_dx = ctx.needs_input_grad[2]   # (cfg, packed, x, h0, c0, head_w, head_b, *params)
+        need_dx = ctx.needs_input_grad[2]   # (cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, *params)
         dx = torch.empty_like(x) if need_dx else None
         B, H = y.shape[1 if time_major else 0], y.shape[2]
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
@@ -271,11 +310,11 @@ class VmlmfSeqFn(torch.autograd.Function):
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
                 _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
                 _ptr(ws), sizes.workspace_bytes, stream, ctypes.byref(ex)))
-        return (None, None, dx, dh0, dc0, dW, db) + grads
+        return (None, None, dx, dh0, dc0, dW, db, None, None) + grads
 
 
 def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", pack_cache=None,
-                   head=None):
+                   head=None, target=None, ignore_index=-100):
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
@@ -284,6 +323,8 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     tensors stay float32 - include/vmlmf_hip.h: vmlmf_desc.dtype).  Returns (y, hT, cT).
     head: (weight (C, H), bias (C) or None) of a classifier on the layer's final hidden state (Net.lin); the call then
     returns (y, hT, cT, logits) and neither the logits nor their backward cost a launch of their own on the VALU kernels.
+    target (with head): (B,) int64 class indices - the mean cross-entropy of the logits against them (nn.CrossEntropyLoss() with
+    default arguments, train.py:58-65) comes back as a fifth element, formed inside the same forward launch.
     """
     dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     packed = None
@@ -294,13 +335,18 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     ops = torch_ops()
     if ops is not None:
+        if target is not None:
+            return ops.sequence_loss(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt, packed,
+                                     head[0], head[1], target, int(ignore_index), unit_gradient(x.device), ce_ticket(x.device))
         out = ops.sequence(x, h0, c0, list(params), variant, g, int(w_rank), list(ur), bool(time_major), dt, packed,
                            None if head is None else head[0], None if head is None else head[1])
         return out if head is not None else out[:3]
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     out = VmlmfSeqFn.apply(cfg, packed, x, h0, c0, None if head is None else head[0], None if head is None else head[1],
-                           *params)
-    return out if head is not None else out[:3]
+                           target, ignore_index, *params)
+    if target is not None:
+        return out
+    return out[:4] if head is not None else out[:3]
 
 
 # ---- stacked layers: one wavefront launch per direction (C ABI 7: vmlmf_stack_*) ----------------------------------------

@@ -19,8 +19,15 @@ processes can starve the riding weight-gradient workers) leaves NaN gradients.  
 the update of such a step, so the parameters stay intact; the host reads the library's status word in front of every replay
 (a host memory read, no GPU call), and when an earlier replay failed - or the library's kernel selection changed since the
 capture (vmlmf_tune_generation) - the step is captured again: the library has switched to the stand-alone weight-gradient
-kernel by then, and the poisoned launch is not replayed any more.  `failed_steps` / `recaptures` count; the step that failed
-is lost (its update was skipped), nothing else is.
+kernel by then, and the poisoned launch is not replayed any more.  `failed_steps` / `recaptures` count.  Replays are
+asynchronous: the host learns of a failed replay when it prepares a later one, and the replays queued in between ran the same
+poisoned graph - each of their updates was skipped on the device too, so up to the queue depth of steps can be lost (their count
+is `optimizer.skipped_steps()`), never a parameter.  That protection is vmlmf_amd.optim.Adam's (guard=True, the default): another
+optimizer would apply the NaN gradients of such a step, which is why the constructor warns when it is handed one while the riding
+weight-gradient workers are on.
+
+When the criterion is the package's cross-entropy and the model offers `loss(x, target)` (vmlmf_amd.Net), the step calls that:
+the criterion then rides on the forward recurrence's launch (one launch less in each direction).
 """
 from __future__ import annotations
 
@@ -31,6 +38,7 @@ import warnings
 import torch
 
 from . import _lib
+from . import functional as _F
 from .functional import unit_gradient
 
 
@@ -52,6 +60,14 @@ class GraphedTrainStep:
             raise RuntimeError("GraphedTrainStep needs HIP tensors")
         params = [p for group in optimizer.param_groups for p in group["params"]]
         self._params = list(params)
+        # the criterion riding on the model's own launches (vmlmf_amd.Net.loss) when it is the package's cross-entropy
+        self._fused_loss = hasattr(model, "loss") and (criterion is _F.cross_entropy or isinstance(criterion, _F.CrossEntropyLoss))
+        self._ignore_index = getattr(criterion, "ignore_index", -100)
+        from .optim import Adam as _Adam
+        if not (isinstance(optimizer, _Adam) and getattr(optimizer, "_guarded", True)):
+            warnings.warn("vmlmf_amd.GraphedTrainStep: only vmlmf_amd.optim.Adam (guard=True) keeps the NaN gradients of a launch that "
+                          "gave up a bounded wait (VMLMF_E_PROTOCOL) away from the parameters inside a replayed graph; with this "
+                          "optimizer run with VMLMF_WRIDE=0 on a GPU that is shared with other processes", RuntimeWarning)
         seen = {id(p) for p in params}
         params += [p for p in model.parameters() if id(p) not in seen]
         with torch.no_grad():
@@ -95,7 +111,11 @@ class GraphedTrainStep:
 
     def _body(self, x=None, t=None):
         self.model.zero_grad(set_to_none=True)
-        loss = self.criterion(self.model(self.x if x is None else x), self.t if t is None else t)
+        xin, tin = self.x if x is None else x, self.t if t is None else t
+        if self._fused_loss:
+            loss = self.model.loss(xin, tin, ignore_index=self._ignore_index)
+        else:
+            loss = self.criterion(self.model(xin), tin)
         loss.backward(self._one if loss.dim() == 0 and loss.dtype == self._one.dtype else None)
         self.optimizer.step()
         return loss.detach()
@@ -110,7 +130,11 @@ class GraphedTrainStep:
         with _lib.on_device(self.x.device):
             rc = lib.vmlmf_check_status()
         if rc == _lib.E_PROTOCOL:
-            self.failed_steps = getattr(self, "failed_steps", 0) + 1
+            # every replay queued since the failing one was skipped on the device as well: the optimizer counted them
+            skipped = getattr(self.optimizer, "skipped_steps", None)
+            lost = int(skipped()) - getattr(self, "_skipped_seen", 0) if callable(skipped) else 1
+            self._skipped_seen = getattr(self, "_skipped_seen", 0) + max(lost, 0)
+            self.failed_steps = getattr(self, "failed_steps", 0) + max(lost, 1)
             warnings.warn("vmlmf_amd.GraphedTrainStep: " + lib.vmlmf_last_error().decode() + " - that step's update was skipped "
                           "on the device; the step is captured again without the launch that failed", RuntimeWarning)
         elif rc != 0:
