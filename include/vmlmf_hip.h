@@ -123,6 +123,8 @@ const char *vmlmf_last_error(void);
  *   "clear_health"  (any value) clear the gradient-health word: it stays set from a backward that wrote non-finite gradients until a
  *                   guarded optimizer step consumes it - a caller that handled such a step some other way says so here, or the
  *                   next guarded step is skipped once
+ *   "direct"        1 (default): layers of the V1 / V3 layouts with narrow inputs and ranks 8 / 16 build their register images inside
+ *                   the recurrent kernels' prologues from the reference layouts (no pack_kernel launch in the call); 0: always pack
  *   "wring"         the batched weight-gradient products of large layers (thread slots >= 256, fp32 tapes, time-major contiguous x / y)
  *                   with their operands streamed through an LDS ring (wgrad_ring_kernel): -1 (default) for the layers of the
  *                   step-wise / clustered recurrences with >= 1024 rows, 0 never, 1 wherever the kernel takes the layer

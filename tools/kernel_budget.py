@@ -28,8 +28,8 @@ BUDGET = {
     "void rec_fwd_kernel<16, 1, false, 256, 3, true>(": (256, 0),     # (its x-projection wave is a callee of its own: below)
     "void rec_fwd_kernel<16, 1, false, 256, 3, false>(": (128, 0),
     "void rec3_bwd_kernel<16, 0>(": (136, 0),
-    "void rec3_bwd_kernel<16, 1>(": (136, 0),
-    "void rec3_bwd_kernel<16, 2>(": (136, 0),
+    "void rec3_bwd_kernel<16, 1>(": (256, 0),      # (riding forms: one workgroup per CU by their LDS request; the direct prologue peaks at ~190)
+    "void rec3_bwd_kernel<16, 2>(": (256, 0),
     "void rec3_bwd_kernel<8, 0>(": (136, 0),
     "void rec_bwd_kernel<16, 1, false, 256, 3, 0>(": (128, 0),
     "void wf_fwd_kernel<24, 4, 1, 256>(": (168, 0),

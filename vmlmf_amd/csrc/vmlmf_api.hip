@@ -448,6 +448,24 @@ int check_pointers(const VGeo& g, const P* p, const char* what) {
 
 int check_params(const VGeo& g, const vmlmf_params* p) { return check_pointers(g, p, "params"); }
 
+// Direct mode (vmlmf_direct.inc): the recurrent kernels of a layer build their register images from the reference layouts in their
+// own prologues and pack_kernel leaves the call.  VMLMF_DIRECT=0 / vmlmf_tune("direct", 0): always pack (A/B runs).  The forward and
+// the backward of a call pair must reach the same verdict: it depends on the descriptor, the parameter addresses and the kernel
+// selection only.
+int g_direct = []() { const char* e = getenv("VMLMF_DIRECT"); return e ? atoi(e) : 1; }();
+bool uses_rec3_fwd(const VGeo& g) {
+  return g_xwave && vg_xwave_ok(g) && ((g_rec3 & 1) || ((g_rec3 & 4) && g.nwg > device_cus())) && rec3_fwd_supported(g);
+}
+bool direct_ok(const VGeo& g, const vmlmf_params* p) {
+  if (g_direct == 0 || !(g.variant == VMLMF_V1_CELL || g.variant == VMLMF_V3_LM)) return false;
+  if (g.generic || g.rb || g.bf || g.G != 1 || g.R != 1 || !g.foldx || !(g_xwave && vg_xwave_ok(g)) || uses_rec3_fwd(g)) return false;
+  if (!(g.KH == 8 || g.KH == 16) || g.ru0 != g.KH || !(g.KX == 8 || g.KX == 16) || g.rw != g.KX) return false;
+  // a training call's backward must be one of the kernels that can do the same (rec3_bwd_kernel / rec4_bwd_kernel)
+  if (g.training && !((g_rec3 & 2) && rec3_bwd_supported(g))) return false;   // (its backward: rec3_bwd_kernel / rec4_bwd_kernel)
+  const uintptr_t al = (uintptr_t)p->v_h[0] | (uintptr_t)p->u_h[0] | (uintptr_t)p->v_x | (uintptr_t)p->u_x;
+  return (al & 15u) == 0;   // rows are read as 16-byte loads
+}
+
 int hip_fail(int rc, const char* what) {
   if (rc == 0) return 0;
   if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, std::string(what) + ": no kernel instantiation for this geometry");
@@ -721,7 +739,8 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   }
   float* gx = ws + L.f_gx;
   const RefP rp = to_refp(p);
-  if (packed == nullptr) {
+  const bool direct = packed == nullptr && direct_ok(g, p);
+  if (packed == nullptr && !direct) {
     Scope sc(0, s);
     if ((rc = hip_fail(launch_pack(g, rp, P, pack, s), "pack")) != 0) return rc;
   }
@@ -797,6 +816,11 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     xw.ce.lse = ce->lse, xw.ce.dz = ce->dlogits_unit, xw.ce.rowloss = ce->rowloss, xw.ce.ticket = ce->ticket;
   }
   a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
+  xw.BH = nullptr, xw.DX = nullptr, xw.direct = 0, xw.pad = 0;
+  if (direct) {   // the reference's own tensors in the places of the images (vmlmf_direct.inc)
+    a.VE = p->v_h[0], a.UR = p->u_h[0], a.EH = p->dia_h, a.xwave = 3;
+    xw.UXP = p->u_x, xw.WXD = p->v_x, xw.BBT = p->b_x, xw.BH = p->b_h, xw.DX = p->dia_x, xw.direct = 1;
+  }
   a.prog = g.training ? reinterpret_cast<unsigned*>(rs + L.r_prog) : nullptr;
   {
     Scope sc(2, s);
@@ -931,6 +955,17 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     plan_wride(g, L, x, y, h0, rs, ws, &ride, s);
   }
   a.wr = ride;
+  const bool direct = packed == nullptr && direct_ok(g, p);   // the forward of this call packed nothing
+  if (direct) {
+    // the backward builds its own images where its workgroups have a CU each (riding workers, weight gradients in the rows'
+    // workgroups); elsewhere, and for the input's gradient (x-side images), this call packs after all
+    const bool own = inrow || ride.K > 0;
+    if (own) a.VE = p->v_h[0], a.UE = p->u_h[0], a.EH = p->dia_h, a.wr.direct = 1;
+    if (!own || !(g.foldx && dx == nullptr)) {
+      Scope sc(0, s);
+      if ((rc = hip_fail(launch_pack(g, to_refp(p), P, const_cast<float*>(pack), s), "pack")) != 0) return rc;
+    }
+  }
   {
     Scope sc(3, s);
     if (inrow) {
@@ -1217,6 +1252,7 @@ int vmlmf_tune(const char* key, int value) {
     if (hw != nullptr && hipMemset(hw, 0, sizeof(unsigned)) != hipSuccess) (void)hipGetLastError();
   }
   else if (k == "wring") g_wring = value;
+  else if (k == "direct") g_direct = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

@@ -48,6 +48,10 @@ struct XwArgs {
   const float *x, *UXP, *WXD, *BBT;
   HeadFwd hd;   // read from the kernel-argument segment by the epilogue only
   CeFwd ce;     // the same
+  // direct mode (vmlmf_direct.inc; direct != 0): UXP / WXD / BBT point at the reference's own u_x (I, rw), v_x (4H, rw), b_x (4H),
+  // and the x-projection wave also needs b_h (4H) and dia_x (1, I)
+  const float *BH, *DX;
+  int direct, pad;
 };
 // operands of the weight-gradient products (vmlmf_atb.inc)
 struct AtbArgs {
@@ -69,7 +73,9 @@ struct WRide {
   AtbArgs a;
   unsigned* prog;
   int K, S, ntg, tasks;
-  int lag, pad;   // lag: segments a progress word trails the stores it covers (a word is published every other segment)
+  int lag;        // segments a progress word trails the stores it covers (a word is published every other segment)
+  int direct;     // (of the whole BwdArgs, kept in this struct's padding) 1: VE / UE / EH are the reference's own v_h, u_h, dia_h
+                  // and the rows' compute waves build their register images themselves (vmlmf_direct.inc)
   unsigned spin;  // looks at the progress words before a worker gives up (WR_SPIN; vmlmf_tune("test_wride_spin") shortens it)
   unsigned* status;   // host-visible status word (vmlmf_api.hip): VMLMF_ST_WRIDE is stored there when a worker gives up
 };

@@ -29,6 +29,30 @@ __device__ __forceinline__ float half_wave_sum(float v) {
   return v;
 }
 
+// The rank-space dot products whose results the recurrent kernels can also form themselves (direct mode, vmlmf_direct.inc: eh and
+// the dense x-side matrix) are ONE arithmetic everywhere: the products in rank order through a chain of fused multiply-adds,
+// u[0] v[0] rounded first (dr_chain).
+template <class FU, class FV>
+__device__ __forceinline__ float chain_dot(const int nr, FU&& u, FV&& v) {
+  // lane r of the 32-lane group loads rank r (one memory latency per 32 ranks), then every lane walks the
+  // chain over the group's registers (v_readlane: both groups of the wave at once, each keeps its own)
+  const int l32 = threadIdx.x & 31;
+  const bool hi = (threadIdx.x & 32) != 0;
+  float acc = 0.f;
+  for (int r0 = 0; r0 < nr; r0 += 32) {   // (ranks beyond 32: the step-wise layers; another block of loads)
+    const int rc = r0 + l32 < nr ? r0 + l32 : nr - 1;   // clamped: unconditional loads
+    const float ul = u(rc), vl = v(rc);
+    const int n32 = nr - r0 < 32 ? nr - r0 : 32;
+    for (int r = 0; r < n32; ++r) {
+      const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ul), r)), u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ul), 32 + r));
+      const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vl), r)), v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vl), 32 + r));
+      const float uu = hi ? u1 : u0, vv = hi ? v1 : v0;
+      acc = (r0 + r == 0) ? uu * vv : fmaf(uu, vv, acc);
+    }
+  }
+  return acc;
+}
+
 // ex(n,k) = dia_x[n] - sum_r ux(n,r) vx(n,k,r), one rank per lane of a 32-lane group (vmlmf.py:102-106 hoisted)
 __device__ __forceinline__ float dot_ex(const VGeo& g, const RefP& p, int n, int k, int l32) {
   float acc = 0.f;
@@ -48,11 +72,8 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
       const int k = d / NT, slot = d - k * NT;
       int n;
       dst = L.EH + d;
-      if (vg_slot_unit(g, slot, n) && !g.novm) {
-        float acc = 0.f;
-        for (int r = l32; r < g.ru0; r += 32) acc = fmaf(ref_uc(g, p, n, r), ref_vc(g, p, n, k, r), acc);
-        v = p.dia_h[n] - half_wave_sum(acc);
-      }
+      if (vg_slot_unit(g, slot, n) && !g.novm)
+        v = p.dia_h[n] - chain_dot(g.ru0, [&](int r) { return ref_uc(g, p, n, r); }, [&](int r) { return ref_vc(g, p, n, k, r); });
     } else if ((d -= D.nEH) < D.nEXI) {   // EXI[k][slot]
       const int k = d / NT, slot = d - k * NT;
       int n;
@@ -70,9 +91,7 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
         if (nn == m && !g.novm) {
           v = p.dia_x[nn];      // diag(d_x) + (U V^T with its diagonal removed): the diagonal is d_x itself
         } else {
-          float acc = 0.f;
-          for (int r = l32; r < g.rw; r += 32) acc = fmaf(ref_ux(g, p, m, r), ref_vx(g, p, nn, kk, r), acc);
-          v = half_wave_sum(acc);
+          v = chain_dot(g.rw, [&](int r) { return ref_ux(g, p, m, r); }, [&](int r) { return ref_vx(g, p, nn, kk, r); });
         }
       }
     }
