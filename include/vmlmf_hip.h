@@ -200,8 +200,9 @@ typedef struct vmlmf_head {
 /* ABI 10: the criterion of the reference's loop (nn.CrossEntropyLoss() with default arguments on Net's output, V/src/train_test/
  * train.py:58-65) riding on the same forward launch as the classifier: the logits of a batch row never leave the workgroup that
  * formed them before the row's log-sum-exp, loss term and d(loss)/d(logits) = (softmax - onehot) / N exist; the mean over the N
- * rows whose target is not ignore_index is a fixed-order sum by the last workgroup to finish (run-to-run identical, no float
- * atomics).  Forward only, together with `head`; values as vmlmf_ce_forward's on the same logits (the mean's summation order
+ * rows whose target is not ignore_index is an integer sum of the rows' terms in fixed point (2^-29 at 64 rows: associative, so
+ * run-to-run identical whatever order the rows finish in, with one atomic per row and no pass over the rows; terms of 2048 and
+ * more are summed at 2^-10, beyond 2^36 / B the loss is +Inf, a NaN term makes it NaN).  Forward only, together with `head`; values as vmlmf_ce_forward's on the same logits (the mean's summation order
  * differs).  On the layer families whose classifier is a launch of its own (row-block, step-wise) the criterion is one too. */
 typedef struct vmlmf_ce {
   const int64_t *target;     /* (B) class indices; an index outside [0, classes) poisons the loss with NaN               */
@@ -209,9 +210,8 @@ typedef struct vmlmf_ce {
   float *loss, *nvalid;      /* 1, 1                                                                                       */
   float *lse;                /* (B)                                                                                        */
   float *dlogits_unit;       /* (B, classes) gradient of the logits for d(loss) = 1, or NULL                               */
-  float *rowloss;            /* (B) scratch: the rows' loss terms                                                          */
-  uint32_t *ticket;          /* ONE word that is zero before the first launch; every launch leaves it zero.  Launches that
-                              * share a word must be ordered on one stream                                                 */
+  uint64_t *ticket;          /* TWO 8-byte words that are zero before the first launch; every launch leaves them zero.
+                              * Launches that share them must be ordered on one stream                                     */
 } vmlmf_ce;
 typedef struct vmlmf_extra {
   const void *packed;        /* kept parameter images (vmlmf_pack_params) or NULL */

@@ -865,3 +865,30 @@ def test_criterion_riding_scales_with_a_foreign_loss_gradient_and_runs_without_g
     assert abs(float(l0) - float(la)) <= 1e-6
     t[3] = 18
     assert torch.isnan(a.loss(x, t))
+
+
+def test_criterion_riding_tiers_of_the_fixed_point_mean():
+    """The mean of the riding criterion is an integer sum (vmlmf_ce, ce_epilogue): terms below 2048 at 2^-29 (64 rows), terms of 2048
+    and more at 2^-10 through the second ticket word, beyond 2^36 / B the loss is +Inf, a NaN term makes it NaN - and the two
+    ticket words are back at zero afterwards (the next call is right again)."""
+    import vmlmf_amd
+    torch.manual_seed(13)
+    net = Net(9, layer_sizes=[64], w_rank=8, u_rank=[8], model=MyLSTM, cell=MyVMLMFCell).cuda()
+    x = torch.randn(12, 5, 9, device=DEV)
+    t = torch.randint(1, 18, (12,), device=DEV)          # never class 0
+    with torch.no_grad():
+        base = float(net.loss(x, t))
+        for bias0, kind in ((5000.0, "coarse"), (1.0e12, "inf"), (float("nan"), "nan"), (0.1, "fine")):
+            net.lin.bias[0] = bias0                        # a logit of class 0 that far above the others: every row's term ~ bias0
+            got, logits = net.loss(x, t, return_logits=True)
+            ref = torch.nn.functional.cross_entropy(logits.double().cpu(), t.cpu())
+            if kind == "coarse":
+                assert abs(float(got) - float(ref)) <= 2e-6 * float(ref), (float(got), float(ref))
+            elif kind == "inf":
+                assert torch.isinf(got) and float(got) > 0
+            elif kind == "nan":
+                assert torch.isnan(got)
+            else:
+                assert abs(float(got) - base) <= 1e-6, (float(got), base)
+    from vmlmf_amd.functional import ce_ticket
+    assert int(ce_ticket(x.device).abs().sum()) == 0

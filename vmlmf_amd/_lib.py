@@ -52,7 +52,7 @@ class Head(ctypes.Structure):
 class Ce(ctypes.Structure):
     """vmlmf_ce (ABI 10): the cross-entropy criterion riding on the classifier's logits in the forward launch."""
     _fields_ = [("target", ctypes.c_void_p), ("ignore_index", ctypes.c_int64), ("loss", ctypes.c_void_p), ("nvalid", ctypes.c_void_p),
-                ("lse", ctypes.c_void_p), ("dlogits_unit", ctypes.c_void_p), ("rowloss", ctypes.c_void_p), ("ticket", ctypes.c_void_p)]
+                ("lse", ctypes.c_void_p), ("dlogits_unit", ctypes.c_void_p), ("ticket", ctypes.c_void_p)]
 
 
 class Extra(ctypes.Structure):

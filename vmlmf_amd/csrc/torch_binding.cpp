@@ -147,11 +147,11 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       TORCH_CHECK(head_w.defined() && ticket_o.has_value(), "vmlmf_amd: a criterion rides on the classifier's logits (head)");
       target = target_o->contiguous();
       TORCH_CHECK(target.scalar_type() == at::kLong && target.dim() == 1 && target.size(0) == B, "vmlmf_amd: target must be (B,) int64");
-      stats = at::empty({2 + 2 * B}, x.options());   // loss | nvalid | lse[B] | rowloss[B]
+      stats = at::empty({2 + B}, x.options());   // loss | nvalid | lse[B]
       if (training) dz_unit = at::empty_like(logits);
       float* sp = stats.data_ptr<float>();
       ce.target = target.data_ptr<int64_t>(), ce.ignore_index = ignore_index, ce.loss = sp, ce.nvalid = sp + 1, ce.lse = sp + 2;
-      ce.rowloss = sp + 2 + B, ce.dlogits_unit = mptr(dz_unit), ce.ticket = (uint32_t*)ticket_o->data_ptr();
+      ce.dlogits_unit = mptr(dz_unit), ce.ticket = (uint64_t*)ticket_o->data_ptr();
       ex.ce = &ce;
     }
     check(vmlmf_seq_forward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), hT.data_ptr<float>(),

@@ -714,7 +714,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   const vmlmf_ce* ce = ex != nullptr ? ex->ce : nullptr;
   if (ce != nullptr) {
     if (head == nullptr) return fail(VMLMF_E_BADARG, "ce: the criterion rides on the classifier's logits (extra.head)");
-    if (!ce->target || !ce->loss || !ce->nvalid || !ce->lse || !ce->rowloss || !ce->ticket) return fail(VMLMF_E_BADARG, "ce: null pointer");
+    if (!ce->target || !ce->loss || !ce->nvalid || !ce->lse || !ce->ticket) return fail(VMLMF_E_BADARG, "ce: null pointer");
   }
   // the criterion behind a classifier that is a launch of its own: a launch too (same values up to the mean's summation order)
   auto ce_after = [&]() -> int {
@@ -811,9 +811,9 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   memset(&xw.hd, 0, sizeof(xw.hd));
   if (head_inside) xw.hd.W = head->weight, xw.hd.bias = head->bias, xw.hd.logits = head->logits, xw.hd.C = head->classes;
   memset(&xw.ce, 0, sizeof(xw.ce));
-  if (head_inside && ce != nullptr && g.R == 1) {   // one batch row per workgroup: the row's terms are workgroup-local
+  if (head_inside && ce != nullptr && g.R == 1 && g.B < 65536) {   // one batch row per workgroup: the row's terms are workgroup-local
     xw.ce.tgt = (const long long*)ce->target, xw.ce.ignore = (long long)ce->ignore_index, xw.ce.loss = ce->loss, xw.ce.nvalid = ce->nvalid;
-    xw.ce.lse = ce->lse, xw.ce.dz = ce->dlogits_unit, xw.ce.rowloss = ce->rowloss, xw.ce.ticket = ce->ticket;
+    xw.ce.lse = ce->lse, xw.ce.dz = ce->dlogits_unit, xw.ce.ticket = (unsigned long long*)ce->ticket;
   }
   a.xwave = xwave ? 1 : 0, a.qxw = g.training ? rs + L.r_qx : nullptr;
   xw.BH = nullptr, xw.DX = nullptr, xw.direct = 0, xw.pad = 0;
@@ -828,6 +828,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
       if ((rc = hip_fail(launch_rec3_fwd(g, a, xw, s), "rec3_fwd")) != 0) return rc;
     } else if ((rc = hip_fail(launch_rec_fwd(g, a, xw, s), "rec_fwd")) != 0) return rc;
   }
+  if (ce != nullptr && xw.ce.tgt == nullptr && (rc = ce_after()) != 0) return rc;   // (a batch beyond the ticket's 16-bit row count)
   return debug_status(s);
 }
 

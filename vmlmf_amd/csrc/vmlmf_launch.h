@@ -35,14 +35,13 @@ struct FwdArgs {
 // from the kernel-argument segment, so it costs the recurrent waves no registers)
 // Cross-entropy of the riding classifier's logits (nn.CrossEntropyLoss of the reference's loop, train.py:58-65) in the same
 // epilogue: every workgroup owns one batch row, so lse, the row's loss term and d(loss)/d(logits) = (softmax - onehot) / N are
-// row-local; the mean is a fixed-order sum by the LAST workgroup to arrive at a ticket counter (no float atomics).  tgt = NULL: none.
+// row-local; the mean comes out of ONE integer atomic per row (count + fixed-point sum, ce_epilogue; no float atomics).  tgt = NULL: none.
 struct CeFwd {
   const long long* tgt;   // (B) class indices
   long long ignore;       // rows with this target contribute nothing
   float *loss, *nvalid;   // 1, 1: mean over the counted rows; their number N
   float *lse, *dz;        // (B), (B,C): row statistics; gradient of the logits for d(loss) = 1
-  float* rowloss;         // (B) the rows' loss terms (what the last workgroup sums)
-  unsigned* ticket;       // one word, zero between launches (the last workgroup puts it back)
+  unsigned long long* ticket;   // two 8-byte words, zero between launches (the last workgroup puts them back)
 };
 struct XwArgs {
   const float *x, *UXP, *WXD, *BBT;

@@ -31,14 +31,14 @@ __device__ __forceinline__ float half_wave_sum(float v) {
 
 // The rank-space dot products whose results the recurrent kernels can also form themselves (direct mode, vmlmf_direct.inc: eh and
 // the dense x-side matrix) are ONE arithmetic everywhere: the products in rank order through a chain of fused multiply-adds,
-// u[0] v[0] rounded first (dr_chain).
+// (dr_chain: the even and the odd ranks through a chain each, added at the end).
 template <class FU, class FV>
 __device__ __forceinline__ float chain_dot(const int nr, FU&& u, FV&& v) {
   // lane r of the 32-lane group loads rank r (one memory latency per 32 ranks), then every lane walks the
   // chain over the group's registers (v_readlane: both groups of the wave at once, each keeps its own)
   const int l32 = threadIdx.x & 31;
   const bool hi = (threadIdx.x & 32) != 0;
-  float acc = 0.f;
+  float acc = 0.f, acc1 = 0.f;   // the chains of the even and of the odd ranks (dr_chain)
   for (int r0 = 0; r0 < nr; r0 += 32) {   // (ranks beyond 32: the step-wise layers; another block of loads)
     const int rc = r0 + l32 < nr ? r0 + l32 : nr - 1;   // clamped: unconditional loads
     const float ul = u(rc), vl = v(rc);
@@ -47,9 +47,11 @@ __device__ __forceinline__ float chain_dot(const int nr, FU&& u, FV&& v) {
       const float u0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ul), r)), u1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ul), 32 + r));
       const float v0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vl), r)), v1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vl), 32 + r));
       const float uu = hi ? u1 : u0, vv = hi ? v1 : v0;
-      acc = (r0 + r == 0) ? uu * vv : fmaf(uu, vv, acc);
+      if (r & 1) acc1 = (r0 + r == 1) ? uu * vv : fmaf(uu, vv, acc1);
+      else acc = (r0 + r == 0) ? uu * vv : fmaf(uu, vv, acc);
     }
   }
+  acc += acc1;
   return acc;
 }
 

@@ -167,11 +167,11 @@ _TICKET = {}
 
 
 def ce_ticket(device):
-    """The ticket word of the criterion that rides on the forward launch (include/vmlmf_hip.h: vmlmf_ce.ticket): one zeroed
-    int32 per device, allocated once; every launch leaves it zero, and the launches of a device are ordered on its current stream."""
+    """The ticket words of the criterion that rides on the forward launch (include/vmlmf_hip.h: vmlmf_ce.ticket): two zeroed
+    int64 per device, allocated once; every launch leaves it zero, and the launches of a device are ordered on its current stream."""
     t = _TICKET.get(device)
     if t is None:
-        t = _TICKET[device] = torch.zeros(1, device=device, dtype=torch.int32)
+        t = _TICKET[device] = torch.zeros(2, device=device, dtype=torch.int64)
     return t
 
 
@@ -218,18 +218,18 @@ class VmlmfSeqFn(torch.autograd.Function):
         ex = _lib.Extra()
         ex.packed = None if packed is None else packed.data_ptr()
         ex.head = ctypes.pointer(hd) if hw is not None else None
-        # the criterion on those logits: loss | nvalid | lse[B] | rowloss[B] in one allocation, the unit gradient of the logits beside it
+        # the criterion on those logits: loss | nvalid | lse[B] in one allocation, the unit gradient of the logits beside it
         stats = dz_unit = None
         ce = _lib.Ce()
         if target is not None:
             if hw is None:
                 raise RuntimeError("vmlmf_amd: a criterion rides on the classifier's logits (head)")
             tg = target.contiguous()
-            stats = torch.empty(2 + 2 * B, device=dev, dtype=torch.float32)
+            stats = torch.empty(2 + B, device=dev, dtype=torch.float32)
             dz_unit = torch.empty_like(logits) if training else None
             base = stats.data_ptr()
             ce.target, ce.ignore_index = tg.data_ptr(), int(ignore_index)
-            ce.loss, ce.nvalid, ce.lse, ce.rowloss = base, base + 4, base + 8, base + 8 + 4 * B
+            ce.loss, ce.nvalid, ce.lse = base, base + 4, base + 8
             ce.dlogits_unit = None if dz_unit is None else dz_unit.data_ptr()
             ce.ticket = ce_ticket(dev).data_ptr()
             ex.ce = ctypes.pointer(ce)
