@@ -125,6 +125,8 @@ const char *vmlmf_last_error(void);
  *                   next guarded step is skipped once
  *   "direct"        1 (default): layers of the V1 / V3 layouts with narrow inputs and ranks 8 / 16 build their register images inside
  *                   the recurrent kernels' prologues from the reference layouts (no pack_kernel launch in the call); 0: always pack
+ *   "finish2"       1 (default): behind a backward whose weight-gradient workers rode on the recurrent launch, ONE launch sums their
+ *                   partial blocks and writes the reference-layout gradients (finish2_kernel); 0: reduce_cg_kernel + finish_kernel
  *   "wring"         the batched weight-gradient products of large layers (thread slots >= 256, fp32 tapes, time-major contiguous x / y)
  *                   with their operands streamed through an LDS ring (wgrad_ring_kernel): -1 (default) for the layers of the
  *                   step-wise / clustered recurrences with >= 1024 rows, 0 never, 1 wherever the kernel takes the layer

@@ -165,7 +165,7 @@ def test_every_documented_kernel_switch_is_accepted():
     keys = re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)
     assert {"rb", "wride", "inrow", "wring", "adam_guard"} <= set(keys), keys
     defaults = {"rb": -1, "rb_min_batch": 0, "rb_cluster": 0, "rb_rows": 0, "rec3": 6, "wride": 1, "inrow": -1, "adam_guard": 1,
-                "clear_health": 0, "wring": -1, "test_wride_spin": 0, "direct": 1}
+                "clear_health": 0, "wring": -1, "test_wride_spin": 0, "direct": 1, "finish2": 1}
     lib = _lib.lib()
     for k in keys:
         assert k in defaults, f"header documents {k}: add its default here"

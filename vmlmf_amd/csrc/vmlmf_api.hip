@@ -361,7 +361,7 @@ struct Layout {
   // forward workspace  : PACK (inference only) | gx
   long long f_pack, f_gx, f_qx, f_trash, f_Qtmp, f_P, f_ccar, f_zeros, f_part, f_xq, f_flag, f_total;
   // backward workspace : dpre | dQs | wpart | cgrad
-  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_headdh, b_total;
+  long long b_dpre, b_dQs, b_dqx, b_wpart, b_cgrad, b_trash, b_dHrec, b_ehterm, b_dcar, b_part, b_xq, b_flag, b_headdh, b_dux, b_total;
 };
 
 Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
@@ -417,6 +417,8 @@ Layout make_layout(const VGeo& g, const VPack& P, const RbGeo& q) {
   L.b_xq = o, o += align64(g.rb ? q.xq_floats : 0);
   L.b_flag = o, o += align64(g.rb ? q.flag_words : 0);
   L.b_headdh = o, o += align64((g.rb || g.generic) ? (long long)g.B * g.H : 0);   // d(hT) of a classifier on the row-block / step-wise families
+  // the riding workers' shares of d(u_x) (finish2_kernel): [worker index][task][16 x 16]
+  L.b_dux = o, o += align64((!g.generic && !g.rb && finish2_ok(g)) ? (long long)g.nchunk * (g.NT / 8) * 256 : 0);
   L.b_total = o;
   return L;
 }
@@ -453,6 +455,9 @@ int check_params(const VGeo& g, const vmlmf_params* p) { return check_pointers(g
 // the backward of a call pair must reach the same verdict: it depends on the descriptor, the parameter addresses and the kernel
 // selection only.
 int g_direct = []() { const char* e = getenv("VMLMF_DIRECT"); return e ? atoi(e) : 1; }();
+// finish2_kernel behind a backward with riding workers (one launch instead of reduce_cg_kernel + finish_kernel): VMLMF_FINISH2=0 /
+// vmlmf_tune("finish2", 0) keeps the two launches (A/B runs)
+int g_finish2 = []() { const char* e = getenv("VMLMF_FINISH2"); return e ? atoi(e) : 1; }();
 bool uses_rec3_fwd(const VGeo& g) {
   return g_xwave && vg_xwave_ok(g) && ((g_rec3 & 1) || ((g_rec3 & 4) && g.nwg > device_cus())) && rec3_fwd_supported(g);
 }
@@ -485,7 +490,7 @@ static WghArgs wgrad_args(const Layout& L, const float* x, const float* y, const
 // gradient folds into the dpre product (no dqx operand, which only exists after that launch), with few enough batch rows that
 // most of the chip is idle during the recurrence.  Fills w (K = 0: no).
 static void plan_wride(const VGeo& g, const Layout& L, const float* x, const float* y, const float* h0, const float* rs, float* ws,
-                       WRide* w, hipStream_t s) {
+                       WRide* w, hipStream_t s, const float* vx = nullptr) {
   memset(w, 0, sizeof(*w));
   const int n1 = (vg_nb1(g) + 31) / 32, n2 = (g.G * g.KH + 31) / 32;
   if (!g_wride || g_wride_tripped.load() != 0 || g.rb || g.generic || g.bf || !g.foldx || g.R != 1 || g.NT > 256 || g.B > g_wride_maxb || n1 > 2 || n2 > 2) return;
@@ -514,6 +519,9 @@ static void plan_wride(const VGeo& g, const Layout& L, const float* x, const flo
   w->lag = g_wride_lag < 8 ? g_wride_lag : 8;
   w->spin = (unsigned)g_wride_spin;
   w->status = status_word(s);
+  // one launch behind this one finishes every gradient (finish2_kernel) where it covers the layer: the workers then contract their
+  // x-fold tiles with v_x themselves
+  if (g_finish2 != 0 && finish2_ok(g) && vx != nullptr) w->dux = ws + L.b_dux, w->vx = vx;
 }
 
 static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, const vmlmf_grads* gr, const float* x, const float* y,
@@ -534,6 +542,14 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
     }
     if ((rc = hip_fail(rr, "wgrad")) != 0) return rc;
   }
+  RefG og;
+  og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
+  og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+  for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
+  if (rode && ride->dux != nullptr) {   // the riding workers left their d(u_x) shares: ONE launch sums the K blocks and finishes
+    Scope sc(7, s);
+    return hip_fail(launch_finish2(g, to_refp(p), ws + L.b_wpart, ride->dux, ride->K, og, hb, ride->prog, s, health_word(s)), "finish2");
+  }
   {
     Scope sc(6, s);
     VGeo gr_ = g;
@@ -542,10 +558,6 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
     if ((rc = hip_fail(launch_reduce(gr_, ws + L.b_wpart, ws + L.b_cgrad, rode ? ride->prog : nullptr, s,
                                      ReduceCounts{{ring_nc[0], ring_nc[1], ring_nc[2]}}), "reduce")) != 0) return rc;
   }
-  RefG og;
-  og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
-  og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
-  for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   {
     Scope sc(7, s);
     if ((rc = hip_fail(launch_finish(g, to_refp(p), ws + L.b_cgrad, og, hb, s, health_word(s)), "finish")) != 0) return rc;
@@ -953,7 +965,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     const WghArgs wh = wgrad_args(L, x, y, h0, rs, ws);
     ride.a.x = wh.x, ride.a.y = wh.y, ride.a.h0 = wh.h0, ride.a.Qs = wh.Qs, ride.a.P = wh.wpart;
   } else {
-    plan_wride(g, L, x, y, h0, rs, ws, &ride, s);
+    plan_wride(g, L, x, y, h0, rs, ws, &ride, s, p->v_x);
   }
   a.wr = ride;
   const bool direct = packed == nullptr && direct_ok(g, p);   // the forward of this call packed nothing
@@ -1254,6 +1266,7 @@ int vmlmf_tune(const char* key, int value) {
   }
   else if (k == "wring") g_wring = value;
   else if (k == "direct") g_direct = value;
+  else if (k == "finish2") g_finish2 = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
   else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;

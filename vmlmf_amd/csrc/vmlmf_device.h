@@ -332,6 +332,21 @@ __device__ inline float ref_bb(const VGeo& g, const RefP& p, int n, int k) {
   if (g.pergate) return vg_gate(p.bg, k)[n];
   return p.b_x[vg_xchunk(g, k) * g.H + n] + p.b_h[vg_hchunk(g, k) * g.H + n];
 }
+// element e of the partial blocks c .. c1 - 1 (PCH floats apart), summed in a FIXED order: four interleaved accumulators over batches
+// of eight loads that are in flight together (reduce_cg_kernel, finish2_kernel: deterministic, no float atomics)
+__device__ __forceinline__ float vg_block_sum(const float* __restrict__ Pall, const long long PCH, const long long e, int c, const int c1) {
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  for (; c < c1; c += 8) {   // (the last batch clamps its addresses and masks its values: as a loop of single loads the six blocks
+                             //  behind 24 of K = 30 were six memory round trips in a row)
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = Pall[(size_t)(c + i < c1 ? c + i : c1 - 1) * PCH + e];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i & 3] += c + i < c1 ? v[i] : 0.f;
+  }
+  return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
 // thread slot -> unit
 __device__ __forceinline__ bool vg_slot_unit(const VGeo& g, int slot, int& n) {
   const int grp = slot / (64 * g.W);

@@ -70,6 +70,10 @@ __device__ __forceinline__ void vg_raise(unsigned* status, unsigned code) {
 }
 struct WRide {
   AtbArgs a;
+  // dux (or NULL): the riding workers also contract their x-fold tile with v_x - the tile's share of d(u_x), [worker k][task][16 x 16]
+  // floats - so that ONE launch behind the recurrence can finish every gradient (finish2_kernel); vx: the reference's v_x (4H, rw)
+  float* dux;
+  const float* vx;
   unsigned* prog;
   int K, S, ntg, tasks;
   int lag;        // segments a progress word trails the stores it covers (a word is published every other segment)
@@ -159,6 +163,11 @@ struct ReduceCounts {
 };
 int launch_reduce(const VGeo& g, const float* wpart, float* cgrad, unsigned* prog, hipStream_t s,
                   ReduceCounts wc = ReduceCounts{{0, 0, 0}});   // prog: words to clear, or NULL
+// reduce + finish of a launch with riding workers in ONE launch (vmlmf_pack.hip: finish2_kernel): K partial blocks and the workers'
+// d(u_x) shares -> the reference-layout gradients; prog: the rows' progress words, cleared here
+bool finish2_ok(const VGeo& g);
+int launch_finish2(const VGeo& g, const RefP& p, const float* wpart, const float* dux, int K, const RefG& out, const HeadBwd& hd,
+                   unsigned* prog, hipStream_t s, unsigned* health);
 int launch_finish(const VGeo& g, const RefP& p, const float* cgrad, const RefG& out, const HeadBwd& hd, hipStream_t s,
                   unsigned* health = nullptr);   // health: device word set when a gradient written is not finite (or NULL)
 // the library's per-device gradient-health word (vmlmf_api.hip), what the optimizers' step guard reads; NULL before the first

@@ -156,16 +156,7 @@ __global__ void __launch_bounds__(256 * NS) wgrad_mfma_stack_kernel(AtbStack S) 
 // chunks (deterministic), then scatter into cgrad[accumulator][slot] (layout finish_kernel reads).
 // fixed-order sum over the blocks of element e: four interleaved accumulators, eight loads in flight
 __device__ __forceinline__ float reduce_cg_sum(const float* __restrict__ Pall, const long long PCH, const long long e, int c, const int c1) {
-  float s[4] = {0.f, 0.f, 0.f, 0.f};
-  for (; c + 7 < c1; c += 8) {
-    float v[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = Pall[(size_t)(c + i) * PCH + e];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) s[i & 3] += v[i];
-  }
-  for (; c < c1; ++c) s[0] += Pall[(size_t)c * PCH + e];
-  return (s[0] + s[1]) + (s[2] + s[3]);
+  return vg_block_sum(Pall, PCH, e, c, c1);   // (vmlmf_device.h: shared with finish2_kernel - the same order, the same bits)
 }
 
 __device__ __forceinline__ void reduce_cg_scatter(const VGeo& g, const long long e, const float total, float* __restrict__ cgrad);
