@@ -391,6 +391,17 @@ int vmlmf_sgd_clip_step(const vmlmf_tensor_list *tensors, float lr, float max_no
 #define VMLMF_GUARD_SKIPPED 66
 int vmlmf_adam_step_guarded(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp_avg_sq, float *steps, float lr,
                             float beta1, float beta2, float eps, float weight_decay, void *guard, void *stream);
+/* ABI 10: an optimizer step that takes several calls (more than VMLMF_MAX_TENSORS tensors, several parameter groups) - ONE verdict
+ * for all of them.  `flags`: VMLMF_ADAM_FIRST on the first call of the step (it reads the health word and leaves the verdict in the
+ * guard block), VMLMF_ADAM_LAST on the last (it clears the health word); the calls of a step share one guard block and one stream.
+ * vmlmf_adam_step_guarded is FIRST | LAST: the whole step in one call.  (Before ABI 10 every call read AND cleared the word: the
+ * second list of a failed step saw a clean word and applied its NaN gradients.)  With the scanning guard (vmlmf_tune("adam_guard",
+ * 2)) every call still gates its own list.  Under the health-word guard a list whose tensors have at most 2^20 elements takes ONE
+ * launch (step counters, verdict and update; the last workgroup to finish commits); other lists a tick launch and the update launch. */
+#define VMLMF_ADAM_FIRST 1
+#define VMLMF_ADAM_LAST 2
+int vmlmf_adam_step_ex(const vmlmf_tensor_list *tensors, float *exp_avg, float *exp_avg_sq, float *steps, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, void *guard, int flags, void *stream);
 
 /*
  * Data-parallel gradient exchange (no reference line: the reference has no distributed

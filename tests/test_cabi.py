@@ -34,7 +34,7 @@ def test_library_loads_and_exports_every_symbol():
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
         "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",
-        "finish_kernel", "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel"]
+        "finish_kernel", "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel", "finish2_kernel"]
 
 
 def test_query_headline_geometry():

@@ -412,3 +412,50 @@ def test_status_word_is_not_lost_when_the_first_call_on_a_device_is_captured():
         "    print('ok' if e.code == _lib.E_PROTOCOL else 'wrong code')\n") % ROOT
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_a_failed_step_is_skipped_for_every_tensor_list_and_parameter_group():
+    """an optimizer step of several launches (more than 48 tensors, two parameter groups) takes ONE verdict.  The
+    first form let the first launch read AND clear the health word: the later lists of the failed step saw a clean word and applied
+    their NaN gradients.  Here the VMLMF layer's backward fails (the riding workers give up), 60 extra small parameters and a second
+    parameter group ride along with NaN-free gradients of their own: nothing may move, one skipped step is counted, and the step
+    after it is an ordinary one for every tensor - with the one-launch form (small tensors) and with the tick + update launches."""
+    import vmlmf_amd
+    from vmlmf_amd import _lib
+    for big in (False, True):
+        net, x, t = _har_net()
+        _clear_status()
+        extra = [torch.nn.Parameter(torch.randn(7, device="cuda")) for _ in range(60)]
+        other = [torch.nn.Parameter(torch.randn(40000 if big else 33, device="cuda"))]     # (> 32768 elements: the two-launch form)
+        opt = vmlmf_amd.optim.Adam([{"params": list(net.parameters()) + extra}, {"params": other, "lr": 0.02}], lr=0.01)
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            loss = vmlmf_amd.cross_entropy(net(x), t) + sum((e * e).sum() for e in extra) + (other[0] * other[0]).mean()
+            for e in extra + other:
+                e.grad = None
+            loss.backward()
+            opt.step()
+
+        step()
+        everything = [p for g in opt.param_groups for p in g["params"]]
+        held = [p.detach().clone() for p in everything]
+        _lib.tune("test_wride_spin", 1)
+        try:
+            step()
+            torch.cuda.synchronize()
+            assert not torch.isfinite(net.rnn.rnncells[0].v_h.grad).all(), "the workers were expected to give up"
+            assert all(torch.isfinite(e.grad).all() for e in extra + other)
+            for p, h in zip(everything, held):
+                assert torch.equal(p.detach(), h), "a tensor list behind the first one applied the failed step"
+            assert opt.skipped_steps() == 1
+            assert all(float(opt.state[p]["step"]) == (1.0 if p.grad is not None else 0.0) for p in everything)
+        finally:
+            _clear_status()
+            _lib.tune("test_wride_spin", 0)
+        step()
+        torch.cuda.synchronize()
+        assert opt.skipped_steps() == 1
+        moved = [not torch.equal(p.detach(), h) for p, h in zip(everything, held) if p.grad is not None]
+        assert all(moved)
+        assert all(float(opt.state[p]["step"]) == (2.0 if p.grad is not None else 0.0) for p in everything)

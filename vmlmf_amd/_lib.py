@@ -14,12 +14,13 @@ LIB_PATH = os.environ.get("VMLMF_LIB") or os.path.join(_HERE, "lib", "libvmlmf_h
 CSRC = os.path.join(_HERE, "csrc")
 
 MAX_G = 2
-NKERNELS = 12
+NKERNELS = 13
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
 ABI_VERSION = 10
 GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
+ADAM_FIRST, ADAM_LAST = 1, 2
 DT_F32, DT_BF16 = 0, 1
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM, E_PROTOCOL = -1, -2, -3, -4, -5, -6
@@ -124,6 +125,8 @@ SYMBOLS = {
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),
     "vmlmf_adam_step_guarded": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _vp]),
+    "vmlmf_adam_step_ex": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
+                                ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp, _i, _vp]),
     "vmlmf_sgd_clip_step": (_i, [ctypes.POINTER(TensorList), ctypes.c_float, ctypes.c_float, _vp, _vp, _vp]),
     "vmlmf_comm_unique_id": (_i, [_vp]),
     "vmlmf_comm_init": (_i, [ctypes.POINTER(_vp), _i, _i, _vp]),

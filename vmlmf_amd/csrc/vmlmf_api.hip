@@ -23,7 +23,7 @@ int fail(int code, const std::string& msg) {
 }
 
 // ---- profiling (bench.py): HIP event pairs around every internal launch, on the launch stream ----
-constexpr int NKERN = 12;
+constexpr int NKERN = 13;
 struct Prof {
   std::mutex mu;
   unsigned mask = 0;  // bit k: bracket kernel k with an event pair
@@ -547,7 +547,7 @@ static int backward_tail(const VGeo& g, const Layout& L, const vmlmf_params* p, 
   og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
   for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   if (rode && ride->dux != nullptr) {   // the riding workers left their d(u_x) shares: ONE launch sums the K blocks and finishes
-    Scope sc(7, s);
+    Scope sc(12, s);
     return hip_fail(launch_finish2(g, to_refp(p), ws + L.b_wpart, ride->dux, ride->K, og, hb, ride->prog, s, health_word(s)), "finish2");
   }
   {
@@ -1405,7 +1405,7 @@ namespace {
 const char* kernel_label(int k) {
   static const char* names[NKERN] = {"pack_kernel",    "xproj_kernel",   "rec_fwd_kernel", "rec_bwd_kernel",
                                      "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",  "finish_kernel",
-                                     "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel"};
+                                     "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel", "finish2_kernel"};
   return (k >= 0 && k < NKERN) ? names[k] : "";
 }
 }  // namespace

@@ -33,16 +33,20 @@ __global__ void tick_kernel(TensorList t, int count, float* steps) {
 // library's gradient-health word when one of them is not finite (the NaN partial products of a launch that gave up a bounded
 // wait, VMLMF_E_PROTOCOL).  The tick reads the word: set -> nothing ticks, guard[GO] = 0 (adam_kernel returns at once), the step
 // is counted as skipped and the word is cleared; clear -> the ordinary tick.  One extra load in a launch that exists anyway.
-__global__ void tick_health_kernel(TensorList t, int count, float* steps, unsigned* guard, unsigned* health) {
-  const unsigned h = health != nullptr ? *health : 0u;
-  const bool go = h == 0u;
+// ABI 10: the verdict is taken ONCE per optimizer step.  An optimizer step can be several launches (tensor lists of
+// VMLMF_MAX_TENSORS, parameter groups): the FIRST one reads the health word and leaves the verdict in guard[GO], the others read
+// guard[GO], and only the LAST one clears the health word - the first form cleared it at once, so the second list of a failed
+// step saw a clean word and applied its NaN gradients.
+__global__ void tick_health_kernel(TensorList t, int count, float* steps, unsigned* guard, unsigned* health, int flags) {
+  const bool first = (flags & VMLMF_ADAM_FIRST) != 0, last = (flags & VMLMF_ADAM_LAST) != 0;
+  const bool go = first ? (health != nullptr ? *health : 0u) == 0u : guard[GUARD_GO_W] != 0u;
   if (go && (int)threadIdx.x < count) steps[t.sidx[threadIdx.x]] += 1.f;
   if (threadIdx.x == 0) {
-    guard[GUARD_GO_W] = go ? 1u : 0u;
-    if (!go) {
-      guard[GUARD_SKIPPED_W] += 1u;
-      *health = 0u;
+    if (first) {
+      guard[GUARD_GO_W] = go ? 1u : 0u;
+      if (!go) guard[GUARD_SKIPPED_W] += 1u;
     }
+    if (last && health != nullptr) *health = 0u;
   }
 }
 
@@ -52,7 +56,7 @@ __global__ void tick_health_kernel(TensorList t, int count, float* steps, unsign
 // slice of every gradient for non-finite values and leaves a flag; the last one to arrive (ticket) decides - all clear: the
 // step counters tick and guard[GO] = 1; otherwise nothing ticks, guard[GO] = 0 and guard[SKIPPED] counts the skipped step.
 // adam_kernel returns at once when guard[GO] is 0: parameters and moments keep their values.
-constexpr int GUARD_FLAGS = 64, GUARD_GO = 64, GUARD_TICKET = 65, GUARD_SKIPPED = 66;   // words of the guard block
+constexpr int GUARD_GO = 64, GUARD_TICKET = 65, GUARD_SKIPPED = 66;   // words of the guard block
 // (The workgroups meet in ONE returning atomic: low half = arrivals, high half = workgroups that saw a non-finite value.  The
 // last arriver reads the whole verdict from the value the atomic returns - no flag array, no release / acquire fences, which
 // cost 1.7 - 3.5 us each on this chip, more than the scan itself.)
@@ -129,6 +133,59 @@ __global__ __launch_bounds__(256) void adam_kernel(TensorList t, float* __restri
     vt[i] = vi;
     const float denom = sqrtf(vi) / bc2s + eps;
     p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+// Tick, verdict and update in ONE launch (lists whose largest tensor has at most ADAM_FUSED_MAX elements - the HAR net's largest is
+// 11 520 -: a tick launch in front of the update is pure latency there).  Every workgroup reads the step counter of its tensor
+// and the verdict (FIRST: the health word; else guard[GO]) and nobody writes either before the LAST workgroup to arrive at a ticket
+// does - a workgroup takes its ticket behind all its reads -: that workgroup ticks the counters, publishes the verdict and, on the
+// LAST launch of the step, clears the health word.
+constexpr long long ADAM_FUSED_MAX = 1 << 20;
+constexpr int GUARD_TICKET_W = 65;
+__global__ __launch_bounds__(256) void adam_fused_kernel(TensorList t, int count, float* __restrict__ m, float* __restrict__ v,
+                                                         float* __restrict__ steps, float lr, float b1, float b2, float eps, float wd,
+                                                         unsigned* __restrict__ guard, unsigned* __restrict__ health, int flags) {
+  const int ti = blockIdx.y, tid = threadIdx.x;
+  const bool first = (flags & VMLMF_ADAM_FIRST) != 0, last = (flags & VMLMF_ADAM_LAST) != 0;
+  bool go = true;
+  if (guard != nullptr) go = first ? (health != nullptr ? *health : 0u) == 0u : guard[GUARD_GO_W] != 0u;
+  if (go) {
+    const long long n = t.n[ti];
+    float* __restrict__ p = t.p[ti];
+    const float* __restrict__ g = t.g[ti];
+    float* __restrict__ mt = m + t.off[ti];
+    float* __restrict__ vt = v + t.off[ti];
+    const float s = steps[t.sidx[ti]] + 1.f;
+    const float bc1 = 1.f - powf(b1, s), bc2 = 1.f - powf(b2, s);
+    const float step_size = lr / bc1, bc2s = sqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * 256 + tid; i < n; i += (long long)gridDim.x * 256) {   // adam_kernel's operation order
+      float gi = g[i];
+      const float pi = p[i];
+      if (wd != 0.f) gi = fmaf(wd, pi, gi);
+      float mi = mt[i], vi = vt[i];
+      mi = mi + (gi - mi) * (1.f - b1);
+      vi = vi * b2 + (1.f - b2) * gi * gi;
+      mt[i] = mi;
+      vt[i] = vi;
+      p[i] = pi - step_size * (mi / (sqrtf(vi) / bc2s + eps));
+    }
+  }
+  __shared__ unsigned last_s;
+  if (tid == 0) {
+    unsigned* tk = &guard[GUARD_TICKET_W];
+    last_s = atomicAdd(tk, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;   // every other workgroup has read what it reads
+    if (last_s) *tk = 0u;
+  }
+  __syncthreads();
+  if (last_s == 0) return;
+  if (go && tid < count) steps[t.sidx[tid]] += 1.f;
+  if (guard != nullptr && tid == 0) {
+    if (first) {
+      guard[GUARD_GO_W] = go ? 1u : 0u;
+      if (!go) guard[GUARD_SKIPPED_W] += 1u;
+    }
+    if (last && health != nullptr) *health = 0u;
   }
 }
 
@@ -253,8 +310,8 @@ unsigned blocks_for(long long maxn) {
 
 extern "C" {
 
-int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
-                            float beta1, float beta2, float eps, float weight_decay, void* guard, void* stream) {
+int vmlmf_adam_step_ex(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
+                       float beta1, float beta2, float eps, float weight_decay, void* guard, int flags, void* stream) {
   TensorList t;
   long long maxn = 0;
   const int rc = fill(tensors, &t, &maxn);
@@ -262,8 +319,13 @@ int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, fl
   if (exp_avg == nullptr || exp_avg_sq == nullptr || steps == nullptr) return VMLMF_E_BADARG;
   hipStream_t s = (hipStream_t)stream;
   const int mode = guard != nullptr ? vmlmf_adam_guard_mode() : 0;
+  if (mode == 1 && maxn <= ADAM_FUSED_MAX) {   // one launch: tick, verdict and update (adam_fused_kernel; its ticket lives in the guard block)
+    hipLaunchKernelGGL(adam_fused_kernel, dim3(blocks_for(maxn), tensors->count), dim3(256), 0, s, t, tensors->count, exp_avg, exp_avg_sq,
+                       steps, lr, beta1, beta2, eps, weight_decay, (unsigned*)guard, vmlmf_health_word_if_any(), flags);
+    return (int)hipGetLastError();
+  }
   if (mode == 1) {
-    hipLaunchKernelGGL(tick_health_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps, (unsigned*)guard, vmlmf_health_word_if_any());
+    hipLaunchKernelGGL(tick_health_kernel, dim3(1), dim3(64), 0, s, t, tensors->count, steps, (unsigned*)guard, vmlmf_health_word_if_any(), flags);
   } else if (mode == 2) {
     // enough workgroups that the largest tensor is one pass (the HAR net: 45 workgroups, ONE round of loads), at most 1024
     // (the arrivals' half of the ticket word holds 16 bits)
@@ -278,9 +340,17 @@ int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, fl
   return (int)hipGetLastError();
 }
 
+// (one call = one whole optimizer step)
+int vmlmf_adam_step_guarded(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
+                            float beta1, float beta2, float eps, float weight_decay, void* guard, void* stream) {
+  return vmlmf_adam_step_ex(tensors, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, guard,
+                            VMLMF_ADAM_FIRST | VMLMF_ADAM_LAST, stream);
+}
+
 int vmlmf_adam_step(const vmlmf_tensor_list* tensors, float* exp_avg, float* exp_avg_sq, float* steps, float lr,
                     float beta1, float beta2, float eps, float weight_decay, void* stream) {
-  return vmlmf_adam_step_guarded(tensors, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, nullptr, stream);
+  return vmlmf_adam_step_ex(tensors, exp_avg, exp_avg_sq, steps, lr, beta1, beta2, eps, weight_decay, nullptr,
+                            VMLMF_ADAM_FIRST | VMLMF_ADAM_LAST, stream);
 }
 
 int vmlmf_sgd_clip_step(const vmlmf_tensor_list* tensors, float lr, float max_norm, float* norm, float* scratch,

@@ -56,8 +56,9 @@ class Adam(torch.optim.Optimizer):
         self._guarded = bool(guard)
 
     def skipped_steps(self):
-        """Steps the device-side gate refused because a gradient was not finite (summed over groups and calls; synchronises)."""
-        return sum(int(gs["guard"][_lib.GUARD_SKIPPED].item()) for gs in getattr(self, "_flat", {}).values() if gs.get("guard") is not None)
+        """Optimizer steps the device-side gate refused because a gradient was not finite (synchronises)."""
+        g = getattr(self, "_guard", None)
+        return 0 if g is None else int(g[_lib.GUARD_SKIPPED].item())
 
     def _group_state(self, gi, group):
         """Flat moment buffers covering every parameter of the group (allocated at the first step; kept out of
@@ -73,8 +74,11 @@ class Adam(torch.optim.Optimizer):
                 offs[p], sidx[p] = total, k
                 total += p.numel()
             gs = dict(m=torch.zeros(total, device=dev), v=torch.zeros(total, device=dev),
-                      steps=torch.zeros(len(ps), device=dev), offs=offs, sidx=sidx,
-                      guard=torch.zeros(_lib.GUARD_WORDS, device=dev, dtype=torch.int32) if getattr(self, "_guarded", True) else None)
+                      steps=torch.zeros(len(ps), device=dev), offs=offs, sidx=sidx)
+            # ONE guard block for the whole optimizer: the verdict on a step's gradients is taken once, by the first launch of the
+            # step, and holds for every tensor list and parameter group of that step
+            if getattr(self, "_guarded", True) and getattr(self, "_guard", None) is None:
+                self._guard = torch.zeros(_lib.GUARD_WORDS, device=dev, dtype=torch.int32)
             self._flat[gi] = gs
             for p in ps:
                 o = offs[p]
@@ -110,6 +114,9 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
+        # every launch of the step first (tensor lists of every group), then FIRST on the first and LAST on the last of them: one
+        # verdict on the step's gradients for all of them (include/vmlmf_hip.h: vmlmf_adam_step_ex)
+        calls = []
         for gi, group in enumerate(self.param_groups):
             live = [p for p in group["params"] if p.grad is not None]
             if not live:
@@ -120,16 +127,18 @@ class Adam(torch.optim.Optimizer):
                 g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                 _check(p, g)
                 pairs.append((p, g))
+            for tl in _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live]):
+                calls.append((tl, gs, group, live))
+        guard = getattr(self, "_guard", None)
+        for ci, (tl, gs, group, live) in enumerate(calls):
             dev = live[0].device
-            stream = _lib.raw_stream(dev)
             b1, b2 = group["betas"]
+            flags = (_lib.ADAM_FIRST if ci == 0 else 0) | (_lib.ADAM_LAST if ci == len(calls) - 1 else 0)
             with _lib.on_device(dev):
-                lists = _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live])
-                guard = None if gs.get("guard") is None else gs["guard"].data_ptr()
-                for tl in lists:
-                    _lib.check(lib.vmlmf_adam_step_guarded(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(),
-                                                           gs["steps"].data_ptr(), float(group["lr"]), float(b1), float(b2),
-                                                           float(group["eps"]), float(group["weight_decay"]), guard, stream))
+                _lib.check(lib.vmlmf_adam_step_ex(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(), gs["steps"].data_ptr(),
+                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]),
+                                                  float(group["weight_decay"]), None if guard is None else guard.data_ptr(), flags,
+                                                  _lib.raw_stream(dev)))
             _bump_versions(live)
         return loss
 
