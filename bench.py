@@ -233,8 +233,7 @@ def other_configs(iters=100):
     out["timesteps_per_s"] = round(24 / (out["ms_per_step"] * 1e-3), 1)
     out["workload"] = "BASELINE configs[2] in fp32: 2 x MyVMLMFCell(256), rank 24, B 128, T 24, I 77; RNN stack forward + backward, hipGraph replay"
     res = {"C_fp32": out}
-    # the same workload on the bf16-MFMA variant (row-block kernels, bf16 tapes; set_compute_dtype): what configs[2] names.  It is
-    # timed here every round so that the choice of fp32 as configs[2]'s default rests on a driver-timed number
+    # the same workload with dtype bf16 (set_compute_dtype): what configs[2] names.  Timed here every round
     try:
         from vmlmf_amd import set_compute_dtype
         torch.manual_seed(0)
@@ -267,8 +266,10 @@ def other_configs(iters=100):
         msb = (time.perf_counter() - t0) / iters * 1e3
         res["C_bf16"] = {"ms_per_step": round(msb, 4), "timesteps_per_s": round(24 / (msb * 1e-3), 1),
                          "vs_fp32": round(msb / out["ms_per_step"], 2),
-                         "workload": "BASELINE configs[2] as named (bf16 MFMA): the same stack on the row-block bf16 kernels, bf16 tapes, fp32 state; "
-                                     "hipGraph replay.  Slower than fp32 at this batch (8 workgroups x 16 rows): fp32 stays the default"}
+                         "workload": "BASELINE configs[2] with dtype bf16 (set_compute_dtype): below 4096 rows the same wavefront launches "
+                                     "with fp32 arithmetic and a bf16 GATE TAPE (8 instead of 16 bytes per unit and step; forward "
+                                     "bit-identical to fp32, gradients within the derived bound of tests/test_gpu_bf16.py); the "
+                                     "bf16-MFMA row-block kernels take over from 4096 rows, where they win; hipGraph replay"}
     except Exception as e:   # never at the expense of the line
         res["C_bf16"] = {"error": f"{type(e).__name__}: {e}"}
     # BASELINE configs[4] on one GPU: two PTB group layers (H 650, ranks 32 / [32, 32]), B 256, T 35 (clustered row-block kernels)
@@ -816,7 +817,8 @@ def main():
                        # ranks of the gradient exchange and WHO counted them: RCCL itself (ncclCommCount, C-ABI transport) or only
                        # the size of the torch.distributed group (backend named: over gloo there is no RCCL communicator)
                        "exchange_ranks": rccl_ranks, "exchange_ranks_counted_by": ranks_counted_by,
-                       "rccl_ranks": rccl_ranks if "nccl" in (ranks_counted_by or "") else None,
+                       # (only a count RCCL itself gave: "ncclCommCount ..."; the torch transport's label names its backend, "nccl" too)
+                       "rccl_ranks": rccl_ranks if (ranks_counted_by or "").startswith("ncclCommCount") else None,
                        "collectives_per_step": collectives_per_step,
                        "reduced_grad_norm_equal_across_ranks": grads_equal,
                        "launch": launch_mode,

@@ -32,8 +32,8 @@ BUDGET = {
     "void rec3_bwd_kernel<16, 2>(": (256, 0),
     "void rec3_bwd_kernel<8, 0>(": (136, 0),
     "void rec_bwd_kernel<16, 1, false, 256, 3, 0>(": (128, 0),
-    "void wf_fwd_kernel<24, 4, 1, 256>(": (168, 0),
-    "void wf_bwd_kernel<24, 4, 1, 256>(": (168, 0),
+    "void wf_fwd_kernel<24, 4, 1, 256, false>(": (168, 0),
+    "void wf_bwd_kernel<24, 4, 1, 256, false>(": (168, 0),
 }
 
 

@@ -182,17 +182,26 @@ def lib():
             # launches on ONE device a resident worker can starve the rows it waits for: such jobs
             # start on the stand-alone weight-gradient kernel instead of finding out through a failed step
             handle.vmlmf_tune(b"wride", 0)
+            import sys
+            print("vmlmf_amd: LOCAL_WORLD_SIZE says several local ranks share a device - the weight-gradient workers that ride on the "
+                  "backward launch are switched off (stand-alone kernel; VMLMF_WRIDE=1 keeps them)", file=sys.stderr)
     return _lib
 
 
 def ranks_share_a_device():
-    """True when the launcher's environment says more local ranks than visible devices (torchrun: LOCAL_WORLD_SIZE)."""
+    """True when the launcher's environment says more LOCAL ranks than visible devices (torchrun: LOCAL_WORLD_SIZE; WORLD_SIZE
+    counts the ranks of every node and is not looked at).  A launcher that masks one device per rank (HIP / ROCR / CUDA_VISIBLE_DEVICES
+    naming a single device) gives every rank a device of its own: not shared."""
     try:
-        local = int(os.environ.get("LOCAL_WORLD_SIZE") or os.environ.get("WORLD_SIZE") or 1)
+        local = int(os.environ.get("LOCAL_WORLD_SIZE") or 1)
     except ValueError:
         return False
     if local <= 1:
         return False
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and len([d for d in v.split(",") if d.strip()]) == 1:
+            return False
     import torch
     return local > max(torch.cuda.device_count(), 1)
 

@@ -1023,15 +1023,31 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
   S.L = L;
   for (int l = 0; l < L; ++l) {
     RbGeo q;
-    const int rc = make_geo(&ly[l].desc, &S.g[l], &q);
+    // dtype bf16 on a stack: below the batch where the bf16-MFMA row blocks pay (4096 rows: DESIGN.md section 4.8) the wavefront
+    // kernels run it with fp32 arithmetic and a bf16 GATE TAPE (VGeo::bt: half the tape bytes written and read back; one-group
+    // layers of padded rank 16 / 24); from there on, and for the layers those instantiations do not cover, the caller chains the
+    // row-block kernels (VMLMF_E_UNSUPPORTED here)
+    vmlmf_desc dd = ly[l].desc;
+    const bool bt = dd.dtype == VMLMF_DT_BF16;
+    if (bt) {
+      if (dd.B >= 4096) return fail(VMLMF_E_UNSUPPORTED, "stack: dtype bf16 at 4096 rows and more runs the row-block bf16-MFMA kernels layer by layer");
+      dd.dtype = VMLMF_DT_F32;
+    }
+    const int rc = make_geo(&dd, &S.g[l], &q);
     if (rc != 0) return rc;
+    if (bt) {
+      const int K = wf_width(S.g[l]);
+      if (S.g[l].G != 1 || !(K == 16 || K == 24) || !g_wf_bwd)
+        return fail(VMLMF_E_UNSUPPORTED, "stack: the bf16 gate tape covers one-group layers of padded rank 16 / 24");
+      S.g[l].bt = 1;
+    }
     const VGeo& g = S.g[l];
     if (!wf_supported(g))
       return fail(VMLMF_E_UNSUPPORTED, "stack: layer not covered by the wavefront kernels (V1-V3, V5, V6; at most four waves of hidden units; padded ranks "
                                        "<= 24, or 32 with at most three waves; fp32)");
     if (l > 0) {
       const VGeo& g0 = S.g[0];
-      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G || g.rw != g0.rw ||
+      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G || g.rw != g0.rw || g.bt != g0.bt ||
           g.time_major != g0.time_major || g.training != g0.training)
         return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, H, ranks, layout and training flag");
       if (g.I != g.H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: input_size must equal hidden_size");

@@ -204,6 +204,12 @@ __device__ __forceinline__ void st1_sv(const void* sbase, unsigned voff, float v
   else if constexpr (SAFE) asm volatile("s_nop 4\n\tglobal_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
   else asm volatile("global_store_dword %0, %1, %2" ::"v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+// (8 bytes: no wait states needed behind it; non-temporal: tapes)
+__device__ __forceinline__ void st2_sv_nt(const void* sbase, unsigned voff, float2 v) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const f32x2_t t = f32x2_t{v.x, v.y};
+  asm volatile("global_store_dwordx2 %0, %1, %2 nt" ::"v"(voff), "v"(t), "s"(sbase) : "memory");
+}
 // system-scope write-through variants (sc0 sc1): rows another workgroup, possibly on another XCD, consumes during the launch
 template <bool SAFE = false>
 __device__ __forceinline__ void st4_sv_sys(const void* sbase, unsigned voff, float4 v) {

@@ -36,6 +36,8 @@ struct VGeo {
                 //    nor the x^T dqx product is needed unless the layer's input wants a gradient
   int generic;  // 1: step-wise path (vmlmf_generic.hip): factors do not fit the register-resident kernels
   int bf;       // 1: desc.dtype = bf16: bf16 MFMA in the recurrence, bf16 tapes (x-side pre-activations, gates, dpre)
+  int bt;       // 1: the gate tape of the wavefront kernels is kept as bf16 (desc.dtype = bf16 on a stack below the batch where the
+                // bf16-MFMA row blocks pay: fp32 arithmetic everywhere, 8 instead of 16 bytes per unit and step written and read back)
   int rb;       // > 0: the recurrence runs on the row-block MFMA kernels (vmlmf_rb.hip), 16 batch rows per workgroup;
                 //      the value is S, the workgroups a row block's hidden units are split over (1 = no cluster)
 };

@@ -360,7 +360,7 @@ def _stack_plan(cfg, L, B, T, I, H, training):
         return _STACK_CACHE[key]
     variant, g, w_rank, u_ranks, time_major, dtype = cfg
     plan = None
-    if 1 <= L <= _lib.STACK_MAX and g in (1, 2) and dtype == _lib.DT_F32:
+    if 1 <= L <= _lib.STACK_MAX and g in (1, 2) and dtype in (_lib.DT_F32, _lib.DT_BF16):
         layers = (_lib.StackLayer * L)()
         descs = []
         for l in range(L):
@@ -541,7 +541,7 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     flat = [p for ps in layer_params for p in ps]
     hw, hb = (None, None) if head is None else head
     ops = torch_ops()
-    if ops is not None and h0 is None and c0 is None:      # (initial states: the ctypes form below)
+    if ops is not None and h0 is None and c0 is None and dt == _lib.DT_F32:      # (initial states, the bf16 tape: the ctypes form below)
         y, hT, cT, logits = ops.stack(x, flat, L, variant, int(w_rank), list(ur), int(g), bool(time_major), hw, hb)
         out = (y, list(hT.unbind(0)), list(cT.unbind(0)))
         return out + (logits,) if head is not None else out
