@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 10
+#define VMLMF_ABI_VERSION 11
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -215,10 +215,24 @@ typedef struct vmlmf_ce {
   uint64_t *ticket;          /* TWO 8-byte words that are zero before the first launch; every launch leaves them zero.
                               * Launches that share them must be ordered on one stream                                     */
 } vmlmf_ce;
+/* ABI 11: the dropout behind a layer of the LM network (`x = self.dropout(x)` of V/src/models/vmlmf_lm.py:438-439, nn.Dropout(p)
+ * of :402) inside the layer's own launches: the forward writes y (kept for the backward and the carried state) AND its dropped copy
+ * y_dropped = y * factor, factor = 0 with probability p and 1/(1-p) otherwise; the backward takes dy as the gradient of y_dropped and
+ * multiplies it by the same factors, regenerated from (state, site) - no mask tensor, no launch.  The factors are a pure function of
+ * (state[0] = seed, state[1] = offset, site, position t*B + b, column): Philox4x32-10, csrc/vmlmf_dropout.h; vmlmf_dropout_factors()
+ * returns them as a tensor (tests: the oracle multiplies by it).  Only layers for which vmlmf_dropout_fused() is 1; others:
+ * VMLMF_E_UNSUPPORTED, use vmlmf_dropout_apply behind the layer. */
+typedef struct vmlmf_dropout {
+  float p;                   /* drop probability, [0, 1)                                                                     */
+  int32_t site;              /* which dropout of the network (a different stream of factors per site)                       */
+  const int64_t *state;      /* device: {seed, offset} as vmlmf_dropout_advance snapshotted them for this forward           */
+  float *y_dropped;          /* forward: layout of y; backward: unused                                                       */
+} vmlmf_dropout;
 typedef struct vmlmf_extra {
   const void *packed;        /* kept parameter images (vmlmf_pack_params) or NULL */
   const vmlmf_head *head;    /* classifier on the final hidden state or NULL      */
   const vmlmf_ce *ce;        /* ABI 10: cross-entropy on that classifier's logits (forward calls; needs `head`) or NULL */
+  const vmlmf_dropout *drop; /* ABI 11: dropout of the layer's output inside its launches, or NULL                     */
 } vmlmf_extra;
 int vmlmf_seq_forward_ex(const vmlmf_desc *d, const vmlmf_params *p, const float *x, const float *h0,
                          const float *c0, float *y, float *hT, float *cT, void *reserve, void *workspace,
@@ -336,6 +350,24 @@ int vmlmf_nll_forward_grad(int R, int V, float *scores, const float *bias, const
  * dweight.  scratch: vmlmf_embed_backward_scratch_bytes(R, V) bytes (one bit per (vocabulary row, position)).  H <= 1024.
  */
 size_t vmlmf_embed_backward_scratch_bytes(int R, int V);
+/* ---- dropout launches (ABI 11; the scheme: vmlmf_dropout above) ----
+ * vmlmf_dropout_fused     1: vmlmf_seq_forward_ex / _backward_ex take extra.drop for this layer (row-block kernels, time-major).
+ * vmlmf_dropout_advance   snapshot = state; state.offset += 1 - one tiny launch per training forward, a node of a captured graph
+ *                         (every replay draws fresh factors).  state / snapshot: two int64 each, device memory.
+ * vmlmf_dropout_apply     y = x * factor over R positions of H columns (x == y allowed): nn.Dropout's forward, and - on the upstream
+ *                         gradient with the same (state, site) - its backward.
+ * vmlmf_dropout_factors   the factors as a (R, H) tensor, columns mapped as layer `d`'s fused kernels map them (d == NULL: as
+ *                         vmlmf_dropout_apply / the embedding entry points do).
+ * vmlmf_embed_dropout_forward   out[r] = weight[tokens[r]] * factor (vmlmf_lm.py:434-435 in one pass)
+ * vmlmf_embed_dropout_backward  vmlmf_embed_backward on the gradient of that dropped output (H a multiple of four) */
+int vmlmf_dropout_fused(const vmlmf_desc *d);
+int vmlmf_dropout_advance(int64_t *state, int64_t *snapshot, void *stream);
+int vmlmf_dropout_apply(int64_t R, int H, const float *x, float *y, float p, const int64_t *state, int site, void *stream);
+int vmlmf_dropout_factors(const vmlmf_desc *d, int64_t R, int H, float p, const int64_t *state, int site, float *factors, void *stream);
+int vmlmf_embed_dropout_forward(int R, int H, int V, const int64_t *tokens, const float *weight, float *out, float p,
+                                const int64_t *state, int site, void *stream);
+int vmlmf_embed_dropout_backward(int R, int H, int V, const int64_t *tokens, const float *dy, float *dweight, void *scratch,
+                                 size_t scratch_bytes, float p, const int64_t *state, int site, void *stream);
 int vmlmf_embed_backward(int R, int H, int V, const int64_t *tokens, const float *dy, float *dweight, void *scratch,
                          size_t scratch_bytes, void *stream);
 

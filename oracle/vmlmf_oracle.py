@@ -633,14 +633,70 @@ def nll_loss_stable(scores, y, dtype=np.float64):
     return loss, g * batch_size / R
 
 
-def literal_lm_forward(sd, x, states, layer_num):
-    """``Model.forward`` with lstm_type "vmlmf" and dropout 0 (V/src/models/vmlmf_lm.py:434-440) on a state-dict style
-    mapping name -> tensor: embed.w[x] -> MyVMLSTM layers -> addmm(fc.b, ., fc.w^T).  Returns (scores, states)."""
+def literal_lm_forward(sd, x, states, layer_num, factors=None):
+    """``Model.forward`` with lstm_type "vmlmf" (V/src/models/vmlmf_lm.py:434-440) on a state-dict style
+    mapping name -> tensor: embed.w[x] -> MyVMLSTM layers -> addmm(fc.b, ., fc.w^T).  Returns (scores, states).
+    factors=None: dropout 0.  Otherwise layer_num + 1 tensors (T, B, H) of nn.Dropout's factors (0, or 1/(1-p) where the element is
+    kept): ``x = self.dropout(x)`` behind the embedding (:435) and behind every layer (:439) as a multiplication by the GIVEN
+    factors - which elements torch's generator would have dropped is not part of the algorithm; the carried states are the
+    layers' undropped final states (:438)."""
     h = sd["embed.w"][x]
+    if factors is not None:
+        h = h * factors[0]
     out_states = []
     for i in range(layer_num):
         P = {k.split(".", 2)[2]: v for k, v in sd.items() if k.startswith(f"rnns.{i}.")}
         h, hT, cT = literal_sequence(V3, P, h, states[i][0], states[i][1], time_major=True)
+        if factors is not None:
+            h = h * factors[i + 1]
         out_states.append((hT, cT))
     scores = torch.addmm(sd["fc.b"], h.view(-1, h.size(2)), sd["fc.w"].t())
     return scores, out_states
+
+
+# ----------------------------------------------------------------------------------------------------
+# dropout factors of the HIP path (csrc/vmlmf_dropout.h): Philox4x32-10 restated in numpy
+# ----------------------------------------------------------------------------------------------------
+# nn.Dropout(p) (V/src/models/vmlmf_lm.py:402,435,439) zeroes an element with probability p and scales the kept ones by 1/(1-p);
+# WHICH elements is the generator's business.  The HIP path draws them from Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel
+# random numbers: as easy as 1, 2, 3", SC'11; Random123 1.x) - restated here so a test can (1) pin the generator on Random123's
+# published known-answer vectors and (2) reproduce the factors a kernel applied, bit for bit.
+PHILOX_KAT = [   # Random123 kat_vectors, philox4x32 10 rounds: counter, key, output
+    ((0x00000000, 0x00000000, 0x00000000, 0x00000000), (0x00000000, 0x00000000), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff, 0xffffffff, 0xffffffff, 0xffffffff), (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+def philox4x32_10(ctr, key):
+    """ctr: (..., 4) uint32 counters, key: (2,) or (..., 2) uint32 -> (..., 4) uint32."""
+    c = [np.asarray(ctr)[..., i].astype(np.uint64) for i in range(4)]
+    key = np.asarray(key)
+    k0 = key[..., 0].astype(np.uint64)
+    k1 = key[..., 1].astype(np.uint64)
+    M0, M1, W0, W1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85), np.uint64(0xFFFFFFFF)
+    sh = np.uint64(32)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> sh) ^ c[1] ^ k0, p1 & mask, (p0 >> sh) ^ c[3] ^ k1, p0 & mask]
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return np.stack(c, axis=-1).astype(np.uint32)
+
+
+def dropout_factors(seed, offset, site, rows, H, p, Hg=None, gstride=0):
+    """(rows, H) float32 factors of dropout site `site` for the generator state (seed, offset): element (position, unit n) maps to
+    column (n // Hg) * gstride + n % Hg (identity for Hg = None), counter = (position, column >> 2, site, offset low word), key =
+    (seed low word, seed high word + offset high word), dropped iff word[column & 3] < round(p 2^32)."""
+    n = np.arange(H)
+    col = n if Hg is None or gstride == 0 or Hg >= H else (n // Hg) * gstride + n % Hg
+    ctr = np.zeros((rows, H, 4), dtype=np.uint32)
+    ctr[..., 0] = np.arange(rows, dtype=np.uint32)[:, None]
+    ctr[..., 1] = (col >> 2).astype(np.uint32)[None, :]
+    ctr[..., 2] = np.uint32(site)
+    ctr[..., 3] = np.uint32(offset & 0xFFFFFFFF)
+    key = np.array([seed & 0xFFFFFFFF, ((seed >> 32) + (offset >> 32)) & 0xFFFFFFFF], dtype=np.uint32)
+    w = philox4x32_10(ctr, key)
+    word = np.take_along_axis(w, np.broadcast_to((col & 3)[None, :, None], (rows, H, 1)), axis=2)[..., 0]
+    thresh = min(int(float(np.float32(p)) * 4294967296.0 + 0.5), 4294967295)
+    scale = np.float32(1.0) / (np.float32(1.0) - np.float32(p))
+    return np.where(word < np.uint32(thresh), np.float32(0.0), scale).astype(np.float32)

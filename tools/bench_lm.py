@@ -2,6 +2,9 @@
 rank 32, vocabulary 10 000, T 35) -> nll_loss -> backward -> clip + SGD.
 
   python tools/bench_lm.py [B]            one MI355X: fused loss / update against the reference's own formulations in stock ops
+  python tools/bench_lm.py [B] --dropout 0.5   the shipped step at the reference's dropout (lm_test.py: --dropout 0.5): p = 0, p with the
+                                          package's mask-free dropout (in the embedding gather and the layers' own launches), p with
+                                          nn.Dropout's launches (Model.stock_dropout)
   python bench.py --config E [--gpus N]   run_config_e() below: BASELINE configs[4] data-parallel (global batch 256 split
                                           contiguously over the ranks, bucketed SUM all-reduce overlapping the recurrent
                                           layers' backward, clip after the reduce, rank-local state carry)
@@ -155,12 +158,13 @@ def stock_nll(scores, y):          # lm_test.py:140-153 as written
     return torch.mean(-torch.log(answerprobs) * batch_size)
 
 
-def run(tag, group, fused, head=False):
+def run(tag, group, fused, head=False, dropout=0.0, stock_dropout=False):
     """head: Model.loss (projection + loss with the gradient formed in place, tuned GEMM forms, the package's embedding
     gradient) instead of model(x) -> nll_loss(scores, y)."""
     import vmlmf_amd
     torch.manual_seed(0)
-    model = Model(V, H, 2, 0.0, 0.05, w_rank=32, u_ranks=[32], lstm_type="vmlmf")
+    model = Model(V, H, 2, dropout, 0.05, w_rank=32, u_ranks=[32], lstm_type="vmlmf")
+    model.stock_dropout = stock_dropout
     if group:   # the reference's Model cannot build the group layers (constructor quirk): put them in by hand
         model.rnns = torch.nn.ModuleList([MyVMLSTMGroup(H, H, w_rank=32, u_ranks=[32, 32]) for _ in range(2)])
         model.reset_parameters()
@@ -196,10 +200,21 @@ def run(tag, group, fused, head=False):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 10 * 1e3
     print(json.dumps({"config": tag, "B": B, "T": T, "vocab": V, "fused_loss_and_update": fused, "head_in_place": head,
+                      "dropout": dropout, "dropout_launches": "none" if dropout == 0 else ("nn.Dropout" if stock_dropout else "package (mask-free)"),
                       "ms_per_step_eager": round(ms, 3), "words_per_s": round(T * B / ms * 1e3)}), flush=True)
+    return ms
 
 
 if __name__ == "__main__":
+    if "--dropout" in sys.argv:
+        p = float(sys.argv[sys.argv.index("--dropout") + 1])
+        tag = "E-model: Embed + 2 x MyVMLSTMGroup + Linear + nll"
+        base = run(tag, True, True, head=True)
+        ours = run(tag, True, True, head=True, dropout=p)
+        stock = run(tag, True, True, head=True, dropout=p, stock_dropout=True)
+        print(json.dumps({"dropout": p, "ms_p0": round(base, 3), "ms_package": round(ours, 3), "ms_nn_dropout": round(stock, 3),
+                          "package_over_p0": round(ours / base, 4), "nn_dropout_over_p0": round(stock / base, 4)}), flush=True)
+        sys.exit(0)
     run("E-model: Embed + 2 x MyVMLSTM + Linear + nll", False, True, head=True)
     if "--only-head" in sys.argv:   # (for a profile of the shipped step alone)
         sys.exit(0)

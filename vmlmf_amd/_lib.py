@@ -18,7 +18,7 @@ NKERNELS = 13
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 10
+ABI_VERSION = 11
 GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
 ADAM_FIRST, ADAM_LAST = 1, 2
 DT_F32, DT_BF16 = 0, 1
@@ -56,8 +56,13 @@ class Ce(ctypes.Structure):
                 ("lse", ctypes.c_void_p), ("dlogits_unit", ctypes.c_void_p), ("ticket", ctypes.c_void_p)]
 
 
+class Dropout(ctypes.Structure):
+    """vmlmf_dropout (ABI 11): dropout of a layer's output inside the layer's launches."""
+    _fields_ = [("p", ctypes.c_float), ("site", ctypes.c_int32), ("state", ctypes.c_void_p), ("y_dropped", ctypes.c_void_p)]
+
+
 class Extra(ctypes.Structure):
-    _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head)), ("ce", ctypes.POINTER(Ce))]
+    _fields_ = [("packed", ctypes.c_void_p), ("head", ctypes.POINTER(Head)), ("ce", ctypes.POINTER(Ce)), ("drop", ctypes.POINTER(Dropout))]
 
 
 class StackLayer(ctypes.Structure):
@@ -120,6 +125,12 @@ SYMBOLS = {
     "vmlmf_nll_forward_grad": (_i, [_i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _vp, _vp, _vp, _vp]),
     "vmlmf_embed_backward_scratch_bytes": (_sz, [_i, _i]),
     "vmlmf_embed_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vmlmf_dropout_fused": (_i, [ctypes.POINTER(Desc)]),
+    "vmlmf_dropout_advance": (_i, [_vp, _vp, _vp]),
+    "vmlmf_dropout_apply": (_i, [ctypes.c_int64, _i, _vp, _vp, ctypes.c_float, _vp, _i, _vp]),
+    "vmlmf_dropout_factors": (_i, [ctypes.POINTER(Desc), ctypes.c_int64, _i, ctypes.c_float, _vp, _i, _vp, _vp]),
+    "vmlmf_embed_dropout_forward": (_i, [_i, _i, _i, _vp, _vp, _vp, ctypes.c_float, _vp, _i, _vp]),
+    "vmlmf_embed_dropout_backward": (_i, [_i, _i, _i, _vp, _vp, _vp, _vp, _sz, ctypes.c_float, _vp, _i, _vp]),
     "vmlmf_transpose": (_i, [_i, _i, _vp, _vp, _vp]),
     "vmlmf_adam_step": (_i, [ctypes.POINTER(TensorList), _vp, _vp, _vp, ctypes.c_float, ctypes.c_float,
                              ctypes.c_float, ctypes.c_float, ctypes.c_float, _vp]),

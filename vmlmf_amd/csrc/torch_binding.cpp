@@ -139,6 +139,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       hd.classes = (int)head_w.size(0), hd.weight = head_w.data_ptr<float>(), hd.bias = cptr(head_b), hd.logits = logits.data_ptr<float>();
     }
     vmlmf_extra ex;
+    memset(&ex, 0, sizeof(ex));
     ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = head_w.defined() ? &hd : nullptr, ex.ce = nullptr;
     Tensor stats, dz_unit, target;
     vmlmf_ce ce;
@@ -244,6 +245,7 @@ struct SeqFn : public torch::autograd::Function<SeqFn> {
       hd.dweight = dW.data_ptr<float>(), hd.dbias = has_head_b ? db.data_ptr<float>() : nullptr;
     }
     vmlmf_extra ex;
+    memset(&ex, 0, sizeof(ex));
     ex.packed = packed.defined() ? packed.data_ptr() : nullptr, ex.head = dlogits.defined() ? &hd : nullptr, ex.ce = nullptr;
     check(vmlmf_seq_backward_ex(&d, &ps, x.data_ptr<float>(), cptr(h0), cptr(c0), y.data_ptr<float>(), reserve.data_ptr(),
                                 cptr(dy), cptr(dhT), cptr(dcT), mptr(dx), mptr(dh0), mptr(dc0), &gs, ws.data_ptr(),

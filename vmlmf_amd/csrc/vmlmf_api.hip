@@ -705,6 +705,19 @@ static int check_head(const VGeo& g, const vmlmf_head* hd, bool fwd) {
   return 0;
 }
 
+// vmlmf_dropout of a call -> kernel arguments (vmlmf_dropout.h); rc != 0: bad arguments / a layer whose kernels do not take it
+static int make_drop(const vmlmf_dropout* dr, const VGeo& g, bool forward, DropArgs* out) {
+  memset(out, 0, sizeof(*out));
+  if (dr == nullptr) return 0;
+  if (!(dr->p >= 0.f && dr->p < 1.f)) return fail(VMLMF_E_BADARG, "dropout: p must be in [0, 1)");
+  if (dr->state == nullptr || (forward && dr->y_dropped == nullptr)) return fail(VMLMF_E_BADARG, "dropout: null state / y_dropped");
+  if (!g.rb || g.syT != (long long)g.B * g.H)
+    return fail(VMLMF_E_UNSUPPORTED, "dropout inside the layer's launches: row-block layers in the time-major layout (vmlmf_dropout_fused)");
+  out->state = reinterpret_cast<const unsigned long long*>(dr->state), out->yd = forward ? dr->y_dropped : nullptr;
+  out->thresh = drop_thresh(dr->p), out->scale = 1.f / (1.f - dr->p), out->site = dr->site;
+  return 0;
+}
+
 int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
                          const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                          size_t workspace_bytes, void* stream, const vmlmf_extra* ex) {
@@ -723,6 +736,8 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
   // their recurrence (same values up to summation order)
   const bool head_inside = head != nullptr && !g.rb && !g.generic;
   if (head != nullptr && !head_inside && hT == nullptr) return fail(VMLMF_E_BADARG, "head on this layer needs the hT output");
+  DropArgs drop;
+  if ((rc = make_drop(ex != nullptr ? ex->drop : nullptr, g, true, &drop)) != 0) return rc;
   const vmlmf_ce* ce = ex != nullptr ? ex->ce : nullptr;
   if (ce != nullptr) {
     if (head == nullptr) return fail(VMLMF_E_BADARG, "ce: the criterion rides on the classifier's logits (extra.head)");
@@ -776,6 +791,7 @@ int vmlmf_seq_forward_ex(const vmlmf_desc* d, const vmlmf_params* p, const float
     io.gates = g.training ? rs + L.r_gates : nullptr, io.cs = g.training ? rs + L.r_cs : nullptr;
     io.Qs = g.training ? rs + L.r_Qs : nullptr;
     io.xq = ws + L.f_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.f_flag), io.status = status_word(s);
+    io.drop = drop;
     {
       Scope sc(2, s);
       if ((rc = hip_fail(launch_rb_fwd(g, q, io, s), "rb_fwd")) != 0) return rc;
@@ -880,6 +896,8 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
   if ((rc = check_pointers(g, gr, "grads")) != 0) return rc;
   if ((rc = check_head(g, head, false)) != 0) return rc;
   const bool head_inside = head != nullptr && !g.rb && !g.generic;
+  DropArgs drop;
+  if ((rc = make_drop(ex != nullptr ? ex->drop : nullptr, g, false, &drop)) != 0) return rc;
   const VPack P = vg_pack_layout(g, q.total);
   const Layout L = make_layout(g, P, q);
   if (workspace_bytes < (size_t)L.b_total * sizeof(float))
@@ -919,6 +937,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     io.gates = const_cast<float*>(rs + L.r_gates), io.cs = const_cast<float*>(rs + L.r_cs), io.EH = pack + P.EH;
     io.img = pack + P.RB, io.dy = dy, io.dhT = dhT, io.dcT = dcT, io.dpre = ws + L.b_dpre, io.dQs = ws + L.b_dQs;
     io.dh0 = dh0, io.dc0 = dc0, io.xq = ws + L.b_xq, io.flag = reinterpret_cast<unsigned*>(ws + L.b_flag), io.status = status_word(s);
+    io.drop = drop;
     {
       Scope sc(3, s);
       if ((rc = hip_fail(launch_rb_bwd(g, q, io, s), "rb_bwd")) != 0) return rc;
@@ -1377,6 +1396,72 @@ int vmlmf_embed_backward(int R, int H, int V, const int64_t* tokens, const float
   if (!tokens || !dy || !dweight) return fail(VMLMF_E_BADARG, "embed: null pointer");
   const int rc = launch_embed_bwd(R, H, V, (const long long*)tokens, dy, dweight, scratch, scratch_bytes, (hipStream_t)stream);
   if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "embed_backward: embedding width > 1024");
+  if (rc == -4) return fail(VMLMF_E_WORKSPACE, "embed_backward: scratch smaller than vmlmf_embed_backward_scratch_bytes()");
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
+// ---- dropout of the LM network (ABI 11; vmlmf_dropout.h) ----
+int vmlmf_dropout_fused(const vmlmf_desc* d) {
+  VGeo g;
+  RbGeo q;
+  if (make_geo(d, &g, &q) != 0) return 0;
+  return (g.rb && g.syT == (long long)g.B * g.H) ? 1 : 0;
+}
+
+int vmlmf_dropout_advance(int64_t* state, int64_t* snapshot, void* stream) {
+  if (!state || !snapshot || state == snapshot) return fail(VMLMF_E_BADARG, "dropout_advance: two distinct device words pairs");
+  const int rc = launch_drop_advance(reinterpret_cast<unsigned long long*>(state), reinterpret_cast<unsigned long long*>(snapshot), (hipStream_t)stream);
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
+static int drop_rows(int mode, int64_t R, int H, int V, float p, const int64_t* state, int site, const DropCols& cm, const float* x,
+                     const int64_t* tokens, float* y, void* stream) {
+  if (R < 0 || H < 1) return fail(VMLMF_E_BADARG, "dropout: R >= 0, H >= 1");
+  if (!(p >= 0.f && p < 1.f)) return fail(VMLMF_E_BADARG, "dropout: p must be in [0, 1)");
+  if (!state || !y || (mode != 1 && !x) || (mode == 2 && !tokens)) return fail(VMLMF_E_BADARG, "dropout: null pointer");
+  if (R >= (1ll << 32)) return fail(VMLMF_E_UNSUPPORTED, "dropout: 2^32 positions and more");
+  DropArgs d;
+  memset(&d, 0, sizeof(d));
+  d.state = reinterpret_cast<const unsigned long long*>(state), d.thresh = drop_thresh(p), d.scale = 1.f / (1.f - p), d.site = site;
+  const int rc = launch_drop_rows(mode, R, H, V, d, cm, x, (const long long*)tokens, y, (hipStream_t)stream);
+  return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
+}
+
+int vmlmf_dropout_apply(int64_t R, int H, const float* x, float* y, float p, const int64_t* state, int site, void* stream) {
+  const DropCols cm = {H, 0};
+  return drop_rows(0, R, H, 0, p, state, site, cm, x, nullptr, y, stream);
+}
+
+int vmlmf_dropout_factors(const vmlmf_desc* d, int64_t R, int H, float p, const int64_t* state, int site, float* factors, void* stream) {
+  DropCols cm = {H, 0};
+  if (d != nullptr) {
+    VGeo g;
+    RbGeo q;
+    int rc = make_geo(d, &g, &q);
+    if (rc != 0) return rc;
+    if (g.H != H) return fail(VMLMF_E_BADARG, "dropout_factors: H is not the layer's hidden size");
+    if (g.rb) cm.Hg = g.Hg, cm.gstride = 64 * g.W;
+  }
+  return drop_rows(1, R, H, 0, p, state, site, cm, nullptr, nullptr, factors, stream);
+}
+
+int vmlmf_embed_dropout_forward(int R, int H, int V, const int64_t* tokens, const float* weight, float* out, float p, const int64_t* state,
+                                int site, void* stream) {
+  if (V < 1) return fail(VMLMF_E_BADARG, "embed: V must be >= 1");
+  const DropCols cm = {H, 0};
+  return drop_rows(2, R, H, V, p, state, site, cm, weight, tokens, out, stream);
+}
+
+int vmlmf_embed_dropout_backward(int R, int H, int V, const int64_t* tokens, const float* dy, float* dweight, void* scratch,
+                                 size_t scratch_bytes, float p, const int64_t* state, int site, void* stream) {
+  if (R < 1 || H < 1 || V < 1) return fail(VMLMF_E_BADARG, "embed: R, H, V must be >= 1");
+  if (!tokens || !dy || !dweight || !state) return fail(VMLMF_E_BADARG, "embed: null pointer");
+  if (!(p >= 0.f && p < 1.f)) return fail(VMLMF_E_BADARG, "dropout: p must be in [0, 1)");
+  DropArgs d;
+  memset(&d, 0, sizeof(d));
+  d.state = reinterpret_cast<const unsigned long long*>(state), d.thresh = drop_thresh(p), d.scale = 1.f / (1.f - p), d.site = site;
+  const int rc = launch_embed_bwd(R, H, V, (const long long*)tokens, dy, dweight, scratch, scratch_bytes, (hipStream_t)stream, &d);
+  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "embed_dropout_backward: embedding width > 1024 or not a multiple of four");
   if (rc == -4) return fail(VMLMF_E_WORKSPACE, "embed_backward: scratch smaller than vmlmf_embed_backward_scratch_bytes()");
   return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
 }

@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "vmlmf_dropout.h"
 #include "vmlmf_launch.h"
 
 namespace {
@@ -64,20 +65,70 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int R, int H, int V, int
   }
 }
 
+// the same sum when the embedding's output went through dropout (vmlmf_lm.py:434-435): dy is the gradient of the DROPPED copy, and
+// the factor of every (position, column) is regenerated here (vmlmf_dropout.h) - no mask tensor, no pass of its own.  A lane owns
+// four neighbouring columns (one generator call), 256 columns per round: H a multiple of four, H <= 1024.
+__global__ __launch_bounds__(256) void embed_bwd_drop_kernel(int R, int H, int V, int words, const unsigned* __restrict__ bits,
+                                                             const float* __restrict__ dy, float* __restrict__ dW, DropArgs d) {
+  const int lane = threadIdx.x & 63;
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  const DropKey key = drop_key(d);
+  const unsigned* brow = bits + (size_t)v * words;
+  float4 acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int w0 = 0; w0 < words; w0 += 64) {
+    const int wi = w0 + lane;
+    const unsigned mine = wi < words ? brow[wi] : 0u;
+    unsigned long long any = __ballot(mine != 0u);
+    while (any != 0ull) {
+      const int src = __ffsll((long long)any) - 1;
+      any &= any - 1ull;
+      unsigned word = (unsigned)__shfl((int)mine, src, 64);
+      while (word != 0u) {
+        const int bit = __ffs((int)word) - 1;
+        word &= word - 1u;
+        const int p = (w0 + src) * 32 + bit;
+        const float* row = dy + (size_t)p * H;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int col = 4 * lane + 256 * c;
+          if (col < H) {
+            float f[4];
+            drop_factors(key, d.thresh, d.scale, (unsigned)p, (unsigned)(col >> 2), f);
+            const float4 g = *reinterpret_cast<const float4*>(row + col);
+            acc[c].x += g.x * f[0], acc[c].y += g.y * f[1], acc[c].z += g.z * f[2], acc[c].w += g.w * f[3];
+          }
+        }
+      }
+    }
+  }
+  float* out = dW + (size_t)v * H;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int col = 4 * lane + 256 * c;
+    if (col < H) *reinterpret_cast<float4*>(out + col) = acc[c];
+  }
+}
+
 }  // namespace
 
 size_t embed_bwd_scratch_bytes(int R, int V) { return (size_t)V * (size_t)((R + 31) / 32) * sizeof(unsigned); }
 
 int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* dy, float* dW, void* scratch, size_t scratch_bytes,
-                     hipStream_t s) {
-  if (H > 64 * EMB_C) return -3;
+                     hipStream_t s, const DropArgs* drop) {
+  if (H > 64 * EMB_C || (drop != nullptr && (H & 3) != 0)) return -3;
   const int words = (R + 31) / 32;
   const size_t need = embed_bwd_scratch_bytes(R, V);
   if (scratch == nullptr || scratch_bytes < need) return -4;
   hipError_t e = hipMemsetAsync(scratch, 0, need, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(embed_mark_kernel, dim3((R + 255) / 256), dim3(256), 0, s, R, V, words, tokens, (unsigned*)scratch);
-  hipLaunchKernelGGL(embed_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, s, R, H, V, words, (const unsigned*)scratch, dy, dW);
+  if (drop != nullptr)
+    hipLaunchKernelGGL(embed_bwd_drop_kernel, dim3((V + 3) / 4), dim3(256), 0, s, R, H, V, words, (const unsigned*)scratch, dy, dW, *drop);
+  else
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, s, R, H, V, words, (const unsigned*)scratch, dy, dW);
   return (int)hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "vmlmf_device.h"
+#include "vmlmf_dropout.h"
 
 // launch bounds of rec_fwd_kernel / rec_bwd_kernel.  (The storer as wave NW + 4, i.e. on the SIMD of the loader / x-projection
 // wave instead of compute wave 0's: -1.5 us with the loader, +1.8 us with the x-projection wave, not shipped -
@@ -128,6 +129,7 @@ struct RbIo {
   unsigned* flag;   // cluster epoch words + error word
   unsigned* status; // host-visible status word (or NULL)
   int flags_zeroed;   // forward: rb_pack_kernel of this call has zeroed the epoch words (no memset node)
+  DropArgs drop;      // dropout of the layer's output (state == nullptr: none): forward writes drop.yd, backward masks dy
 };
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
 bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
@@ -201,6 +203,11 @@ int launch_nll_fwd_grad(int R, int V, float* scores, const float* bias, const lo
 size_t embed_bwd_scratch_bytes(int R, int V);
 int launch_transpose(int rows, int cols, const float* src, float* dst, hipStream_t s);   // dst (cols x rows) = src^T
 int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* dy, float* dW, void* scratch, size_t scratch_bytes,
+                     hipStream_t s, const DropArgs* drop = nullptr);
+// dropout launches (vmlmf_dropout.hip): snapshot + advance of the generator state; mode 0: y = x * factor, 1: y = factor, 2: y =
+// w[tokens] * factor over R positions of H columns
+int launch_drop_advance(unsigned long long* state, unsigned long long* snap, hipStream_t s);
+int launch_drop_rows(int mode, long long R, int H, int V, const DropArgs& d, const DropCols& cm, const float* x, const long long* tokens, float* y,
                      hipStream_t s);
 
 // ---- wavefront kernels for stacked layers (vmlmf_wave.inc) ----

@@ -180,7 +180,7 @@ class VmlmfSeqFn(torch.autograd.Function):
     target (with a head): mean cross-entropy of the logits against it as the fifth output (vmlmf_ce: inside the same launch)."""
 
     @staticmethod
-    def forward(ctx, cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, *params):
+    def forward(ctx, cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, drop, *params):
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -233,6 +233,13 @@ class VmlmfSeqFn(torch.autograd.Function):
             ce.dlogits_unit = None if dz_unit is None else dz_unit.data_ptr()
             ce.ticket = ce_ticket(dev).data_ptr()
             ex.ce = ctypes.pointer(ce)
+        # dropout of the layer's output inside its launches (vmlmf_dropout, ABI 11): drop = (p, snapshot, site); the first output is
+        # then the DROPPED copy, y itself stays with the backward
+        yd = dr = None
+        if drop is not None:
+            yd = torch.empty_like(y)
+            dr = _lib.Dropout(float(drop[0]), int(drop[2]), drop[1].data_ptr(), yd.data_ptr())
+            ex.drop = ctypes.pointer(dr)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_seq_forward_ex(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0c), _ptr(c0c), _ptr(y), _ptr(hT),
@@ -242,12 +249,13 @@ class VmlmfSeqFn(torch.autograd.Function):
             ctx.has_h0, ctx.has_c0 = h0 is not None, c0 is not None
             ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
             ctx.has_ce = dz_unit is not None
+            ctx.drop = None if drop is None else (float(drop[0]), int(drop[2]))
             ctx.save_for_backward(x, y, reserve, *params, *([h0c] if h0 is not None else []),
                                   *([c0c] if c0 is not None else []), *([hw] if hw is not None else []),
-                                  *([dz_unit] if dz_unit is not None else []))
+                                  *([dz_unit] if dz_unit is not None else []), *([drop[1]] if drop is not None else []))
             ctx.nparams = len(params)
         loss = stats[0] if stats is not None else torch.empty((0,), device=dev, dtype=torch.float32)
-        return y, hT, cT, logits, loss
+        return (y if yd is None else yd), hT, cT, logits, loss
 
     @staticmethod
     def backward(ctx, dy, dhT, dcT, dlogits, dloss):
@@ -267,12 +275,13 @@ class VmlmfSeqFn(torch.autograd.Function):
             if not (unit is not None and dloss.data_ptr() == unit.data_ptr()):
                 dz = dz * dloss
             dlogits = dz if dlogits is None else dlogits + dz
+        snap = rest.pop(0) if ctx.drop is not None else None
         dev = x.device
         desc, sizes = ctx.desc, ctx.sizes
         dy = None if dy is None else dy.contiguous()
         dhT = None if dhT is None else dhT.contiguous()
         dcT = None if dcT is None else dcT.contiguous()
-        need_dx = ctx.needs_input_grad[2]   # (cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, *params)
+        need_dx = ctx.needs_input_grad[2]   # (cfg, packed, x, h0, c0, head_w, head_b, target, ignore_index, drop, *params)
         dx = torch.empty_like(x) if need_dx else None
         B, H = y.shape[1 if time_major else 0], y.shape[2]
         dh0 = torch.empty((B, H), device=dev, dtype=torch.float32) if ctx.has_h0 else None
@@ -305,16 +314,19 @@ class VmlmfSeqFn(torch.autograd.Function):
         ex = _lib.Extra()
         ex.packed = None if ctx.packed is None else ctx.packed.data_ptr()
         ex.head = ctypes.pointer(hd) if use_head else None
+        if snap is not None:   # dy is the gradient of the dropped copy: the launch regenerates the forward's factors
+            dr = _lib.Dropout(ctx.drop[0], ctx.drop[1], snap.data_ptr(), None)
+            ex.drop = ctypes.pointer(dr)
         with _lib.on_device(dev):
             _lib.check(_lib.lib().vmlmf_seq_backward_ex(
                 ctypes.byref(desc), ctypes.byref(ps), _ptr(x), _ptr(h0), _ptr(c0), _ptr(y), _ptr(reserve),
                 _ptr(dy), _ptr(dhT), _ptr(dcT), _ptr(dx), _ptr(dh0), _ptr(dc0), ctypes.byref(gs),
                 _ptr(ws), sizes.workspace_bytes, stream, ctypes.byref(ex)))
-        return (None, None, dx, dh0, dc0, dW, db, None, None) + grads
+        return (None, None, dx, dh0, dc0, dW, db, None, None, None) + grads
 
 
 def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", pack_cache=None,
-                   head=None, target=None, ignore_index=-100):
+                   head=None, target=None, ignore_index=-100, drop=None):
     """Run one VMLMF layer over a whole sequence on the GPU.
 
     params: tensors in the order dia_x, dia_h, u_x, v_x, b_x, b_h, u_h[0], v_h[0] (, u_h[1], v_h[1]),
@@ -325,8 +337,23 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
     returns (y, hT, cT, logits) and neither the logits nor their backward cost a launch of their own on the VALU kernels.
     target (with head): (B,) int64 class indices - the mean cross-entropy of the logits against them (nn.CrossEntropyLoss() with
     default arguments, train.py:58-65) comes back as a fifth element, formed inside the same forward launch.
+    drop: (p, snapshot, site) - nn.Dropout(p) behind the layer (vmlmf_lm.py:438-439) without a mask tensor: the returned y is the
+    dropped activation; inside the layer's own launches where the library takes it (vmlmf_dropout_fused: the row-block kernels,
+    time-major), one launch of the package's otherwise (dropout()).
     """
     dt = _lib.DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
+    if drop is not None and head is None and x.is_cuda:
+        ur_ = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
+        cfg = (variant, g, int(w_rank), ur_, bool(time_major), dt)
+        T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
+        training = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+        desc, _ = _desc_for(cfg, B, T, x.shape[2], _hidden_size(variant, params), training)
+        if _lib.lib().vmlmf_dropout_fused(ctypes.byref(desc)) == 1:
+            return VmlmfSeqFn.apply(cfg, None, x, h0, c0, None, None, None, ignore_index, tuple(drop), *params)[:3]
+    if drop is not None:
+        y, hT, cT = vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=g, time_major=time_major, dtype=dtype,
+                                   pack_cache=pack_cache)
+        return dropout(y, drop[0], drop[1], drop[2]), hT, cT
     packed = None
     if pack_cache is not None and x.is_cuda:
         T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
@@ -343,7 +370,7 @@ def vmlmf_sequence(variant, x, h0, c0, params, w_rank, u_ranks, g=1, time_major=
         return out if head is not None else out[:3]
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     out = VmlmfSeqFn.apply(cfg, packed, x, h0, c0, None if head is None else head[0], None if head is None else head[1],
-                           target, ignore_index, *params)
+                           target, ignore_index, None, *params)
     if target is not None:
         return out
     return out[:4] if head is not None else out[:3]
@@ -1015,6 +1042,131 @@ class EmbedFn(torch.autograd.Function):
             _lib.check(lib.vmlmf_embed_backward(R, H, V, _ptr(tok), _ptr(dy2), _ptr(dw), scratch.data_ptr(), nbytes,
                                                 _lib.raw_stream(dy.device)))
         return dw, None
+
+
+# ---- dropout of the LM network without mask tensors (C ABI 11: vmlmf_dropout_*; csrc/vmlmf_dropout.h) --------------------------
+def dropout_state(device, seed=None):
+    """{seed, offset} of the package's dropout generator on `device` (int64[2]).  seed=None: drawn from torch's CPU generator, so
+    torch.manual_seed() makes the masks repeatable."""
+    if seed is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+    return torch.tensor([int(seed), 0], dtype=torch.int64, device=device)
+
+
+def dropout_advance(state):
+    """This forward's snapshot of `state`; the state moves on by one (one tiny launch: a node of a captured step, so every replay
+    draws fresh factors)."""
+    if not state.is_cuda or state.dtype != torch.int64 or state.numel() != 2:
+        raise RuntimeError("vmlmf_amd: the dropout state is two int64 words on a HIP device (dropout_state())")
+    snap = torch.empty_like(state)
+    with _lib.on_device(state.device):
+        _lib.check(_lib.lib().vmlmf_dropout_advance(state.data_ptr(), snap.data_ptr(), _lib.raw_stream(state.device)))
+    return snap
+
+
+class DropoutFn(torch.autograd.Function):
+    """y = x * factor(snapshot, site) over the rows of x (..., H): nn.Dropout(p) in one launch per direction, the factors
+    regenerated in the backward (no mask is kept)."""
+
+    @staticmethod
+    def forward(ctx, x, p, snap, site):
+        _require_hip(x, "input")
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        H = x.shape[-1]
+        with _lib.on_device(x.device):
+            _lib.check(_lib.lib().vmlmf_dropout_apply(x.numel() // H, H, _ptr(x), _ptr(y), float(p), snap.data_ptr(), int(site),
+                                                      _lib.raw_stream(x.device)))
+        ctx.save_for_backward(snap)
+        ctx.p, ctx.site = float(p), int(site)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (snap,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        H = dy.shape[-1]
+        with _lib.on_device(dy.device):
+            _lib.check(_lib.lib().vmlmf_dropout_apply(dy.numel() // H, H, _ptr(dy), _ptr(dx), ctx.p, snap.data_ptr(), ctx.site,
+                                                      _lib.raw_stream(dy.device)))
+        return dx, None, None, None
+
+
+def dropout(x, p, snap, site):
+    """nn.Dropout(p)(x) in training mode with the package's generator: x (..., H) float32 on a HIP device."""
+    if p <= 0.0:
+        return x
+    if x.dtype != torch.float32:
+        raise RuntimeError("vmlmf_amd.dropout: float32 activations")
+    return DropoutFn.apply(x, p, snap, site)
+
+
+def dropout_factors(rows, H, p, snap, site, layer_desc=None):
+    """The (rows, H) factors (0 or 1/(1-p)) the kernels apply for (snapshot, site) - for a layer whose launches apply them
+    themselves pass its descriptor (vmlmf_dropout_factors).  Tests: an oracle multiplies by this tensor."""
+    out = torch.empty((rows, H), device=snap.device, dtype=torch.float32)
+    with _lib.on_device(snap.device):
+        _lib.check(_lib.lib().vmlmf_dropout_factors(None if layer_desc is None else ctypes.byref(layer_desc), rows, H, float(p),
+                                                     snap.data_ptr(), int(site), out.data_ptr(), _lib.raw_stream(snap.device)))
+    return out
+
+
+class EmbedDropFn(torch.autograd.Function):
+    """dropout(w[tokens]) of vmlmf_lm.py:434-435 as one gather launch; backward: EmbedFn's scatter-add with the factors regenerated
+    on the fly."""
+
+    @staticmethod
+    def forward(ctx, w, tokens, p, snap, site):
+        V, H = w.shape
+        tok = tokens.reshape(-1).contiguous()
+        out = torch.empty(tuple(tokens.shape) + (H,), device=w.device, dtype=torch.float32)
+        with _lib.on_device(w.device):
+            _lib.check(_lib.lib().vmlmf_embed_dropout_forward(tok.numel(), H, V, _ptr(tok), _ptr(w), _ptr(out), float(p), snap.data_ptr(),
+                                                              int(site), _lib.raw_stream(w.device)))
+        ctx.save_for_backward(tok, snap)
+        ctx.wshape, ctx.p, ctx.site = w.shape, float(p), int(site)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, snap = ctx.saved_tensors
+        V, H = ctx.wshape
+        dy2 = dy.reshape(-1, H).contiguous()
+        R = dy2.shape[0]
+        dw = torch.empty((V, H), device=dy.device, dtype=torch.float32)
+        lib = _lib.lib()
+        nbytes = lib.vmlmf_embed_backward_scratch_bytes(R, V)
+        scratch = _embed_scratch(dy.device, nbytes)
+        with _lib.on_device(dy.device):
+            _lib.check(lib.vmlmf_embed_dropout_backward(R, H, V, _ptr(tok), _ptr(dy2), _ptr(dw), scratch.data_ptr(), nbytes, ctx.p,
+                                                        snap.data_ptr(), ctx.site, _lib.raw_stream(dy.device)))
+        return dw, None, None, None, None
+
+
+def _embed_scratch(dev, nbytes):
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    key = ("embed", dev.index, _lib.raw_stream(dev).value)
+    scratch = _WORKSPACE.get(key)
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = _WORKSPACE[key] = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    return scratch
+
+
+def _embed_covered(weight, tokens):
+    return (weight.is_cuda and weight.dtype == torch.float32 and weight.dim() == 2 and weight.shape[1] <= 1024 and tokens.dtype == torch.int64
+            and weight.is_contiguous() and weight.shape[0] * ((tokens.numel() + 31) // 32) * 4 <= (64 << 20))
+
+
+def embedding_dropout(weight, tokens, p, snap, site=0):
+    """dropout(weight[tokens]) - the first two lines of Model.forward (vmlmf_lm.py:434-435) - as one launch per direction on HIP fp32
+    tables whose width is a multiple of four; embedding() followed by dropout() otherwise."""
+    if p <= 0.0:
+        return embedding(weight, tokens)
+    if _embed_covered(weight, tokens) and weight.shape[1] % 4 == 0:
+        return EmbedDropFn.apply(weight, tokens, p, snap, site)
+    return dropout(embedding(weight, tokens), p, snap, site)
 
 
 def embedding(weight, tokens):

@@ -47,18 +47,21 @@ class MyVMLSTM(nn.Module):
     def kernel_params(self):
         return (self.dia_x, self.dia_h, self.u_x, self.w_x, self.b_x, self.b_h, self.u_h, self.w_h)
 
-    def _run(self, x, h, c):
+    def _run(self, x, h, c, drop=None):
         return vmlmf_sequence(self.variant, x, h, c, self.kernel_params(), self.w_rank, [self.u_ranks],
-                              g=1, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
+                              g=1, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None),
+                              drop=drop)
 
     def lstm_step(self, x, h, c):
         """One timestep (vmlmf_lm.py:222-269): T = 1 of the sequence kernels."""
         _, hn, cn = self._run(x.unsqueeze(0), h, c)
         return hn, cn
 
-    def forward(self, x, states):
+    def forward(self, x, states, drop=None):
+        """drop = (p, snapshot, site): the returned y went through Model's dropout (vmlmf_lm.py:438-439) - inside this layer's own
+        launches where the library covers it (functional.vmlmf_sequence)."""
         h, c = states
-        y, hT, cT = self._run(x, h, c)
+        y, hT, cT = self._run(x, h, c, drop)
         return y, (hT, cT)
 
 
@@ -94,17 +97,20 @@ class MyVMLSTMGroup(nn.Module):
             out += [self.u_h[s], self.v_h[s]]
         return tuple(out)
 
-    def _run(self, x, h, c):
+    def _run(self, x, h, c, drop=None):
         return vmlmf_sequence(self.variant, x, h, c, self.kernel_params(), self.w_rank, list(self.u_ranks),
-                              g=self.g, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None))
+                              g=self.g, time_major=True, dtype=getattr(self, "compute_dtype", "f32"), pack_cache=getattr(self, "_pack_cache", None),
+                              drop=drop)
 
     def lstm_step(self, x, h, c):
         _, hn, cn = self._run(x.unsqueeze(0), h, c)
         return hn, cn
 
-    def forward(self, x, states):
+    def forward(self, x, states, drop=None):
+        """drop = (p, snapshot, site): the returned y went through Model's dropout (vmlmf_lm.py:438-439) - inside this layer's own
+        launches where the library covers it (functional.vmlmf_sequence)."""
         h, c = states
-        y, hT, cT = self._run(x, h, c)
+        y, hT, cT = self._run(x, h, c, drop)
         return y, (hT, cT)
 
 
@@ -260,7 +266,22 @@ class Model(nn.Module):
         return lm_head_loss(h, self.fc.w, self.fc.b, y), states
 
     def features(self, x, states):
-        """Everything of forward() in front of the vocabulary projection (vmlmf_lm.py:434-439): (T, B, H) activations, states."""
+        """Everything of forward() in front of the vocabulary projection (vmlmf_lm.py:434-439): (T, B, H) activations, states.
+        Training with p > 0 on a HIP device: the three dropouts run without mask tensors (functional.dropout_*: Philox factors
+        regenerated in the backward) - the embedding's inside its gather, a VMLMF layer's inside the layer's launches; with
+        self.stock_dropout = True they are nn.Dropout's launches as in the reference."""
+        p = self.dropout.p
+        if self.training and p > 0 and x.is_cuda and not getattr(self, "stock_dropout", False):
+            from .functional import dropout, dropout_advance, embedding_dropout
+            snap = dropout_advance(self.dropout_state())
+            x = embedding_dropout(self.embed.w, x, p, snap, 0)
+            for i, rnn in enumerate(self.rnns):
+                if isinstance(rnn, (MyVMLSTM, MyVMLSTMGroup)):
+                    x, states[i] = rnn(x, states[i], drop=(p, snap, i + 1))
+                else:
+                    x, states[i] = rnn(x, states[i])
+                    x = dropout(x, p, snap, i + 1)
+            return x, states
         x = self.embed(x)
         x = self.dropout(x)
         stacked = self._stack(x, states)
@@ -274,3 +295,13 @@ class Model(nn.Module):
                 x, states[i] = rnn(x, states[i])
                 x = self.dropout(x)
         return x, states
+
+    def dropout_state(self, seed=None):
+        """{seed, offset} of this model's dropout generator on its device (created on first use; seed=None draws it from torch's CPU
+        generator).  Create it BEFORE capturing a training step into a hipGraph (any eager warm-up step does)."""
+        dev = self.embed.w.device
+        st = getattr(self, "_drop_state", None)
+        if st is None or st.device != dev or seed is not None:
+            from .functional import dropout_state
+            st = self._drop_state = dropout_state(dev, seed)
+        return st
