@@ -725,6 +725,49 @@ def main():
             log(f"training-step capture failed ({type(e).__name__}: {e})")
             torch.cuda.synchronize()
 
+    # what a maintainer's loop gets (verdict r4 item 7), one GPU, after everything the metric needs has been measured - these
+    # loops move the parameters: (a) train.py:47,58-65 as written - eager launches, nn.CrossEntropyLoss, torch.optim.Adam; (b) the
+    # same loop with the package's pieces, still eager (host-bound: ~20 Python-level calls per step); (c) the two-line opt-in of
+    # vmlmf_amd.optim.Adam + GraphedTrainStep (every step through its __call__, input copies included)
+    harness = None
+    if world == 1 and not args.no_extra:
+        def loop_ms(body, n=100):
+            for _ in range(10):
+                body()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(n):
+                body()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t1) / n * 1e3
+        try:
+            crit_t, opt_t = torch.nn.CrossEntropyLoss(), torch.optim.Adam(net.parameters(), lr=0.002)
+
+            def literal():
+                opt_t.zero_grad()
+                loss = crit_t(net(x), tgt)
+                loss.backward()
+                opt_t.step()
+            literal_ms = loop_ms(literal)
+            opt_p = vmlmf_amd.optim.Adam(net.parameters(), lr=0.002)
+
+            def eager_pkg():
+                opt_p.zero_grad(set_to_none=True)
+                loss = net.loss(x, tgt)
+                loss.backward(one)
+                opt_p.step()
+            eager_pkg_ms = loop_ms(eager_pkg)
+            gstep = vmlmf_amd.GraphedTrainStep(net, vmlmf_amd.CrossEntropyLoss(), vmlmf_amd.optim.Adam(net.parameters(), lr=0.002), x, tgt)
+            optin_ms = loop_ms(lambda: gstep(x, tgt))
+            harness = {"unchanged_loop_ms": round(literal_ms, 4), "unchanged_loop": "train.py:47,58-65 as written: eager launches, nn.CrossEntropyLoss, torch.optim.Adam",
+                       "eager_package_loop_ms": round(eager_pkg_ms, 4), "eager_package_loop": "eager launches, Net.loss, vmlmf_amd.optim.Adam",
+                       "two_line_opt_in_ms": round(optin_ms, 4), "two_line_opt_in": "vmlmf_amd.optim.Adam + vmlmf_amd.GraphedTrainStep called per batch (INTEGRATION.md section 1)",
+                       "recaptures": getattr(gstep, "recaptures", 0)}
+            del gstep
+        except Exception as e:
+            log(f"harness loops failed ({type(e).__name__}: {e})")
+            torch.cuda.synchronize()
+
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     tmin = tmax.clone()
     if collective:
@@ -798,6 +841,12 @@ def main():
             # + fused Adam in one graph: packs every step by construction) - config.workload says which one `value` is
             ("ms_per_step_repack" if args.keep_images else "ms_per_step_kept_images"): None if alt_ms is None else round(alt_ms, 4),
             "train_step_ms": None if train_step_ms is None else round(train_step_ms, 4),
+            "harness": harness,
+            # the riding weight-gradient workers at the end of the run: False when VMLMF_WRIDE=0 / vmlmf_tune("wride", 0) switched them
+            # off or a launch gave up a bounded wait on a shared GPU and the library fell back to the stand-alone kernel (then
+            # ms_per_step is that form's, not a regression of the riding one)
+            "riding_workers": {"armed": bool(_lib.tune_get("wride")), "stand_alone_weight_gradient_launch_in_step": kern.get("wgrad_mfma_kernel", 0.0) > 0.0,
+                               "status": lib.vmlmf_check_status()},
             "ms_per_step_min_over_ranks": round(dt_min / args.steps * 1e3, 4),
             "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32",

@@ -179,6 +179,10 @@ int vmlmf_seq_backward_packed(const vmlmf_desc *d, const vmlmf_params *p, const 
                               const vmlmf_grads *g, void *workspace, size_t workspace_bytes, void *stream,
                               const void *packed);
 int vmlmf_tune_generation(void);
+/* ABI 11: the current value of a vmlmf_tune switch.  "wride" reads 0 while the riding weight-gradient workers are off - by
+ * VMLMF_WRIDE=0, by vmlmf_tune("wride", 0), or because a launch gave up a bounded wait (VMLMF_E_PROTOCOL) and the library fell back
+ * to the stand-alone kernel: a benchmark reports it, so a shared GPU cannot pass for a regression. */
+int vmlmf_tune_get(const char *key, int *value);
 
 /*
  * Classifier riding on a layer (ABI 6): Net applies nn.Linear(H, 18) to the last layer's final hidden state

@@ -176,3 +176,9 @@ def test_every_documented_kernel_switch_is_accepted():
     # the measured-no-gain forms of round 4 left the product library (tools/experiments/*.patch): their switches are gone with them
     for k in (b"inrow_rows", b"rb_wgrad", b"rb_xfold"):
         assert lib.vmlmf_tune(k, 0) == _lib.E_BADARG, k
+    # ABI 11: the switches read back (a benchmark reports whether the riding workers were armed)
+    assert lib.vmlmf_tune(b"wride", 0) == 0 and _lib.tune_get("wride") == 0
+    assert lib.vmlmf_tune(b"wride", 1) == 0 and _lib.tune_get("wride") == (0 if os.environ.get("VMLMF_WRIDE") == "0" else 1)
+    assert lib.vmlmf_tune(b"rec3", 7) == 0 and _lib.tune_get("rec3") == 7 and lib.vmlmf_tune(b"rec3", 6) == 0
+    import ctypes
+    assert lib.vmlmf_tune_get(b"no_such_switch", ctypes.byref(ctypes.c_int(0))) == _lib.E_BADARG

@@ -8,9 +8,10 @@ MI355X (gfx950), behind the reference's own nn.Module API.
 from .cells import MyVMLMFCell, MyVMLMFCellg2, MyVMLMFgCellg2, MyLSTMCell, MyLSTM, Net, TIME_STEPS, RECURRENT_MAX, RECURRENT_MIN
 from .lm import MyVMLSTM, MyVMLSTMGroup, Embed, Linear, LSTM, Model
 from .functional import (vmlmf_sequence, vmlmf_stack, head_linear, cross_entropy, CrossEntropyLoss, nll_loss, linear_nll, lm_head_loss, embedding, unit_gradient,
-                         set_compute_dtype, cache_packed_parameters)
+                         set_compute_dtype, cache_packed_parameters, dropout, dropout_state, dropout_advance, embedding_dropout)
 from . import optim
 from .graphed import GraphedTrainStep
 
 __all__ = ["GraphedTrainStep", "vmlmf_stack", "optim", "head_linear", "cross_entropy", "CrossEntropyLoss", "MyVMLMFCell", "MyVMLMFCellg2", "MyVMLMFgCellg2", "MyLSTMCell", "MyLSTM", "Net", "MyVMLSTM", "MyVMLSTMGroup",
-           "Embed", "Linear", "LSTM", "Model", "nll_loss", "linear_nll", "lm_head_loss", "embedding", "unit_gradient", "vmlmf_sequence"]
+           "Embed", "Linear", "LSTM", "Model", "nll_loss", "linear_nll", "lm_head_loss", "embedding", "unit_gradient", "vmlmf_sequence", "dropout", "dropout_state", "dropout_advance",
+           "embedding_dropout"]

@@ -109,6 +109,7 @@ SYMBOLS = {
     "vmlmf_seq_backward_packed": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp, _vp, _vp, _vp, ctypes.POINTER(Params), _vp, _sz, _vp, _vp]),
     "vmlmf_tune_generation": (_i, []),
+    "vmlmf_tune_get": (_i, [ctypes.c_char_p, ctypes.POINTER(_i)]),
     "vmlmf_seq_forward_ex": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _vp, _sz, _vp, ctypes.POINTER(Extra)]),
     "vmlmf_seq_backward_ex": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Params), _vp, _vp, _vp, _vp, _vp, _vp,
@@ -246,6 +247,13 @@ def make_desc(variant, B, T, I, H, w_rank, u_ranks, g=1, time_major=False, train
     d.training = 1 if training else 0
     d.dtype = DTYPES[dtype] if isinstance(dtype, str) else int(dtype)
     return d
+
+
+def tune_get(key):
+    """Current value of a vmlmf_tune switch ("wride": 0 while the riding workers are off or have tripped)."""
+    v = ctypes.c_int(0)
+    check(lib().vmlmf_tune_get(key.encode(), ctypes.byref(v)))
+    return v.value
 
 
 def query(desc):

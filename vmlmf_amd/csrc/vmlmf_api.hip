@@ -1311,6 +1311,24 @@ int vmlmf_tune(const char* key, int value) {
   return 0;
 }
 
+int vmlmf_tune_get(const char* key, int* value) {
+  if (key == nullptr || value == nullptr) return fail(VMLMF_E_BADARG, "tune_get: null pointer");
+  const std::string k(key);
+  if (k == "rb") *value = g_rb_mode;
+  else if (k == "rec3") *value = g_rec3;
+  else if (k == "inrow") *value = g_inrow;
+  else if (k == "adam_guard") *value = g_adam_guard;
+  else if (k == "wring") *value = g_wring;
+  else if (k == "direct") *value = g_direct;
+  else if (k == "finish2") *value = g_finish2;
+  else if (k == "wride") *value = (g_wride && g_wride_tripped.load() == 0) ? 1 : 0;   // 0 also after a bounded wait gave up (VMLMF_ST_WRIDE)
+  else if (k == "rb_min_batch") *value = g_rb_minB;
+  else if (k == "rb_cluster") *value = g_rb_S;
+  else if (k == "rb_rows") *value = g_rb_rows;
+  else return fail(VMLMF_E_BADARG, "tune_get: unknown key " + k);
+  return 0;
+}
+
 int vmlmf_profile_enable(int mask) {
   std::lock_guard<std::mutex> lk(g_prof.mu);
   g_prof.mask = (unsigned)mask;
