@@ -985,6 +985,7 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
     ride.a.x = wh.x, ride.a.y = wh.y, ride.a.h0 = wh.h0, ride.a.Qs = wh.Qs, ride.a.P = wh.wpart;
   } else {
     plan_wride(g, L, x, y, h0, rs, ws, &ride, s, p->v_x);
+    if (ride.K > 0 && !((g_rec3 & 2) && rec3_bwd_supported(g)) && !rec_bwd_rides(g)) memset(&ride, 0, sizeof(ride));
   }
   a.wr = ride;
   const bool direct = packed == nullptr && direct_ok(g, p);   // the forward of this call packed nothing

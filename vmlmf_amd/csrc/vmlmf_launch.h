@@ -146,6 +146,9 @@ int launch_rec_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_
 int launch_rec_bwd(const VGeo& g, const BwdArgs& a, hipStream_t s);
 // third form of the recurrent kernels (vmlmf_rec3.inc): one-group layers, padded hidden rank <= 16, <= 3 waves of units; the
 // forward also needs the x-projection wave's envelope (narrow input, x-fold).  Same tapes as the kernels above.
+// rec_bwd_kernel has a form with the riding weight-gradient workers for this layer (wider ranks / four waves of units: what
+// rec3_bwd_kernel does not cover)
+inline bool rec_bwd_rides(const VGeo& g) { return g.KH > 16 || g.W > 3; }
 bool rec3_fwd_supported(const VGeo& g);
 bool rec3_bwd_supported(const VGeo& g);
 int launch_rec3_fwd(const VGeo& g, const FwdArgs& a, const XwArgs& xw, hipStream_t s);

@@ -1104,7 +1104,7 @@ def dropout(x, p, snap, site):
 
 def dropout_factors(rows, H, p, snap, site, layer_desc=None):
     """The (rows, H) factors (0 or 1/(1-p)) the kernels apply for (snapshot, site) - for a layer whose launches apply them
-    themselves pass its descriptor (vmlmf_dropout_factors).  Tests: an oracle multiplies by this tensor."""
+    themselves pass its descriptor (vmlmf_dropout_factors).  The parity tests multiply a CPU restatement by this tensor."""
     out = torch.empty((rows, H), device=snap.device, dtype=torch.float32)
     with _lib.on_device(snap.device):
         _lib.check(_lib.lib().vmlmf_dropout_factors(None if layer_desc is None else ctypes.byref(layer_desc), rows, H, float(p),
