@@ -796,7 +796,7 @@ def main():
             raise KeyError(dom)
 
         b256 = strong and rows_gpu == 256
-        for name in (("r04_pmc_traffic_b256.json",) if b256 else ()) + ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in (("r05_pmc_traffic_b256.json", "r04_pmc_traffic_b256.json") if b256 else ()) + ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = prof_entry(pmc["kernels"])["hbm_bytes_per_launch"]
@@ -805,7 +805,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
-            util_file = next(f for f in ((("r04_pmc_util_b256.json",) if b256 else ()) + ("r04_pmc_util.json", "r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json"))
+            util_file = next(f for f in ((("r05_pmc_util_b256.json", "r04_pmc_util_b256.json") if b256 else ()) + ("r05_pmc_util.json", "r04_pmc_util.json", "r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json"))
                              if os.path.exists(os.path.join(ROOT, "profiles", f)))
             u = prof_entry(json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"])["derived"]
             util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
