@@ -363,7 +363,7 @@ size_t vmlmf_embed_backward_scratch_bytes(int R, int V);
  * vmlmf_dropout_factors   the factors as a (R, H) tensor, columns mapped as layer `d`'s fused kernels map them (d == NULL: as
  *                         vmlmf_dropout_apply / the embedding entry points do).
  * vmlmf_embed_dropout_forward   out[r] = weight[tokens[r]] * factor (vmlmf_lm.py:434-435 in one pass)
- * vmlmf_embed_dropout_backward  vmlmf_embed_backward on the gradient of that dropped output (H a multiple of four) */
+ * vmlmf_embed_dropout_backward  vmlmf_embed_backward on the gradient of that dropped output */
 int vmlmf_dropout_fused(const vmlmf_desc *d);
 int vmlmf_dropout_advance(int64_t *state, int64_t *snapshot, void *stream);
 int vmlmf_dropout_apply(int64_t R, int H, const float *x, float *y, float p, const int64_t *state, int site, void *stream);

@@ -116,10 +116,11 @@ def test_stand_alone_dropout_forward_and_backward(shape):
 
 
 @gpu
-@pytest.mark.parametrize("case", [(35, 8, 1000, 64), (11, 3, 50, 652), (5, 2, 9, 30)], ids=str)
+@pytest.mark.parametrize("case", [(35, 8, 1000, 64), (11, 3, 50, 652), (5, 2, 9, 30), (35, 16, 300, 650), (3, 2, 7, 33), (4, 1, 5, 1100)], ids=str)
 def test_embedding_with_dropout_vs_restatement(case):
     """vmlmf_lm.py:434-435 in one launch per direction: out = w[tokens] * F; dw = scatter-add of (dy * F) in position order.
-    (H = 30: not a multiple of four - the gather and the dropout are two launches, same values.)"""
+    (Widths that are not a multiple of four - the PTB network's 650 - take scalar accesses with the same one call per four columns;
+    H = 1100: beyond the embedding kernels' 1024 columns, the gather and the dropout are two launches - same values.)"""
     from vmlmf_amd.functional import embedding_dropout
     T, B, V, H = case
     r = np.random.Generator(np.random.PCG64(5))

@@ -1480,7 +1480,7 @@ int vmlmf_embed_dropout_backward(int R, int H, int V, const int64_t* tokens, con
   memset(&d, 0, sizeof(d));
   d.state = reinterpret_cast<const unsigned long long*>(state), d.thresh = drop_thresh(p), d.scale = 1.f / (1.f - p), d.site = site;
   const int rc = launch_embed_bwd(R, H, V, (const long long*)tokens, dy, dweight, scratch, scratch_bytes, (hipStream_t)stream, &d);
-  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "embed_dropout_backward: embedding width > 1024 or not a multiple of four");
+  if (rc == -3) return fail(VMLMF_E_UNSUPPORTED, "embed_dropout_backward: embedding width > 1024");
   if (rc == -4) return fail(VMLMF_E_WORKSPACE, "embed_backward: scratch smaller than vmlmf_embed_backward_scratch_bytes()");
   return rc == 0 ? 0 : fail(rc, hipGetErrorString((hipError_t)rc));
 }

@@ -36,20 +36,29 @@ __global__ void __launch_bounds__(256) drop_rows_kernel(long long R, int H, int 
   }
   float* dst = y + (size_t)r * H;
   const bool ident = cm.gstride == 0 || cm.Hg >= H;
-  if (ident && (H & 3) == 0) {
+  if (ident) {   // one call for the thread's four columns; 16-byte accesses where the rows allow them
     float f[4];
     drop_factors(k, d.thresh, d.scale, (unsigned)r, (unsigned)(n0 >> 2), f);
-    float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (MODE != 1) v = *reinterpret_cast<const float4*>(src + n0);
-    *reinterpret_cast<float4*>(dst + n0) = make_float4(v.x * f[0], v.y * f[1], v.z * f[2], v.w * f[3]);
+    if ((H & 3) == 0) {
+      float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (MODE != 1) v = *reinterpret_cast<const float4*>(src + n0);
+      *reinterpret_cast<float4*>(dst + n0) = make_float4(v.x * f[0], v.y * f[1], v.z * f[2], v.w * f[3]);
+    } else {   // (H = 650 of the PTB network: rows start 8 bytes off)
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (MODE != 1 && n0 + e < H) ? src[n0 + e] : 1.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + e < H) dst[n0 + e] = v[e] * f[e];
+    }
     return;
   }
-  // ragged widths and mapped columns: element by element (a call per element; the LM's widths take the path above)
+  // mapped columns (the factors a row-block layer's kernels apply, as a tensor): a call per element
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int n = n0 + e;
     if (n >= H) break;
-    const int col = ident ? n : (n / cm.Hg) * cm.gstride + n % cm.Hg;
+    const int col = (n / cm.Hg) * cm.gstride + n % cm.Hg;
     float f[4];
     drop_factors(k, d.thresh, d.scale, (unsigned)r, (unsigned)(col >> 2), f);
     const float fe = f[col & 3];

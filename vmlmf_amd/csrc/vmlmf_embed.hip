@@ -67,13 +67,14 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(int R, int H, int V, int
 
 // the same sum when the embedding's output went through dropout (vmlmf_lm.py:434-435): dy is the gradient of the DROPPED copy, and
 // the factor of every (position, column) is regenerated here (vmlmf_dropout.h) - no mask tensor, no pass of its own.  A lane owns
-// four neighbouring columns (one generator call), 256 columns per round: H a multiple of four, H <= 1024.
+// four neighbouring columns (one generator call), 256 columns per round: H <= 1024 (16-byte accesses when H is a multiple of four).
 __global__ __launch_bounds__(256) void embed_bwd_drop_kernel(int R, int H, int V, int words, const unsigned* __restrict__ bits,
                                                              const float* __restrict__ dy, float* __restrict__ dW, DropArgs d) {
   const int lane = threadIdx.x & 63;
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (v >= V) return;
   const DropKey key = drop_key(d);
+  const bool vec = (H & 3) == 0;
   const unsigned* brow = bits + (size_t)v * words;
   float4 acc[4];
 #pragma unroll
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(256) void embed_bwd_drop_kernel(int R, int H, int V
           if (col < H) {
             float f[4];
             drop_factors(key, d.thresh, d.scale, (unsigned)p, (unsigned)(col >> 2), f);
-            const float4 g = *reinterpret_cast<const float4*>(row + col);
+            float4 g;
+            if (vec) g = *reinterpret_cast<const float4*>(row + col);
+            else g = make_float4(row[col], col + 1 < H ? row[col + 1] : 0.f, col + 2 < H ? row[col + 2] : 0.f, col + 3 < H ? row[col + 3] : 0.f);
             acc[c].x += g.x * f[0], acc[c].y += g.y * f[1], acc[c].z += g.z * f[2], acc[c].w += g.w * f[3];
           }
         }
@@ -108,7 +111,15 @@ __global__ __launch_bounds__(256) void embed_bwd_drop_kernel(int R, int H, int V
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const int col = 4 * lane + 256 * c;
-    if (col < H) *reinterpret_cast<float4*>(out + col) = acc[c];
+    if (col >= H) continue;
+    if (vec) {
+      *reinterpret_cast<float4*>(out + col) = acc[c];
+    } else {
+      out[col] = acc[c].x;
+      if (col + 1 < H) out[col + 1] = acc[c].y;
+      if (col + 2 < H) out[col + 2] = acc[c].z;
+      if (col + 3 < H) out[col + 3] = acc[c].w;
+    }
   }
 }
 
@@ -118,7 +129,7 @@ size_t embed_bwd_scratch_bytes(int R, int V) { return (size_t)V * (size_t)((R + 
 
 int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* dy, float* dW, void* scratch, size_t scratch_bytes,
                      hipStream_t s, const DropArgs* drop) {
-  if (H > 64 * EMB_C || (drop != nullptr && (H & 3) != 0)) return -3;
+  if (H > 64 * EMB_C) return -3;
   const int words = (R + 31) / 32;
   const size_t need = embed_bwd_scratch_bytes(R, V);
   if (scratch == nullptr || scratch_bytes < need) return -4;

@@ -1161,10 +1161,10 @@ def _embed_covered(weight, tokens):
 
 def embedding_dropout(weight, tokens, p, snap, site=0):
     """dropout(weight[tokens]) - the first two lines of Model.forward (vmlmf_lm.py:434-435) - as one launch per direction on HIP fp32
-    tables whose width is a multiple of four; embedding() followed by dropout() otherwise."""
+    tables up to 1024 wide; embedding() followed by dropout() otherwise."""
     if p <= 0.0:
         return embedding(weight, tokens)
-    if _embed_covered(weight, tokens) and weight.shape[1] % 4 == 0:
+    if _embed_covered(weight, tokens):
         return EmbedDropFn.apply(weight, tokens, p, snap, site)
     return dropout(embedding(weight, tokens), p, snap, site)
 
