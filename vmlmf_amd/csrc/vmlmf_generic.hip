@@ -340,8 +340,14 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // (rows 12 KB apart); the BT instantiations stay for A/B runs (VMLMF_SKINNY=4).
 // NSUB: 16-column sub-tiles per workgroup (2: a 16 x 32 tile whose two MFMA chains share the A operand -- for tall
 // products such as dqx = dpre VxT (8960 x 32, K = 3072), where A is the 110 MB operand and should be read once).
-template <int NWV, bool BT, int SK_CH, int NSUB>
+// BMODE 0: B is K x N row-major; 1 (BT): `B` points at B^T; 2: B "quad-interleaved" along k, [k / 4][n][k % 4] (ldb = N): the four
+// contraction steps a lane feeds from one 16-byte load of A get their B values from one 16-byte load too, sixteen lanes' loads
+// contiguous (256 bytes) - with the row-major B every one of them was a dword load of its own, 96 of 108 load instructions of a
+// batch (dqx = dpre VxT of the H = 650 layers: 58 -> 50.5 us; batches of 6 or 4 blocks and four instead of
+// eight waves measured the same within 4 us: what is left is the 64-byte row segments of A, rows 12 KB apart)
+template <int NWV, int BMODE, int SK_CH, int NSUB>
 __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
+  constexpr bool BT = BMODE == 1;
   __shared__ float4 red[NSUB][NWV - 1][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
   constexpr int TN = 16 * NSUB;
@@ -366,7 +372,7 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
   for (int u = 0; u < NSUB; ++u) {
     col_ok[u] = n0 + 16 * u + r < a.N;
     const int c = col_ok[u] ? n0 + 16 * u + r : 0;
-    Bp[u] = BT ? a.B + (long long)c * a.ldb : a.B + c;
+    Bp[u] = BT ? a.B + (long long)c * a.ldb : (BMODE == 2 ? a.B + (long long)c * 4 : a.B + c);
   }
   const float* Ap = a.A + (long long)(row_ok ? m0 + r : 0) * a.lda;
   f32x4v acc[NSUB];
@@ -399,7 +405,10 @@ __global__ void __launch_bounds__(NWV * 64) gemm_skinny_kernel(GemmArgs a) {
         }
 #pragma unroll
         for (int u = 0; u < NSUB; ++u) {
-          if (BT && BV) {
+          if (BMODE == 2) {   // (K a multiple of four, k too: a quad is entirely inside or outside the slice)
+            const float4 t = ld4(Bp[u] + (long long)((k < kb1 ? k : 0) >> 2) * a.ldb * 4);
+            bv[u][c][0] = t.x, bv[u][c][1] = t.y, bv[u][c][2] = t.z, bv[u][c][3] = t.w;
+          } else if (BT && BV) {
             const float4 t = ld4(Bp[u] + (k < kb1 ? k : 0));
             bv[u][c][0] = t.x, bv[u][c][1] = t.y, bv[u][c][2] = t.z, bv[u][c][3] = t.w;
           } else if (BT) {
@@ -555,9 +564,9 @@ static int launch_dq_split(const float* dpre_t, long long lda, const float* VdT,
   a.zstride = (long long)B * GK;
   const int t16 = ((B + 15) / 16) * ((GK + 15) / 16);
   if (K / DQ_ZS >= 1536)
-    hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
   else
-    hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 8, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 8, 1>), dim3(t16, DQ_ZS), dim3(512), 0, s, a);
   return (int)hipGetLastError();
 }
 
@@ -608,7 +617,7 @@ static int launch_dhrec(const float* part, int GK, const float* UdT, int H, floa
 // Bt / ldbt: the same factor stored transposed (N x K), or nullptr
 static int gemm(const float* A, long long lda, const float* B, long long ldb, float* C, long long ldc, int M, int N,
                 int K, float* part, long long part_cap, int* ticket, int ticket_cap, hipStream_t s,
-                const float* Bt = nullptr, long long ldbt = 0, int epi = 0, const EpiArgs* ea = nullptr) {
+                const float* Bt = nullptr, long long ldbt = 0, int epi = 0, const EpiArgs* ea = nullptr, bool bquad = false) {
   GemmArgs a{A, lda, B, ldb, C, ldc, M, N, K, part, ticket};
   static bool raised = false;
   if (!raised) {   // 69 KB of dynamic LDS
@@ -617,6 +626,16 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
       if (e != hipSuccess) return (int)e;
     }
     raised = true;
+  }
+  if (bquad) {   // B is [k / 4][n][k % 4] (the caller's image; K and lda multiples of four): always the skinny kernel (VMLMF_SKINNY has
+                 // no row-major image to fall back to)
+    if (N > 128 || K % 4 != 0 || lda % 4 != 0) return -3;
+    const int t16 = ((M + 15) / 16) * ((N + 15) / 16);
+    if (N % 32 == 0 && t16 >= 1024)
+      hipLaunchKernelGGL((gemm_skinny_kernel<8, 2, 12, 2>), dim3(t16 / 2), dim3(512), 0, s, a);
+    else
+      hipLaunchKernelGGL((gemm_skinny_kernel<8, 2, 12, 1>), dim3(t16), dim3(512), 0, s, a);
+    return (int)hipGetLastError();
   }
   if (epi == 2 || epi == 3) {   // 16 x 64 tiles, operands straight into MFMA layout; 2: gate derivatives as the epilogue
     const int t16 = ((M + 15) / 16) * ((N + 63) / 64);
@@ -639,16 +658,16 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
     if (Bt != nullptr && g_skinny_mode == 4) {   // both operands along k (measured slower: rows 12 KB apart)
       a.B = Bt, a.ldb = ldbt;
       if (K >= 1536)
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, true, 12, 1>), dim3(t16), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, 1, 12, 1>), dim3(t16), dim3(512), 0, s, a);
       else
-        hipLaunchKernelGGL((gemm_skinny_kernel<4, true, 12, 1>), dim3(t16), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<4, 1, 12, 1>), dim3(t16), dim3(256), 0, s, a);
     } else if (K >= 1536) {
       if (N % 32 == 0 && t16 >= 1024)   // tall: plenty of tiles, read A once per pair of column tiles
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 2>), dim3(t16 / 2), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 2>), dim3(t16 / 2), dim3(512), 0, s, a);
       else
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 12, 1>), dim3(t16), dim3(512), 0, s, a);
+        hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 1>), dim3(t16), dim3(512), 0, s, a);
     } else {
-      hipLaunchKernelGGL((gemm_skinny_kernel<8, false, 8, 1>), dim3(t16), dim3(512), 0, s, a);
+      hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 8, 1>), dim3(t16), dim3(512), 0, s, a);
     }
     return (int)hipGetLastError();
   }
@@ -857,8 +876,9 @@ int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s) {
   const int B = g.B, NT = g.NT, T = g.T;
   int rc;
   // dqx over all rows, then dx
+  // (w.VxT is the quad-interleaved image [slot][r][gate]: pack_kernel)
   if ((rc = gemm(w.dpre, (long long)NT * 4, w.VxT, g.KX, w.dqx, g.KX, T * B, g.KX, NT * 4, w.part, w.part_cap, w.ticket,
-                 w.ticket_cap, s)) != 0)
+                 w.ticket_cap, s, nullptr, 0, 0, nullptr, true)) != 0)
     return rc;
   if (w.dx != nullptr) {
     const dim3 dgrid((unsigned)((T * B + DXR - 1) / DXR));

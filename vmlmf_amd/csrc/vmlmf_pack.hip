@@ -201,12 +201,13 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
           j = c / g.KH; rr = c - j * g.KH; k = i & 3;
           if (vg_slot_unit(g, i >> 2, n)) mode = 2; else n = -1;
         }
-      } else if (e < L.TKT) {   // VXTT[slot*4+k][r]
+      } else if (e < L.TKT) {   // VXTT[slot][r][k]: V_x^T with the four gates of a slot side by side - the B operand of dqx = dpre VxT
+                                //  as ONE 16-byte load per lane and four contraction steps (gemm_skinny_kernel, BMODE 2)
         const int le = e - (int)L.VXTT;
         if (le < N4 * g.KX) {
-          const int i = le / g.KX;
-          rr = le - i * g.KX; k = i & 3;
-          if (vg_slot_unit(g, i >> 2, n)) mode = 3; else n = -1;
+          const int sl = le / (4 * g.KX), rem = le - sl * 4 * g.KX;
+          rr = rem >> 2; k = rem & 3;
+          if (vg_slot_unit(g, sl, n)) mode = 3; else n = -1;
         }
       } else if (e >= L.WXD) {  // WXD: dot workgroups
         if (e - (int)L.WXD < D.nWXD) continue;
