@@ -182,3 +182,13 @@ def test_every_documented_kernel_switch_is_accepted():
     assert lib.vmlmf_tune(b"rec3", 7) == 0 and _lib.tune_get("rec3") == 7 and lib.vmlmf_tune(b"rec3", 6) == 0
     import ctypes
     assert lib.vmlmf_tune_get(b"no_such_switch", ctypes.byref(ctypes.c_int(0))) == _lib.E_BADARG
+
+
+def test_the_product_library_stays_pruned():
+    """Verdict r4 item 6: no probe-only / unreachable instantiations in the shipped library - under 9 MB, and none of the ablation
+    template parameters' names in its kernel symbols."""
+    import subprocess
+    size = os.path.getsize(_lib.LIB_PATH)
+    assert size < 9_000_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
+    out = subprocess.run(["strings", "-n", "12", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "VMLMF_R4_ABL" not in out and "VMLMF_WRIDE_DRY" not in out

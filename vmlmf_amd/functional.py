@@ -1050,6 +1050,9 @@ def dropout_state(device, seed=None):
     torch.manual_seed() makes the masks repeatable."""
     if seed is None:
         seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        # data-parallel replicas seeded alike (torch.manual_seed(s) on every rank) still draw different masks for their shards
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            seed = (seed + torch.distributed.get_rank() * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
     return torch.tensor([int(seed), 0], dtype=torch.int64, device=device)
 
 
