@@ -81,3 +81,34 @@ def test_one_rank_self_tests_of_the_rccl_paths():
     c = j["config"]
     assert c["allreduce_transport"].startswith("cabi") and c["exchange_ranks"] == 1 and c["collectives_per_step"] == 5
     assert j["reduced_grad_norm_equal_across_ranks"] is True and 8.0 < j["loss_per_token"] < 10.5
+
+
+def test_the_default_single_gpu_line_keeps_its_contract():
+    """`python bench.py` as the driver runs it at N = 1 (shortened): ONE JSON line with the graded fields, the roofline and
+    cpu_baseline objects, the round-5 additions (harness, riding_workers) - and the headline step as three launches: no pack /
+    criterion / reduce / finish launch in the per-kernel breakdown, the finishing launch present."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5"],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 30 and j["warmup"] == 5 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["dtype"] == "f32" and j["data"] == "synthetic" and "configs[1]" in j["config"]["workload"] and j["value"] > 0
+    assert abs(j["value"] - 128 * 1e3 / j["ms_per_step"]) <= 1e-3 * j["value"]          # 64-row batches x T per second
+    rf = j["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] in ("GB/s", "TFLOP/s") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-4
+    assert rf["traffic"] is None or rf["traffic"] > 0
+    cb = j["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    k = j["kernels_us"]
+    assert k["pack_kernel"] == 0 and k["ce_fwd_kernel"] == 0 and k["reduce_cg_kernel"] == 0 and k["finish_kernel"] == 0, k
+    assert k["rec_fwd_kernel"] > 0 and k["rec_bwd_kernel"] > 0 and k["finish2_kernel"] > 0, k
+    h = j["harness"]
+    assert h["two_line_opt_in_ms"] < h["eager_package_loop_ms"] <= h["unchanged_loop_ms"] * 1.05, h
+    rw = j["riding_workers"]
+    assert rw["armed"] is True and rw["stand_alone_weight_gradient_launch_in_step"] is False and rw["status"] == 0, rw
