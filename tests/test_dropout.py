@@ -357,3 +357,38 @@ def test_a_captured_training_step_draws_fresh_factors_on_every_replay():
     # ... and each equals the eager step at the same offset
     st[1] = off0 + 1
     assert abs(step().item() - losses[1]) <= 1e-6 * abs(losses[1])
+
+
+@gpu
+def test_config_e_layer_at_full_size_drop_equals_the_undropped_layer_times_the_factors_bit_for_bit():
+    """BASELINE configs[4]'s own size (B 256, T 35, H 650, ranks 32 / [32, 32]) - too large for the fp64 oracle in a test, so the
+    size-independent property: the fused layer's y_dropped IS (the same layer's y) * factors, and its gradients ARE the
+    undropped layer's gradients for the upstream gradient dy * factors - the same kernels with one multiplication moved, every
+    bit equal; the factors at that size have the asked rate."""
+    from hip_util import ORDER
+    from vmlmf_amd import vmlmf_sequence, _lib
+    from vmlmf_amd.functional import dropout_factors
+    variant, g, B, T, H, rw, ru, p = O.V4, 2, 256, 35, 650, 32, [32, 32], 0.5
+    desc = _rb_desc(variant, B, T, H, rw, ru, g)
+    assert _lib.lib().vmlmf_dropout_fused(desc) == 1
+    P = O.make_params(variant, H, H, rw, ru, seed=77, scale=0.05)
+    torch.manual_seed(3)
+    x = 0.5 * torch.randn(T, B, H, device="cuda")
+    h0, c0 = 0.3 * torch.randn(B, H, device="cuda"), 0.3 * torch.randn(B, H, device="cuda")
+    dy, dhT, dcT = torch.randn(T, B, H, device="cuda"), torch.randn(B, H, device="cuda"), torch.randn(B, H, device="cuda")
+    snap = _state(SEED, 2024)
+    F = dropout_factors(T * B, H, p, snap, 1, layer_desc=desc).reshape(T, B, H)
+    assert abs((F == 0).double().mean().item() - p) < 5 * (0.25 / F.numel()) ** 0.5
+
+    def run(drop, upstream):
+        params = [torch.tensor(np.asarray(P[k]), device="cuda").requires_grad_(True) for k in ORDER[variant]]
+        xg, h0g, c0g = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        y, hT, cT = vmlmf_sequence(variant, xg, h0g, c0g, params, rw, ru, g=g, time_major=True, drop=drop)
+        ((y * upstream).sum() + (hT * dhT).sum() + (cT * dcT).sum()).backward()
+        return y.detach(), hT.detach(), cT.detach(), [xg.grad, h0g.grad, c0g.grad] + [q.grad for q in params]
+
+    yd, hTd, cTd, gd = run((p, snap, 1), dy)
+    y, hT, cT, gu = run(None, dy * F)
+    assert torch.equal(yd, y * F) and torch.equal(hTd, hT) and torch.equal(cTd, cT)
+    for a, b in zip(gd, gu):
+        assert torch.equal(a, b)

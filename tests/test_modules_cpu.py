@@ -165,6 +165,13 @@ def test_lm_network_surface_matches_reference():
     with pytest.raises(TypeError):
         Model(V, H, L, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vmgroup")
     assert type(Model(V, H, 1, 0.0, 0.1, w_rank=rw, u_ranks=[2, 2], lstm_type="vm_group").rnns[0]) is torch.nn.LSTM
+    # ... and the package's own way to the group network the reference cannot construct (not part of the reference's interface)
+    from vmlmf_amd import MyVMLSTMGroup
+    mg = Model.with_group_layers(V, H, 2, 0.5, 0.1, w_rank=rw, u_ranks=[2, 3])
+    assert all(type(r) is MyVMLSTMGroup for r in mg.rnns) and mg.lstm_type == "vmgroup" and mg.dropout.p == 0.5
+    assert mg.rnns[1].u_h[1].shape == (2, H // 2, 3) and mg.rnns[0].v_h[0].shape == (2, 2, 4 * (H // 2))
+    assert all(float(p.abs().max()) <= 0.1 and float(p.abs().max()) > 0 for p in mg.parameters())
+    assert [tuple(s.shape) for s in mg.state_init(3)[0]] == [(3, H), (3, H)]
     # dense_layer= overrides the class built for lstm_type="custom" (default: vmlmf_amd.LSTM, tested against the reference below)
 
     class Dense(torch.nn.Module):          # stand-in with the reference's layer interface

@@ -216,6 +216,20 @@ class Model(nn.Module):
         for param in self.parameters():
             nn.init.uniform_(param, -self.winit, self.winit)
 
+    @classmethod
+    def with_group_layers(cls, vocab_size, hidden_size, layer_num, dropout, winit, w_rank, u_ranks, g=2):
+        """The network of BASELINE configs[4] - Model with MyVMLSTMGroup layers - which the reference's constructor cannot build
+        (lstm_type "vmgroup" reduces the rank list to its last element and MyVMLSTMGroup then fails, vmlmf_lm.py:387-392; "vm_group",
+        the CLI's spelling, builds nn.LSTM).  NOT part of the reference's interface: the constructor above keeps the reference's
+        behaviour, this puts the group layers in by hand (as a maintainer has to) and initialises every parameter as
+        Model.reset_parameters does.  u_ranks: one rank per group rotation, e.g. [32, 32]."""
+        model = cls(vocab_size, hidden_size, layer_num, dropout, winit, w_rank=w_rank, u_ranks=[list(u_ranks)[-1]], lstm_type="vmlmf")
+        model.rnns = nn.ModuleList([MyVMLSTMGroup(hidden_size, hidden_size, w_rank=w_rank, u_ranks=list(u_ranks), g=g)
+                                    for _ in range(layer_num)])
+        model.lstm_type = "vmgroup"
+        model.reset_parameters()
+        return model
+
     def state_init(self, batch_size):
         dev = next(self.parameters()).device
         flat = self.lstm_type in ["custom", "vmlmf", "vmgroup", "hmd"]
