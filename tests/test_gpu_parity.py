@@ -244,7 +244,7 @@ def test_dy_is_never_read_past_its_end():
 
 
 @pytest.mark.parametrize("env", [{"VMLMF_SKINNY": "0"}, {"VMLMF_FUSE_GATES": "0"}, {"VMLMF_DQ_SPLIT": "0"},
-                                 {"VMLMF_FUSE_GATES": "3"}, {"VMLMF_SKINNY": "4"}, {"VMLMF_XWAVE": "0"}, {"VMLMF_XEXP": "0"}],
+                                 {"VMLMF_FUSE_GATES": "3"}, {"VMLMF_XWAVE": "0"}, {"VMLMF_XEXP": "0"}],
                          ids=lambda e: "_".join(f"{k[6:]}{v}" for k, v in e.items()))
 def test_measurement_switches_compute_the_same_thing(env):
     """The A/B switches of the native code (read once when the library loads) select alternative kernels for the same

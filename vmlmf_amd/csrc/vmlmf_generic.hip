@@ -337,7 +337,7 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 // BT: `B` points at B^T (N x K row-major, ldb its row stride): both operands are then read along k, 16 bytes per lane
 // and load (the step-wise path keeps every factor in both orientations); otherwise B is K x N and a lane fetches its
 // column element row by row (four 64-byte segments per load instruction).  Reading both along k measured slower
-// (rows 12 KB apart); the BT instantiations stay for A/B runs (VMLMF_SKINNY=4).
+// (rows 12 KB apart): no BT instantiation is built any more.
 // NSUB: 16-column sub-tiles per workgroup (2: a 16 x 32 tile whose two MFMA chains share the A operand -- for tall
 // products such as dqx = dpre VxT (8960 x 32, K = 3072), where A is the 110 MB operand and should be read once).
 // BMODE 0: B is K x N row-major; 1 (BT): `B` points at B^T; 2: B "quad-interleaved" along k, [k / 4][n][k % 4] (ldb = N): the four
@@ -655,20 +655,12 @@ static int gemm(const float* A, long long lda, const float* B, long long ldb, fl
   }
   if (N <= 128 && K >= 256 && g_skinny) {   // skinny output, long K: 16 x 16 tiles, K split inside the workgroup
     const int t16 = ((M + 15) / 16) * ((N + 15) / 16);
-    if (Bt != nullptr && g_skinny_mode == 4) {   // both operands along k (measured slower: rows 12 KB apart)
-      a.B = Bt, a.ldb = ldbt;
-      if (K >= 1536)
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, 1, 12, 1>), dim3(t16), dim3(512), 0, s, a);
-      else
-        hipLaunchKernelGGL((gemm_skinny_kernel<4, 1, 12, 1>), dim3(t16), dim3(256), 0, s, a);
-    } else if (K >= 1536) {
-      if (N % 32 == 0 && t16 >= 1024)   // tall: plenty of tiles, read A once per pair of column tiles
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 2>), dim3(t16 / 2), dim3(512), 0, s, a);
-      else
-        hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 1>), dim3(t16), dim3(512), 0, s, a);
-    } else {
+    // (B^T with both operands read along k - VMLMF_SKINNY=4 - measured slower, rows 12 KB apart, and left the library in round 5
+    //  together with the 16 x 32 tile form of the row-major B, whose one user - dqx - reads the quad image now)
+    if (K >= 1536)
+      hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 12, 1>), dim3(t16), dim3(512), 0, s, a);
+    else
       hipLaunchKernelGGL((gemm_skinny_kernel<8, 0, 8, 1>), dim3(t16), dim3(512), 0, s, a);
-    }
     return (int)hipGetLastError();
   }
   const int tiles = ((M + GBM - 1) / GBM) * ((N + GBN - 1) / GBN);
