@@ -158,3 +158,37 @@ def test_both_selections_of_the_third_kernel_form(case, rec3):
     compare_all(base, ref, "rec3=6")
     for k in ("y", "hT", "cT"):
         assert np.abs(got[k] - base[k]).max() <= 2e-6 * max(np.abs(base[k]).max(), 1.0), k
+
+
+def test_parameter_tensors_that_are_not_16_byte_aligned_take_the_packed_images():
+    """Direct mode reads parameter rows as 16-byte loads; a tensor that starts 4 bytes into an allocation (a view into a flat
+    buffer) must fall back to pack_kernel's images - same results against the oracle, and a pack launch in the counters."""
+    import torch
+    from hip_util import ORDER
+    from vmlmf_amd import vmlmf_sequence
+    variant, B, T, I, H, rw, ru = O.V1, 64, 12, 9, 180, 16, [16]
+    P, x, h0, c0, dy, dhT, dcT = _case(variant, B, T, I, H, rw, ru, seed=17)
+    names = ORDER[variant]
+    total = sum(int(np.asarray(P[k]).size) + 2 for k in names)
+    flat = torch.zeros(total + 4, device="cuda")
+    params, o = [], 1                       # every tensor starts at an odd float offset
+    for k in names:
+        a = np.asarray(P[k], np.float32)
+        v = flat[o:o + a.size].view(a.shape)
+        v.copy_(torch.tensor(a))
+        params.append(v.detach().requires_grad_(True))
+        o += a.size + (1 if (o + a.size) % 2 == 0 else 2)
+    assert any(p.data_ptr() % 16 for p in params)
+
+    def run():
+        xt = torch.tensor(x, device="cuda")
+        y, hT, cT = vmlmf_sequence(variant, xt, torch.tensor(h0, device="cuda"), torch.tensor(c0, device="cuda"), params, rw, ru, g=1)
+        ((y * torch.tensor(dy, device="cuda")).sum() + (hT * torch.tensor(dhT, device="cuda")).sum()).backward()
+        return y
+    y, counts = _kernel_counts(run)
+    assert counts["pack_kernel"] >= 1, counts
+    ref = run_literal(variant, P, x, h0, c0, dy, dhT, None)
+    from hip_util import assert_out, assert_grad
+    assert_out(y.detach().cpu().numpy(), ref["y"], "y")
+    for k, p in zip(names, params):
+        assert_grad(p.grad.cpu().numpy(), ref["G"][k], k)
