@@ -1,6 +1,8 @@
 """GPU: the nn.Module surface (what the reference's harness calls) against golden vectors from the reference:
 Net + Adam loop (train.py:58-65), two-layer MyLSTM at BASELINE config C's shape, LM state carry
 (lm_test.py:196-203), bare cell calls."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -892,3 +894,131 @@ def test_criterion_riding_tiers_of_the_fixed_point_mean():
                 assert abs(float(got) - base) <= 1e-6, (float(got), base)
     from vmlmf_amd.functional import ce_ticket
     assert int(ce_ticket(x.device).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("variant,I,H,rw,ru,B,T,tm", [(O.V1, 9, 64, 8, [8], 6, 5, False), (O.V3, 650, 650, 32, [32], 16, 3, True)])
+def test_plain_c_abi_calls_behind_a_dirty_stack(variant, I, H, rw, ru, B, T, tm, tmp_path):
+    """vmlmf_seq_forward / vmlmf_seq_backward go through the *_packed wrappers, whose stack `vmlmf_extra` left the
+    fields added later (ce, drop) unset.  Called behind a function that filled the stack with 0xA5 (tests/shims/dirty_stack.c, gcc),
+    on a register-resident layer and on a row-block layer (the family that applies dropout inside its launches), the plain entry
+    points must return 0 and the oracle's results."""
+    import ctypes
+    import subprocess
+    from hip_util import ORDER, assert_grad, assert_out, run_literal
+    from vmlmf_amd import _lib
+    from vmlmf_amd.functional import _params_struct, _ptr
+    so = str(tmp_path / "dirty_stack.so")
+    subprocess.run(["gcc", "-O1", "-shared", "-fPIC", os.path.join(os.path.dirname(__file__), "shims", "dirty_stack.c"), "-o", so], check=True)
+    shim = ctypes.CDLL(so)
+    lib = _lib.lib()
+    rng = np.random.Generator(np.random.PCG64(11))
+    P = O.make_params(variant, I, H, rw, ru[0], seed=2)
+    if variant == O.V3:
+        P = {k: (np.asarray(v) * 0.3).astype(np.float32) for k, v in P.items()}
+    shape = (T, B, I) if tm else (B, T, I)
+    x = (rng.standard_normal(shape) * 0.5).astype(np.float32)
+    dy = rng.standard_normal(shape[:2] + (H,)).astype(np.float32)
+    ref = run_literal(variant, P, x, None, None, dy, time_major=tm)
+    params = [torch.tensor(np.asarray(P[k]), device=DEV) for k in ORDER[variant]]
+    grads = [torch.empty_like(p) for p in params]
+    desc = _lib.make_desc(variant, B, T, I, H, rw, ru, time_major=tm, training=True)
+    sz = _lib.query(desc)
+    xt, dyt = torch.tensor(x, device=DEV), torch.tensor(dy, device=DEV)
+    y, hT, cT = torch.empty(shape[:2] + (H,), device=DEV), torch.empty(B, H, device=DEV), torch.empty(B, H, device=DEV)
+    dx = torch.empty_like(xt)
+    ws = torch.empty(sz.workspace_bytes, device=DEV, dtype=torch.uint8)
+    reserve = torch.empty(sz.reserve_bytes, device=DEV, dtype=torch.uint8)
+    ps, gs = _params_struct(params, 1, variant), _params_struct(grads, 1, variant)
+    stream = _lib.raw_stream(torch.device("cuda", 0))
+    vp = ctypes.c_void_p
+    shim.dirty_forward.argtypes = [vp] * 11 + [ctypes.c_size_t, vp]
+    shim.dirty_backward.argtypes = [vp] * 16 + [ctypes.c_size_t, vp]
+    fn = lambda f: ctypes.cast(f, vp)
+    rc = shim.dirty_forward(fn(lib.vmlmf_seq_forward), ctypes.addressof(desc), ctypes.addressof(ps), _ptr(xt), None, None, _ptr(y), _ptr(hT),
+                            _ptr(cT), _ptr(reserve), _ptr(ws), sz.workspace_bytes, stream)
+    assert rc == 0, lib.vmlmf_last_error().decode()
+    rc = shim.dirty_backward(fn(lib.vmlmf_seq_backward), ctypes.addressof(desc), ctypes.addressof(ps), _ptr(xt), None, None, _ptr(y),
+                             _ptr(reserve), _ptr(dyt), None, None, _ptr(dx), None, None, ctypes.addressof(gs), _ptr(ws),
+                             sz.workspace_bytes, stream)
+    assert rc == 0, lib.vmlmf_last_error().decode()
+    torch.cuda.synchronize()
+    assert_out(y.cpu().numpy(), ref["y"], "dirty.y")
+    assert_out(hT.cpu().numpy(), ref["hT"], "dirty.hT")
+    assert_grad(dx.cpu().numpy(), ref["dx"], "dirty.dx")
+    for k, g_ in zip(ORDER[variant], grads):
+        assert_grad(g_.cpu().numpy(), ref["G"][k], f"dirty.{k}")
+
+
+def _cfg_a_net(d):
+    _, B, T, I, H, rw, ru = (int(v) for v in d["meta"])
+    torch.manual_seed(0)
+    net = Net(I, layer_sizes=[H], w_rank=rw, u_rank=[ru], model=MyLSTM, cell=MyVMLMFCell)
+    load_cell(net.rnn.rnncells[0], O.make_params(O.V1, I, H, rw, ru, seed=int(d["seeds"][0])))
+    x, tgt = O.synthetic_batch(B, T, I, seed=int(d["seeds"][1]))
+    return net.to(DEV), torch.tensor(x, device=DEV), torch.tensor(tgt, device=DEV).long()
+
+
+@pytest.mark.parametrize("graphed", [False, True])
+def test_the_graded_step_itself_vs_reference_golden(graphed):
+    """the bench's own step - Net.loss (criterion in the forward launch) -> backward(unit_gradient) ->
+    finish2_kernel -> vmlmf_amd.optim.Adam, eager and replayed from GraphedTrainStep's hipGraph - against the reference's own three
+    Adam steps at config A (cfgA_net_adam3: V/src/train_test/train.py:47,58-65 run on the imported reference): the three losses,
+    the three logit matrices and the final parameters, at the tolerances of test_net_adam_three_steps_vs_reference."""
+    import vmlmf_amd
+    d = load_golden("cfgA_net_adam3")
+    net, x, tgt = _cfg_a_net(d)
+    opt = vmlmf_amd.optim.Adam(net.parameters(), lr=0.002)
+    if graphed:
+        step = vmlmf_amd.GraphedTrainStep(net, vmlmf_amd.cross_entropy, opt, x, tgt, warmup=2)
+        assert step._fused_loss
+    for it in range(3):
+        if graphed:
+            loss = float(step(x, tgt))        # (the replay has applied the update already: the logits are checked on the eager leg)
+        else:
+            opt.zero_grad(set_to_none=True)
+            l, logits = net.loss(x, tgt, return_logits=True)
+            l.backward(vmlmf_amd.unit_gradient(l.device))
+            opt.step()
+            loss = float(l)
+            assert_out(logits.detach().cpu().numpy(), d["logits"][it], f"logits[{it}]", atol=2e-5)
+        assert abs(loss - float(d["losses"][it])) < 2e-5, (graphed, it, loss, d["losses"][it])
+    assert all(p.grad is None for p in net.cell.parameters())
+    sd = net.state_dict()
+    for k, v in d["final"].items():
+        assert_out(sd[k].cpu().numpy(), v, "final." + k, atol=2e-5, rtol=1e-3)
+
+
+@pytest.mark.parametrize("variant,cls,ru,kw", [(O.V1, MyVMLMFCell, [6], {}), (O.V2, MyVMLMFCellg2, [4, 6], {"g": 2})])
+def test_mylstm_time_major_module_vs_oracle(variant, cls, ru, kw):
+    """MyLSTM(batch_first=False) (V/src/models/vmlmf.py:255,273-276: x is (T, B, I), y (T, B, H)) through the MODULE for V1 and V2,
+    two layers, against literal_sequence(time_major=True) chained layer by layer in fp64."""
+    from hip_util import ORDER
+    B, T, I, H, rw = 5, 7, 12, 24, 5
+    rng = np.random.Generator(np.random.PCG64(21))
+    rnn = MyLSTM(I, hidden_layer_sizes=[H, H], batch_first=False, w_rank=rw, u_ranks=ru, cell=cls, **kw)
+    Ps = [O.make_params(variant, I if l == 0 else H, H, rw, ru if len(ru) > 1 else ru[0], seed=30 + l) for l in range(2)]
+    for l in range(2):
+        load_cell(rnn.rnncells[l], Ps[l])
+    rnn = rnn.to(DEV)
+    x = rng.standard_normal((T, B, I)).astype(np.float32)
+    dy = rng.standard_normal((T, B, H)).astype(np.float32)
+    dh = rng.standard_normal((B, 2 * H)).astype(np.float32)
+    xg = torch.tensor(x, device=DEV, requires_grad=True)
+    y, hcat = rnn(xg)
+    assert y.shape == (T, B, H) and hcat.shape == (B, 2 * H)
+    ((y * torch.tensor(dy, device=DEV)).sum() + (hcat * torch.tensor(dh, device=DEV)).sum()).backward()
+    Pt = [O.to_torch(P, dtype=torch.float64, requires_grad=True) for P in Ps]
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    cur, hs = xt, []
+    for l in range(2):
+        cur, h, _ = O.literal_sequence(variant, Pt[l], cur, None, None, time_major=True)
+        hs.append(h)
+    ((cur * torch.tensor(dy, dtype=torch.float64)).sum() + (torch.cat(hs, -1) * torch.tensor(dh, dtype=torch.float64)).sum()).backward()
+    assert_out(y.detach().cpu().numpy(), cur.detach().numpy(), "tm.y")
+    assert_out(hcat.detach().cpu().numpy(), torch.cat(hs, -1).detach().numpy(), "tm.hcat")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "tm.dx")
+    for l in range(2):
+        cell = rnn.rnncells[l]
+        for k in ORDER[variant]:
+            got = (cell.layers[k] if hasattr(cell, "layers") else getattr(cell, k)).grad
+            assert_grad(got.cpu().numpy(), Pt[l][k].grad.numpy(), f"tm.layer{l}.{k}")

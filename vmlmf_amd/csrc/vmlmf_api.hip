@@ -693,7 +693,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
 int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
                              const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                              size_t workspace_bytes, void* stream, const void* packed) {
-  vmlmf_extra ex;
+  vmlmf_extra ex = {};   // every field the caller does not set is a null pointer (drop, ce, ...)
   ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_forward_ex(d, p, x, h0, c0, y, hT, cT, reserve, workspace, workspace_bytes, stream, &ex);
 }
@@ -873,7 +873,7 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
                               const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
                               const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
                               const void* packed) {
-  vmlmf_extra ex;
+  vmlmf_extra ex = {};   // every field the caller does not set is a null pointer (drop, ce, ...)
   ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_backward_ex(d, p, x, h0, c0, y, reserve, dy, dhT, dcT, dx, dh0, dc0, gr, workspace, workspace_bytes, stream, &ex);
 }

@@ -189,7 +189,7 @@ __device__ __forceinline__ void st1g_agent(gf32* p, float v) {
 //      SAFE_ST constants of the kernels), and tools/check_asm_hazards.py, run by the CPU tests on the built library,
 //      disassembles every kernel and fails on either hazard at any store with a scalar base.
 // NT: the non-temporal hint (streamed data nobody re-reads soon: the forward's tape, 41 MB per launch at the headline shape - ten
-// times the L2 of an XCD; rec_fwd_kernel's storer 69.1 -> 67.5 us, 0.1566 -> 0.1559 ms per step same-box, tools/sessions/r03y6.sh)
+// times the L2 of an XCD; rec_fwd_kernel's storer 69.1 -> 67.5 us, 0.1566 -> 0.1559 ms per step same-box, (git c7e095c) tools/sessions/r03y6.sh)
 template <bool SAFE = false, bool NT = false>
 __device__ __forceinline__ void st4_sv(const void* sbase, unsigned voff, float4 v) {
   const f32x4 t = f32x4{v.x, v.y, v.z, v.w};

@@ -146,7 +146,7 @@ int launch_embed_bwd(int R, int H, int V, const long long* tokens, const float* 
 // ---------------------------------------------------------------------------------------------------
 // dst (cols x rows) = src (rows x cols)^T, fp32, through 64 x 64 LDS tiles (both sides in whole 256-byte row segments).  The LM
 // head's weight gradient is fastest as the library GEMM that yields dW^T (H x V); the strided copy that turned it into dW took
-// 43 us for 26 MB (tools/sessions/r04p.sh) - this takes the bytes' time.
+// 43 us for 26 MB ((git c7e095c) tools/sessions/r04p.sh) - this takes the bytes' time.
 __global__ void __launch_bounds__(256) transpose_kernel(int rows, int cols, const float* __restrict__ src, float* __restrict__ dst) {
   __shared__ float tile[64][65];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;

@@ -172,6 +172,7 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(TensorList t, int count
     }
   }
   __shared__ unsigned last_s;
+  __syncthreads();   // every wave of this workgroup has read steps / health / guard[GO] and finished its update loop before the ticket is taken
   if (tid == 0) {
     unsigned* tk = &guard[GUARD_TICKET_W];
     last_s = atomicAdd(tk, 1u) == gridDim.x * gridDim.y - 1 ? 1u : 0u;   // every other workgroup has read what it reads

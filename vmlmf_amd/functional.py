@@ -164,14 +164,31 @@ def _require_hip(t, what):
 
 
 _TICKET = {}
+_TICKET_CAPTURE_SLOTS = 16
 
 
 def ce_ticket(device):
     """The ticket words of the criterion that rides on the forward launch (include/vmlmf_hip.h: vmlmf_ce.ticket): two zeroed
-    int64 per device, allocated once; every launch leaves it zero, and the launches of a device are ordered on its current stream."""
-    t = _TICKET.get(device)
+    int64; every launch leaves them zero.  Launches that share a ticket must be ordered on ONE stream, so the pair is kept per
+    (device, stream).  Nothing is allocated inside a stream capture (the allocation would land in the graph's private pool and a
+    memset node in the graph): a captured forward takes the next pair of a block of 16 that the first call outside a capture set
+    aside for the device, so different graphs - replayed on whatever streams - do not meet on one pair either.  Only a process whose
+    very first forward is captured pays a zeroing node in that graph (the pair is then the graph's own and is not kept here)."""
+    device = torch.device(device)
+    capturing = torch.cuda.is_current_stream_capturing()
+    block = _TICKET.get((device.index, "capture"))
+    if block is None and not capturing:
+        block = _TICKET[(device.index, "capture")] = [torch.zeros(2 * _TICKET_CAPTURE_SLOTS, device=device, dtype=torch.int64), 0]
+    if capturing:
+        if block is None:
+            return torch.zeros(2, device=device, dtype=torch.int64)
+        i = block[1] % _TICKET_CAPTURE_SLOTS
+        block[1] += 1
+        return block[0][2 * i:2 * i + 2]
+    key = (device.index, _lib.raw_stream(device).value)
+    t = _TICKET.get(key)
     if t is None:
-        t = _TICKET[device] = torch.zeros(2, device=device, dtype=torch.int64)
+        t = _TICKET[key] = torch.zeros(2, device=device, dtype=torch.int64)
     return t
 
 
@@ -267,10 +284,10 @@ class VmlmfSeqFn(torch.autograd.Function):
         h0 = rest.pop(0) if ctx.has_h0 else None
         c0 = rest.pop(0) if ctx.has_c0 else None
         hw = rest.pop(0) if ctx.has_head else None
-        if ctx.has_ce and dloss is not None:
+        dz = rest.pop(0) if ctx.has_ce else None   # (popped whether or not the loss takes part: what follows it is the dropout snapshot)
+        if dz is not None and dloss is not None:
             # the criterion's share of d(logits): what the forward launch wrote for d(loss) = 1 - as it is when the incoming
             # gradient IS the package's constant one (vmlmf_amd.unit_gradient), scaled otherwise
-            dz = rest.pop(0)
             unit = _UNIT.get(dz.device)
             if not (unit is not None and dloss.data_ptr() == unit.data_ptr()):
                 dz = dz * dloss

@@ -128,9 +128,9 @@ class Adam(torch.optim.Optimizer):
                 _check(p, g)
                 pairs.append((p, g))
             for tl in _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live]):
-                calls.append((tl, gs, group, live))
+                calls.append((tl, gs, group, live, pairs))   # pairs: the .contiguous() copies live until their launch is issued
         guard = getattr(self, "_guard", None)
-        for ci, (tl, gs, group, live) in enumerate(calls):
+        for ci, (tl, gs, group, live, _keep) in enumerate(calls):
             dev = live[0].device
             b1, b2 = group["betas"]
             flags = (_lib.ADAM_FIRST if ci == 0 else 0) | (_lib.ADAM_LAST if ci == len(calls) - 1 else 0)
