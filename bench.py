@@ -305,13 +305,22 @@ def other_configs(iters=100):
         xe32 = 0.05 * torch.randn(35, 32, 650, device="cuda")
         st32 = [(torch.zeros(32, 650, device="cuda"), torch.zeros(32, 650, device="cuda")) for _ in layers]
 
-        def fbe32():
+        from vmlmf_amd.lm import stack_layers
+
+        def fbe_rows(xin, sts):   # Model.features' layer loop: one launch per direction where the clusters of both layers are co-resident
             for l in layers:
                 l.zero_grad(set_to_none=True)
-            h = xe32
-            for l, st in zip(layers, st32):
-                h, _ = l(h, st)
+            out = stack_layers(layers, xin, sts)
+            if out is not None:
+                h = out[0]
+            else:
+                h = xin
+                for l, st in zip(layers, sts):
+                    h, _ = l(h, st)
             h.sum().backward()
+
+        def fbe32():
+            fbe_rows(xe32, st32)
 
         for _ in range(3):
             fbe32()
@@ -322,7 +331,21 @@ def other_configs(iters=100):
         torch.cuda.synchronize()
         ms32 = (time.perf_counter() - t0) / 20 * 1e3
         res["E_32rows"] = {"ms_per_step": round(ms32, 4), "timesteps_per_s": round(35 / (ms32 * 1e-3), 1),
-                           "workload": "the same two layers at 32 rows (configs[4]'s share of one GPU on an 8-GPU node), eager launches"}
+                           "workload": "the same two layers at 32 rows (configs[4]'s share of one GPU on an 8-GPU node), eager launches; both "
+                                       "layers in ONE launch per direction (csrc/vmlmf_rbx.hip), as Model.features runs them"}
+        for rows in (64, 128):   # the 4-GPU and 2-GPU shares
+            xr = 0.05 * torch.randn(35, rows, 650, device="cuda")
+            sr = [(torch.zeros(rows, 650, device="cuda"), torch.zeros(rows, 650, device="cuda")) for _ in layers]
+            for _ in range(3):
+                fbe_rows(xr, sr)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                fbe_rows(xr, sr)
+            torch.cuda.synchronize()
+            msr = (time.perf_counter() - t0) / 20 * 1e3
+            res[f"E_{rows}rows"] = {"ms_per_step": round(msr, 4), "timesteps_per_s": round(35 / (msr * 1e-3), 1),
+                                    "workload": f"the same two layers at {rows} rows, eager launches, one launch per direction"}
     except Exception as e:   # never at the expense of the line
         res["E_32rows"] = {"error": f"{type(e).__name__}: {e}"}
     return res

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 11
+#define VMLMF_ABI_VERSION 12
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -278,7 +278,19 @@ typedef struct vmlmf_stack_layer {
   const float *dhT, *dcT;
   float *dh0, *dc0;
   const vmlmf_grads *grads;
+  const vmlmf_dropout *drop; /* ABI 12: dropout of this layer's output inside the stack's launches (vmlmf_lm.py:438-439), or NULL:
+                              * the layer above (and the caller, for the top layer) reads drop->y_dropped instead of y.  Only the
+                              * clustered form takes it (vmlmf_stack_dropout_fused) */
 } vmlmf_stack_layer;
+/* ABI 12 - a second form behind the same three entry points: layers too large for one CU (the PTB layers, hidden_size 650) run on
+ * CLUSTERS of workgroups (vmlmf_seq_forward's row-block kernels); stacked, every layer keeps its own clusters inside ONE launch per
+ * direction and layer l + 1 follows layer l a few time steps behind (csrc/vmlmf_rbx.hip) - T + 3 dependent cluster steps per
+ * direction instead of L x T - and each layer forms its x side inside that launch as well.  Covered: 2..4 V3 or V4 layers of one
+ * configuration, fp32, time-major, input_size == hidden_size for every layer, w_rank 17..32, as long as the clusters of all layers
+ * are co-resident (L x ceil(B / rows) x 16 workgroups <= the device's CUs: up to 128 rows for two layers).  vmlmf_stack_query()
+ * returns VMLMF_E_UNSUPPORTED otherwise.  No classifier head on this form. */
+/* 1: the layers' `drop` fields are honoured by this stack (the clustered form) */
+int vmlmf_stack_dropout_fused(int L, const vmlmf_stack_layer *layers);
 /* sizes for the stack: reserve_bytes[l] per layer, one workspace for either direction */
 int vmlmf_stack_query(int L, const vmlmf_stack_layer *layers, size_t *reserve_bytes, size_t *workspace_bytes);
 /* head (or NULL): a classifier on the TOP layer's final hidden state (Net.lin, vmlmf.py:345,353-355), as in

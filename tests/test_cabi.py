@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in declared_functions():
         assert hasattr(handle, name), f"missing export {name}"
     lib = _lib.lib()
-    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 11
+    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 12
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
         "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",

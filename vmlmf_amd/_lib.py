@@ -18,7 +18,7 @@ NKERNELS = 13
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 11
+ABI_VERSION = 12
 GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
 ADAM_FIRST, ADAM_LAST = 1, 2
 DT_F32, DT_BF16 = 0, 1
@@ -70,7 +70,7 @@ class StackLayer(ctypes.Structure):
     _fields_ = [("desc", Desc), ("params", ctypes.POINTER(Params)), ("h0", ctypes.c_void_p), ("c0", ctypes.c_void_p),
                 ("y", ctypes.c_void_p), ("hT", ctypes.c_void_p), ("cT", ctypes.c_void_p), ("reserve", ctypes.c_void_p),
                 ("dhT", ctypes.c_void_p), ("dcT", ctypes.c_void_p), ("dh0", ctypes.c_void_p), ("dc0", ctypes.c_void_p),
-                ("grads", ctypes.POINTER(Params))]
+                ("grads", ctypes.POINTER(Params)), ("drop", ctypes.POINTER(Dropout))]
 
 
 STACK_MAX = 4
@@ -97,6 +97,7 @@ SYMBOLS = {
     "vmlmf_tune": (_i, [ctypes.c_char_p, _i]),
     "vmlmf_check_status": (_i, []),
     "vmlmf_stack_query": (_i, [_i, _vp, _vp, _vp]),
+    "vmlmf_stack_dropout_fused": (_i, [_i, _vp]),
     "vmlmf_stack_forward": (_i, [_i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vmlmf_stack_backward": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vmlmf_query": (_i, [ctypes.POINTER(Desc), ctypes.POINTER(Sizes)]),

@@ -51,6 +51,10 @@ struct RbGeo {
   unsigned tgcode;              // four bits per M-tile m: 1 + the one group whose units feed it in the forward reduce, 0: several / all
   long long UA, VA, VB, UB, total;   // float offsets of the A-operand images inside the RB region of PACK
   long long xq_floats, flag_words;   // cluster exchange scratch (S > 1)
+  // x side inside the clustered kernels (vmlmf_rbx.inc: stacked layers in one launch): images of U_x / V_x in the same pairings, and
+  // NPX more tiles (the x ranks) in every exchange.  xf = 0: not packed (offsets 0)
+  int xf, NPX;
+  long long UXA, VXA, VXB, UXB;
 };
 
 // float offsets inside the PACK region (parameter images, produced by pack_kernel)

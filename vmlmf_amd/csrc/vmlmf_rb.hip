@@ -54,12 +54,30 @@ __device__ inline float rb_vc(const VGeo& g, const RefP& p, int slot, int k, int
   return ref_vc(g, p, n, k, rr);
 }
 
+// x side of a layer whose input is as wide as its hidden state (I == H: input n belongs to the slot of unit n): u_x row of the
+// slot's unit / v_x row of (unit, gate), zero beyond the rank and for padded slots
+__device__ inline float rb_ux(const VGeo& g, const RefP& p, int slot, int r) {
+  int n;
+  if (!vg_slot_unit(g, slot, n) || n >= g.I) return 0.f;
+  return ref_ux(g, p, n, r);
+}
+__device__ inline float rb_vx(const VGeo& g, const RefP& p, int slot, int k, int r) {
+  int n;
+  if (!vg_slot_unit(g, slot, n)) return 0.f;
+  return ref_vx(g, p, n, k, r);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // A-operand images.  Element (.., lane) is what lane (c = lane & 15, kq = lane >> 4) feeds to the MFMA: A[i = c][k = kq].
 //   UA[tv][m][r]      reduce (fwd):   row pi-position c of M-tile m  x  unit 4 kq + r of the tile
 //   VA[tv][k][s4]     expand (fwd):   unit c of the tile, gate k     x  rank 4 s4 + kq
 //   VB[tv][k][mv][r]  reduce (bwd):   rank 16 mv + pi(c)             x  (unit 4 kq + r, gate k)
 //   UB[tv][m][r]      expand (bwd):   unit c of the tile             x  row 16 m + 4 r + kq of the padded rank space
+// x side inside the clustered kernels (RbGeo::xf; vmlmf_rbx.inc), the same four pairings with u_x / v_x and the x ranks:
+//   UXA[tv][mx][r]    reduce (fwd):   x rank 16 mx + pi(c)           x  input 4 kq + r of the tile
+//   VXA[tv][k][s4]    expand (fwd):   unit c of the tile, gate k     x  x rank 4 s4 + kq
+//   VXB[tv][k][mx][r] reduce (bwd):   x rank 16 mx + pi(c)           x  (unit 4 kq + r, gate k)
+//   UXB[tv][mx][r]    expand (bwd):   input c of the tile            x  x rank 16 mx + 4 r + kq
 // ---------------------------------------------------------------------------------------------------
 // `flags` (or NULL): the cluster's epoch words of the forward launch behind this one, zeroed here instead of by a memset node of
 // their own (a 5 us launch for 1 KB)
@@ -72,10 +90,45 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
   const int nUA = NTV * NMT * 4 * 64, nVA = NTV * 4 * KS * 64, nVB = NTV * 4 * NP * 4 * 64;
   const int total = 2 * nUA + nVA + nVB;
   const int e = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (e >= total) return;
   const int lane = e & 63, c = lane & 15, kq = lane >> 4;
   int le = e;
   int grp, sb, n0;
+  if (e >= total) {                     // the x-side images (q.xf), laid out behind the four above
+    if (!q.xf) return;
+    const int NPX = q.NPX, KSX = g.KX / 4;
+    const int nUXA = NTV * NPX * 4 * 64, nVXA = NTV * 4 * KSX * 64, nVXB = NTV * 4 * NPX * 4 * 64;
+    le = e - total;
+    if (le < nUXA) {                    // UXA
+      int j = le >> 6;
+      const int r = j & 3;
+      j >>= 2;
+      const int tv = j / NPX, mx = j - tv * NPX;
+      rb_tile(g, q, tv, grp, sb, n0);
+      out[q.UXA + le] = rb_ux(g, p, sb + 4 * kq + r, 16 * mx + rb_pi(c));
+    } else if ((le -= nUXA) < nVXA) {   // VXA
+      int j = le >> 6;
+      const int j2 = j / KSX, s4 = j - j2 * KSX;
+      const int k = j2 & 3, tv = j2 >> 2;
+      rb_tile(g, q, tv, grp, sb, n0);
+      out[q.VXA + le] = rb_vx(g, p, sb + c, k, 4 * s4 + kq);
+    } else if ((le -= nVXA) < nVXB) {   // VXB
+      int j = le >> 6;
+      const int r = j & 3;
+      j >>= 2;
+      const int j2 = j / NPX, mx = j - j2 * NPX;
+      const int k = j2 & 3, tv = j2 >> 2;
+      rb_tile(g, q, tv, grp, sb, n0);
+      out[q.VXB + le] = rb_vx(g, p, sb + 4 * kq + r, k, 16 * mx + rb_pi(c));
+    } else if ((le -= nVXB) < nUXA) {   // UXB
+      int j = le >> 6;
+      const int r = j & 3;
+      j >>= 2;
+      const int tv = j / NPX, mx = j - tv * NPX;
+      rb_tile(g, q, tv, grp, sb, n0);
+      out[q.UXB + le] = rb_ux(g, p, sb + c, 16 * mx + 4 * r + kq);
+    }
+    return;
+  }
   if (le < nUA) {                       // UA
     int j = le >> 6;
     const int r = j & 3;
@@ -145,7 +198,7 @@ static bool rb_has(int ks, int mt, int nmu, bool flat, int G, bool bf) {
   return (ks == 4 || ks == 8) && nmu == 2;
 }
 
-bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
+bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows, int xf) {
   RbGeo q;
   memset(&q, 0, sizeof(q));
   if (g.KH % 4 != 0 || g.G > 2 || (RB_WAVES * S) % g.G != 0) return false;
@@ -205,8 +258,20 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
   q.VA = take(NTV * 4 * KS * 64);
   q.VB = take(NTV * 4 * g.NP * 4 * 64);
   q.UB = take(NTV * q.NMT * 4 * 64);
+  // the x side inside the clustered kernels: fp32 clusters with one tile per wave, an input as wide as the hidden state
+  // (input n <-> unit n), padded x rank <= 32
+  q.xf = 0, q.NPX = 0;
+  if (xf) {
+    if (!(S > 1 && q.MT == 1 && !g.bf && g.I == g.H && g.KX % 4 == 0 && g.KX <= 32 && !g.novm && !g.pergate)) return false;
+    q.xf = 1, q.NPX = (g.KX + 15) / 16;
+    q.UXA = take(NTV * q.NPX * 4 * 64);
+    q.VXA = take(NTV * 4 * (g.KX / 4) * 64);
+    q.VXB = take(NTV * 4 * q.NPX * 4 * 64);
+    q.UXB = take(NTV * q.NPX * 4 * 64);
+  }
+  // (the x-side images must start right behind the four others: rb_pack_kernel indexes them as one range)
   q.total = o;
-  q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * q.NMT * 256 : 0;
+  q.xq_floats = S > 1 ? (long long)q.nrb * 2 * S * (q.NMT + q.NPX) * 256 : 0;
   q.flag_words = S > 1 ? (long long)q.nrb * S * 32 + 64 : 0;   // (vmlmf_rb.inc: RB_FLAG_STRIDE)
   if (!rb_has(g.KH / 4, q.MT, q.nmu, g.flat != 0, g.G, g.bf != 0)) return false;
   *out = q;
@@ -215,6 +280,8 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows) {
 
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags) {
   if (q.total >= (1LL << 30)) return -3;
+  // one thread per image element: the four h-side images are dense from 0 (element e <-> offset UA + e: `take` pads to 64 and every
+  // image is a multiple of 64 floats); the x-side images follow densely from q.UXA
   const long long blocks = (q.total + 255) / 256;
   hipLaunchKernelGGL(rb_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, q, p, img, q.S > 1 ? zero_flags : nullptr);
   return (int)hipGetLastError();

@@ -423,13 +423,27 @@ def _stack_plan(cfg, L, B, T, I, H, training):
     return plan
 
 
+def stack_takes_dropout(cfg, L, B, T, I, H, training):
+    """Does the stack run in the clustered form (include/vmlmf_hip.h: vmlmf_stack_dropout_fused), whose launches apply the dropout
+    between the layers themselves?"""
+    plan = _stack_plan(cfg, L, B, T, I, H, training)
+    if plan is None:
+        return False
+    layers = (_lib.StackLayer * L)()
+    for l in range(L):
+        layers[l].desc = plan[0][l]
+    return _lib.lib().vmlmf_stack_dropout_fused(L, ctypes.addressof(layers)) == 1
+
+
 class VmlmfStackFn(torch.autograd.Function):
     """y_top, hT_0 .. hT_{L-1}, cT_0 .. cT_{L-1} = f(x, params of layer 0, ..., params of layer L-1): every layer of a stack in
     one launch per direction (include/vmlmf_hip.h: vmlmf_stack_forward / vmlmf_stack_backward).  Initial states are zero
     (MyLSTM.forward, vmlmf.py:296-298)."""
 
     @staticmethod
-    def forward(ctx, cfg, L, x, head_w, head_b, h0, c0, *params):
+    def forward(ctx, cfg, L, x, head_w, head_b, h0, c0, drops, *params):
+        # drops: None, or one entry per layer - None / (p, snapshot, site): nn.Dropout(p) behind that layer inside the stack's launches
+        # (the clustered form only: vmlmf_stack_dropout_fused); the first output is then the top layer's DROPPED copy
         variant, g, w_rank, u_ranks, time_major, _ = cfg
         ctx.set_materialize_grads(False)
         _require_hip(x, "input")
@@ -455,11 +469,17 @@ class VmlmfStackFn(torch.autograd.Function):
         c0c = None if c0 is None else c0.contiguous()
         layers = (_lib.StackLayer * L)()
         keep = []
+        yds = [None] * L
         for l in range(L):
             ps = _params_struct(params[l * nper:(l + 1) * nper], g, variant)
             keep.append(ps)
             ly = layers[l]
             ly.desc, ly.params = descs[l], ctypes.pointer(ps)
+            if drops is not None and drops[l] is not None:
+                yds[l] = torch.empty_like(ys[l])
+                dr = _lib.Dropout(float(drops[l][0]), int(drops[l][2]), drops[l][1].data_ptr(), yds[l].data_ptr())
+                keep.append(dr)
+                ly.drop = ctypes.pointer(dr)
             ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[0, l].data_ptr(), hc[1, l].data_ptr()
             ly.reserve = None if reserves[l] is None else reserves[l].data_ptr()
             ly.h0 = None if h0c is None else h0c[l].data_ptr()
@@ -481,9 +501,12 @@ class VmlmfStackFn(torch.autograd.Function):
             ctx.cfg, ctx.L, ctx.nper, ctx.plan = cfg, L, nper, plan
             ctx.has_head, ctx.has_head_b = hw is not None, hb is not None
             ctx.has_h0, ctx.has_c0 = h0c is not None, c0c is not None
+            ctx.drops = None if drops is None else [None if d is None else (float(d[0]), int(d[2])) for d in drops]
+            dsaved = [] if drops is None else [t for l in range(L) if drops[l] is not None for t in (yds[l], drops[l][1])]
             ctx.save_for_backward(x, *ys, *reserves, *params, *([hw] if hw is not None else []),
-                                  *([h0c] if h0c is not None else []), *([c0c] if c0c is not None else []))
-        return (ys[-1],) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L)) + (logits,)
+                                  *([h0c] if h0c is not None else []), *([c0c] if c0c is not None else []), *dsaved)
+        top = ys[-1] if yds[-1] is None else yds[-1]
+        return (top,) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L)) + (logits,)
 
     @staticmethod
     def backward(ctx, dy, *dstates):
@@ -492,6 +515,13 @@ class VmlmfStackFn(torch.autograd.Function):
         descs, rbytes, wbytes = ctx.plan
         saved = ctx.saved_tensors
         x, ys, reserves, params = saved[0], saved[1:1 + L], saved[1 + L:1 + 2 * L], list(saved[1 + 2 * L:])
+        dsaved = {}
+        if ctx.drops is not None:     # (dropped copy, snapshot) of every layer with a dropout, saved behind everything else
+            for l in reversed(range(L)):
+                if ctx.drops[l] is not None:
+                    snap = params.pop()
+                    yd = params.pop()
+                    dsaved[l] = (yd, snap)
         c0 = params.pop() if ctx.has_c0 else None
         h0 = params.pop() if ctx.has_h0 else None
         hw = params.pop() if ctx.has_head else None
@@ -522,6 +552,10 @@ class VmlmfStackFn(torch.autograd.Function):
             keep += [ps, gs]
             ly = layers[l]
             ly.desc, ly.params, ly.grads = descs[l], ctypes.pointer(ps), ctypes.pointer(gs)
+            if l in dsaved:   # the launch regenerates the forward's factors; the layer above's weight gradients read the dropped copy
+                dr = _lib.Dropout(ctx.drops[l][0], ctx.drops[l][1], dsaved[l][1].data_ptr(), dsaved[l][0].data_ptr())
+                keep.append(dr)
+                ly.drop = ctypes.pointer(dr)
             ly.y, ly.reserve = ys[l].data_ptr(), reserves[l].data_ptr()
             ly.h0 = None if h0 is None else h0[l].data_ptr()
             ly.c0 = None if c0 is None else c0[l].data_ptr()
@@ -542,7 +576,7 @@ class VmlmfStackFn(torch.autograd.Function):
             _lib.check(_lib.lib().vmlmf_stack_backward(L, ctypes.addressof(layers), x.data_ptr(), _ptr(dy), _ptr(dx),
                                                        ctypes.addressof(hd) if use_head else None, ws.data_ptr(), wbytes,
                                                        _lib.raw_stream(dev)))
-        return (None, None, dx, dW, db, dh0, dc0) + tuple(grads)
+        return (None, None, dx, dW, db, dh0, dc0, None) + tuple(grads)
 
 
 def stack_mode():
@@ -554,7 +588,7 @@ def stack_mode():
     return os.environ.get("VMLMF_STACK", "auto")
 
 
-def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", head=None, h0=None, c0=None):
+def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False, dtype="f32", head=None, h0=None, c0=None, drops=None):
     """Run a stack of VMLMF layers (zero initial states) in one wavefront launch per direction.  layer_params: one parameter
     tuple per layer, in vmlmf_sequence's order.  Returns (y of the top layer, [hT per layer], [cT per layer]) or None when
     the stack is not covered / not worth it (the caller then chains vmlmf_sequence calls).  head: (weight (C, H), bias or
@@ -582,14 +616,20 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
                                             or (head is not None and any(t is not None and t.requires_grad for t in head)))
     if _stack_plan(cfg, L, B, T, x.shape[2], H, training) is None:
         return None
+    if drops is not None and any(d is not None for d in drops):
+        # drops: per layer None / (p, snapshot, site) - only the clustered form applies dropout inside its launches
+        if not stack_takes_dropout(cfg, L, B, T, x.shape[2], H, training):
+            return None
+    else:
+        drops = None
     flat = [p for ps in layer_params for p in ps]
     hw, hb = (None, None) if head is None else head
     ops = torch_ops()
-    if ops is not None and h0 is None and c0 is None and dt == _lib.DT_F32:      # (initial states, the bf16 tape: the ctypes form below)
+    if ops is not None and h0 is None and c0 is None and dt == _lib.DT_F32 and drops is None:      # (initial states, the bf16 tape, dropout: the ctypes form below)
         y, hT, cT, logits = ops.stack(x, flat, L, variant, int(w_rank), list(ur), int(g), bool(time_major), hw, hb)
         out = (y, list(hT.unbind(0)), list(cT.unbind(0)))
         return out + (logits,) if head is not None else out
-    res = VmlmfStackFn.apply(cfg, L, x, hw, hb, h0, c0, *flat)
+    res = VmlmfStackFn.apply(cfg, L, x, hw, hb, h0, c0, drops, *flat)
     out = (res[0], list(res[1:1 + L]), list(res[1 + L:1 + 2 * L]))
     return out + (res[1 + 2 * L],) if head is not None else out
 

@@ -179,6 +179,37 @@ class Linear(nn.Module):
         return f"FC(input: {self.input_size}, output: {self.hidden_size})"
 
 
+def stack_layers(rnns, x, states, drops=None):
+    """The layer loop of Model.forward (vmlmf_lm.py:437-439: `x, states[i] = rnn(x, states[i]); x = dropout(x)`) as ONE launch per
+    direction with the carried states as initial states (functional.vmlmf_stack): the wavefront kernels for hidden sizes up to 256
+    (MyVMLSTM layers, no dropout between the layers), or - layers of the PTB size, MyVMLSTM or MyVMLSTMGroup, at batch sizes whose
+    clusters are co-resident for all layers (up to 128 rows for two layers: what a GPU of an 8-GPU node holds of configs[4]) - the
+    clustered form (csrc/vmlmf_rbx.hip), which also applies the dropout behind every layer inside its launches (drops: one
+    (p, snapshot, site) per layer; the returned activations are then the top layer's dropped copy).
+    Returns (y, [(hT, cT) per layer]), or None when the stack is not covered: the caller loops over the layers."""
+    rnns = list(rnns)
+    if not x.is_cuda or len(rnns) < 2:
+        return None
+    kind = type(rnns[0])
+    if kind not in (MyVMLSTM, MyVMLSTMGroup) or not all(type(r) is kind for r in rnns):
+        return None
+    r0 = rnns[0]
+    if any((r.input_size, r.hidden_size, r.w_rank, r.u_ranks) != (r0.input_size, r0.hidden_size, r0.w_rank, r0.u_ranks) for r in rnns):
+        return None
+    if any(getattr(r, "compute_dtype", "f32") != "f32" for r in rnns):
+        return None
+    from .functional import vmlmf_stack
+    h0 = torch.stack([st[0] for st in states])
+    c0 = torch.stack([st[1] for st in states])
+    ur = r0.u_ranks if isinstance(r0.u_ranks, (list, tuple)) else [r0.u_ranks]
+    out = vmlmf_stack(variant=r0.variant, x=x, layer_params=[r.kernel_params() for r in rnns], w_rank=r0.w_rank,
+                      u_ranks=list(ur), g=getattr(r0, "g", 1), time_major=True, h0=h0, c0=c0, drops=drops)
+    if out is None:
+        return None
+    y, hs, cs = out
+    return y, [(hs[i], cs[i]) for i in range(len(rnns))]
+
+
 class Model(nn.Module):
     """The language model of lm_test.py (vmlmf_lm.py:366-440): Embed -> dropout -> layer_num x (LSTM layer ->
     dropout) -> Linear.  Constructor logic is the reference's, quirks included: `u_ranks` is reduced to its last
@@ -240,31 +271,11 @@ class Model(nn.Module):
     def detach(self, states):
         return [(h.detach(), c.detach()) for (h, c) in states]
 
-    def _stack(self, x, states):
-        """The layer loop of forward() (vmlmf_lm.py:437-439) as ONE wavefront launch per direction with the carried states as
-        initial states (functional.vmlmf_stack), when that gives the same values: no dropout between the layers (p = 0 or
-        eval mode), MyVMLSTM layers of one configuration, and a stack the wavefront kernels cover (hidden sizes up to 256).
-        None otherwise: the caller loops over the layers."""
-        if (self.training and self.dropout.p > 0) or not x.is_cuda or len(self.rnns) < 2:
+    def _stack(self, x, states, drops=None):
+        """stack_layers() on this model's layers, unless dropout is active and not handed in (`drops`)."""
+        if (self.training and self.dropout.p > 0) and drops is None:
             return None
-        if not all(type(r) is MyVMLSTM for r in self.rnns):
-            return None
-        r0 = self.rnns[0]
-        if any((r.input_size, r.hidden_size, r.w_rank, r.u_ranks) != (r0.input_size, r0.hidden_size, r0.w_rank, r0.u_ranks)
-               for r in self.rnns):
-            return None
-        if any(getattr(r, "compute_dtype", "f32") != "f32" for r in self.rnns):
-            return None
-        from .functional import vmlmf_stack
-        h0 = torch.stack([st[0] for st in states])
-        c0 = torch.stack([st[1] for st in states])
-        ur = r0.u_ranks if isinstance(r0.u_ranks, (list, tuple)) else [r0.u_ranks]
-        out = vmlmf_stack(variant=r0.variant, x=x, layer_params=[r.kernel_params() for r in self.rnns], w_rank=r0.w_rank,
-                          u_ranks=list(ur), g=1, time_major=True, h0=h0, c0=c0)
-        if out is None:
-            return None
-        y, hs, cs = out
-        return y, [(hs[i], cs[i]) for i in range(len(self.rnns))]
+        return stack_layers(self.rnns, x, states, drops)
 
     def forward(self, x, states):
         x, states = self.features(x, states)
@@ -289,6 +300,12 @@ class Model(nn.Module):
             from .functional import dropout, dropout_advance, embedding_dropout
             snap = dropout_advance(self.dropout_state())
             x = embedding_dropout(self.embed.w, x, p, snap, 0)
+            stacked = self._stack(x, states, drops=[(p, snap, i + 1) for i in range(len(self.rnns))])
+            if stacked is not None:       # every layer in one launch per direction, the dropouts behind them inside it
+                x, new_states = stacked
+                for i, st in enumerate(new_states):
+                    states[i] = st
+                return x, states
             for i, rnn in enumerate(self.rnns):
                 if isinstance(rnn, (MyVMLSTM, MyVMLSTMGroup)):
                     x, states[i] = rnn(x, states[i], drop=(p, snap, i + 1))
