@@ -800,7 +800,9 @@ def test_a_packed_image_made_for_something_else_is_refused():
     assert rc == _lib.E_BADARG and "another descriptor" in lib.vmlmf_last_error().decode()
     stray = torch.zeros(imgA.numel(), device=DEV, dtype=torch.uint8)
     rc, _ = forward(dA, sA, stray, 8, 5, 9, 64)                   # memory vmlmf_pack_params never filled
-    assert rc == _lib.E_BADARG and "not an image" in lib.vmlmf_last_error().decode()
+    # (refused either way: as memory no image was ever packed into - or, when the allocator hands the test an address where an earlier
+    #  test's image lived, as an image packed for another descriptor: the library's registry is keyed by address)
+    assert rc == _lib.E_BADARG and any(m in lib.vmlmf_last_error().decode() for m in ("not an image", "another descriptor"))
     _lib.tune("rec3", 6)                                          # any vmlmf_tune() call moves the generation
     rc, _ = forward(dA, sA, imgA, 8, 5, 9, 64)
     assert rc == _lib.E_BADARG

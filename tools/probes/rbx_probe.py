@@ -10,7 +10,8 @@ from vmlmf_amd.lm import MyVMLSTM, MyVMLSTMGroup
 plain = "--plain" in sys.argv
 T, H = 35, 650
 torch.manual_seed(0)
-layers = [(MyVMLSTM(H, H, w_rank=32, u_ranks=32) if plain else MyVMLSTMGroup(H, H, w_rank=32, u_ranks=[32, 32], g=2)).cuda() for _ in range(2)]
+NL = 1 if "--one" in sys.argv else 2
+layers = [(MyVMLSTM(H, H, w_rank=32, u_ranks=32) if plain else MyVMLSTMGroup(H, H, w_rank=32, u_ranks=[32, 32], g=2)).cuda() for _ in range(NL)]
 for l in layers:
     for p in l.parameters():
         torch.nn.init.uniform_(p, -0.05, 0.05)
@@ -72,9 +73,14 @@ for B in [int(a) for a in sys.argv[1:] if a.isdigit()] or [32, 64, 128]:
         out[0].sum().backward()
 
     rec = {"B": B, "plain": plain}
-    rec["chained_eager_ms"] = round(timed(chained), 4)
-    rec["stacked_eager_ms"] = round(timed(stacked), 4)
-    rec["chained_graph_ms"] = round(graphed(chained), 4)
-    rec["stacked_graph_ms"] = round(graphed(stacked), 4)
+    if "--stacked-only" in sys.argv:      # (for rocprofv3 --kernel-trace --stats: 23 eager steps of the one-launch form, nothing else)
+        rec["stacked_eager_ms"] = round(timed(stacked), 4)
+    elif "--chained-only" in sys.argv:
+        rec["chained_eager_ms"] = round(timed(chained), 4)
+    else:
+        rec["chained_eager_ms"] = round(timed(chained), 4)
+        rec["stacked_eager_ms"] = round(timed(stacked), 4)
+        rec["chained_graph_ms"] = round(graphed(chained), 4)
+        rec["stacked_graph_ms"] = round(graphed(stacked), 4)
     rec["status"] = _lib.lib().vmlmf_check_status()
     print(json.dumps(rec), flush=True)

@@ -343,7 +343,43 @@ class Net(nn.Module):
         u = u_rank[-1] if cell == MyVMLMFCell else u_rank
         self.cell = cell(input_size, layer_sizes[-1], w_rank=w_rank, u_ranks=u)
 
+    def _fast(self, x):
+        """The per-call plan of the headline family - ONE VMLMF layer with a narrow input (its x side rides inside the recurrent
+        launch) under a classifier of at most 32 classes, fp32 on a HIP device, the C++ binding loaded: everything run_layers() and
+        vmlmf_sequence() would find out again on every call, found out once.  (cell's parameter dict, constants of the C++ op) or None.
+        Invalidated by anything that changes the answer: another device / dtype, kept parameter images, a compute dtype, the
+        VMLMF_STACK mode (read at build time only for mode "1", which routes single layers to the wavefront launch)."""
+        plan = self.__dict__.get("_fast_plan")
+        if plan is None:
+            plan = False
+            rnn = self.rnn
+            if (type(rnn) is MyLSTM and rnn.batch_first and len(rnn.rnncells) == 1 and type(rnn.rnncells[0]) is MyVMLMFCell
+                    and stack_mode() != "1"):
+                cell = rnn.rnncells[0]
+                from .functional import torch_ops
+                ops = torch_ops()
+                if (ops is not None and cell.input_size <= 16 and cell.hidden_size <= 192 and self.lin.weight.shape[0] <= _lib.HEAD_MAX_CLASSES
+                        and self.lin.weight.dtype == torch.float32):
+                    plan = (ops, cell, cell._parameters, self.lin._parameters, int(cell.w_rank), [int(cell.u_ranks)])
+            self.__dict__["_fast_plan"] = plan
+        if plan is False or not x.is_cuda or x.dtype != torch.float32 or x.dim() != 3:
+            return None
+        cd = plan[1].__dict__
+        if cd.get("_pack_cache") is not None or cd.get("compute_dtype", "f32") != "f32":
+            return None
+        return plan
+
+    def _apply(self, fn, *args, **kwargs):   # .to() / .cuda() / .float(): the plan is looked up again
+        self.__dict__.pop("_fast_plan", None)
+        return super()._apply(fn, *args, **kwargs)
+
     def forward(self, x):
+        plan = self._fast(x)
+        if plan is not None:
+            ops, cell, cp, lp, rw, ur = plan
+            out = ops.sequence(x, None, None, [cp["dia_x"], cp["dia_h"], cp["u_x"], cp["v_x"], cp["b_x"], cp["b_h"], cp["u_h"], cp["v_h"]],
+                               cell.variant, 1, rw, ur, False, 0, None, lp["weight"], lp["bias"])
+            return out[3].squeeze(1)
         if isinstance(self.rnn, MyLSTM) and self.rnn.batch_first:
             # y[:, -1] IS the last layer's final h (same kernel value): taking it from there keeps autograd
             # from materialising a zero (B,T,H) gradient for y just to carry its last slice
@@ -370,6 +406,14 @@ class Net(nn.Module):
         row's logits, log-sum-exp, loss term and d(loss)/d(logits) come out of the forward recurrence's epilogue, and the backward
         needs no criterion launch either.  Same values as the two lines (the mean's summation order differs); wherever the classifier
         cannot ride (CPU tensors, other dtypes, more than 32 classes, stacks on the wavefront launches) it IS the two lines."""
+        plan = self._fast(x) if (target.dtype == torch.int64 and target.dim() == 1) else None
+        if plan is not None:
+            from .functional import ce_ticket, unit_gradient
+            ops, cell, cp, lp, rw, ur = plan
+            out = ops.sequence_loss(x, None, None, [cp["dia_x"], cp["dia_h"], cp["u_x"], cp["v_x"], cp["b_x"], cp["b_h"], cp["u_h"], cp["v_h"]],
+                                    cell.variant, 1, rw, ur, False, 0, None, lp["weight"], lp["bias"], target, int(ignore_index),
+                                    unit_gradient(x.device), ce_ticket(x.device))
+            return (out[4], out[3]) if return_logits else out[4]
         ride = (isinstance(self.rnn, MyLSTM) and self.rnn.batch_first and x.is_cuda and x.dtype == torch.float32
                 and self.lin.weight.shape[0] <= _lib.HEAD_MAX_CLASSES and self.lin.weight.dtype == torch.float32
                 and target.dtype == torch.int64 and target.dim() == 1)

@@ -1053,7 +1053,7 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
     VGeo g0;
     if (d0.dtype == VMLMF_DT_F32 && make_geo(&d0, &g0, &q0) == 0 && g0.generic && g0.rb > 1) {
       if (!g_rbx) return fail(VMLMF_E_UNSUPPORTED, "stack: the clustered form is switched off (VMLMF_RBX=0)");
-      if (L < 2) return fail(VMLMF_E_UNSUPPORTED, "stack: a single clustered layer runs as vmlmf_seq_forward");
+      if (L < 2 && g_rbx != 2) return fail(VMLMF_E_UNSUPPORTED, "stack: a single clustered layer runs as vmlmf_seq_forward");
       if (L > RBX_MAXL) return fail(VMLMF_E_UNSUPPORTED, "stack: at most four clustered layers");
       for (int l = 0; l < L; ++l) {
         RbGeo ql;
@@ -1161,6 +1161,10 @@ static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, co
   RbxFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.status = status_word(s), a.L = L;
+  RefP rps[RBX_MAXL];
+  float* packs[RBX_MAXL];
+  float* imgs[RBX_MAXL];
+  unsigned* fflags[RBX_MAXL];
   for (int l = 0; l < L; ++l) {
     const VGeo& g = S.g[l];
     if ((rc = check_params(g, ly[l].params)) != 0) return rc;
@@ -1170,12 +1174,7 @@ static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, co
     const Layout& Lr = S.lay[l];
     float* wl = ws + S.ws_layer[l];
     float* pack = training ? rs + Lr.r_pack : wl + Lr.f_pack;
-    const RefP rp = to_refp(ly[l].params);
-    {
-      Scope sc(0, s);
-      if ((rc = hip_fail(launch_pack(g, rp, S.P[l], pack, s), "pack")) != 0) return rc;
-      if ((rc = hip_fail(launch_rb_pack(g, S.q, rp, pack + S.P[l].RB, s, reinterpret_cast<unsigned*>(wl + Lr.f_flag)), "rb_pack")) != 0) return rc;
-    }
+    rps[l] = to_refp(ly[l].params), packs[l] = pack, imgs[l] = pack + S.P[l].RB, fflags[l] = reinterpret_cast<unsigned*>(wl + Lr.f_flag);
     RbxLayerF& w = a.l[l];
     if ((rc = rbx_drop(ly[l].drop, true, &w.drop)) != 0) return rc;
     // the layer's input: x, or the rows of the layer below (their dropped copy under dropout)
@@ -1187,6 +1186,14 @@ static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, co
     w.xq = wl + Lr.f_xq, w.flag = reinterpret_cast<unsigned*>(wl + Lr.f_flag);
     w.pflag = l > 0 ? reinterpret_cast<unsigned*>(ws + S.ws_layer[l - 1] + S.lay[l - 1].f_flag) : nullptr;
     w.pub = l < L - 1 ? 1 : 0;
+  }
+  {   // every layer's parameter images in two launches (pack_kernel's for all layers, the clusters' MFMA operand images for all
+      // layers; the second also clears the forward launch's epoch words)
+    Scope sc(0, s);
+    WfPack W0;
+    memset(&W0, 0, sizeof(W0));
+    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s), "pack")) != 0) return rc;
+    if ((rc = hip_fail(launch_rb_pack_stack(S.g[0], S.q, L, rps, imgs, fflags, s), "rb_pack")) != 0) return rc;
   }
   Scope sc(2, s);
   return hip_fail(launch_rbx_fwd(S.g[0], S.q, a, s), "rbx_fwd");

@@ -121,6 +121,7 @@ int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s);
 // qx = x U_x over all rows of a large time-major layer
 int generic_qx(const VGeo& g, const float* x, const float* UXP, float* qx, hipStream_t s);
 
+constexpr int RBX_MAXL = 4;   // layers of a clustered stack (vmlmf_rbx.hip)
 // row-block MFMA recurrent kernels (vmlmf_rb.hip)
 struct RbIo {
   const float *gx, *EH, *h0, *c0, *img, *dy, *dhT, *dcT;
@@ -141,7 +142,6 @@ bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0, int xf = 0);
 // but the rows y_l[t] (their dropped copy under dropout), which it takes from L2 a few steps behind: a member reads the 16 units of
 // its own tiles, written by the SAME member index of the layer below, whose epoch word says when they are complete.  Backward: the
 // same with dx_l[t] going down.  Needs L x (row blocks) x S workgroups co-resident (one per CU).
-constexpr int RBX_MAXL = 4;
 struct RbxLayerF {
   const float *x, *EH, *EXT, *BBT, *h0, *c0, *img;
   float *y, *hT, *cT, *gates, *cs, *Qs, *qx;
@@ -181,6 +181,8 @@ int launch_rbx_bwd(const VGeo& g, const RbGeo& q, const RbxBwdArgs& a, hipStream
 int launch_rbx_zero(const VGeo& g, const RbGeo& q, int L, float* const* dpre, unsigned* const* flags, hipStream_t s);
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags = nullptr);
 int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
+// rb_pack_kernel for every layer of a clustered stack (all layers share the geometry) in one launch
+int launch_rb_pack_stack(const VGeo& g, const RbGeo& q, int L, const RefP* p, float* const* img, unsigned* const* zero_flags, hipStream_t s);
 int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 
 // every launcher returns hipGetLastError() of its launch, or VMLMF_E_UNSUPPORTED (-3) when no

@@ -19,6 +19,7 @@
 // and for layers beyond the register-resident VALU kernels.  Same tapes, so the weight-gradient kernels are shared.
 #include "vmlmf_launch.h"
 #include <cstring>
+#include <cstddef>
 
 namespace {
 
@@ -81,7 +82,7 @@ __device__ inline float rb_vx(const VGeo& g, const RefP& p, int slot, int k, int
 // ---------------------------------------------------------------------------------------------------
 // `flags` (or NULL): the cluster's epoch words of the forward launch behind this one, zeroed here instead of by a memset node of
 // their own (a 5 us launch for 1 KB)
-__global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out, unsigned* __restrict__ flags) {
+__device__ __forceinline__ void rb_pack_body(const VGeo& g, const RbGeo& q, const RefP& p, float* __restrict__ out, unsigned* __restrict__ flags) {
   if (flags != nullptr && blockIdx.x == 0)
     for (int i = threadIdx.x; i < (int)q.flag_words; i += 256) flags[i] = 0u;
   // 32-bit index arithmetic throughout (64-bit divisions by run-time values cost hundreds of cycles each: the first
@@ -159,6 +160,23 @@ __global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, f
     rb_tile(g, q, tv, grp, sb, n0);
     out[q.UB + le] = rb_udz(g, p, 16 * m + 4 * r + kq, sb + c);
   }
+}
+__global__ void __launch_bounds__(256) rb_pack_kernel(VGeo g, RbGeo q, RefP p, float* __restrict__ out, unsigned* __restrict__ flags) {
+  rb_pack_body(g, q, p, out, flags);
+}
+// the same for every layer of a stack of clustered layers (vmlmf_rbx.hip) in one launch: blockIdx.y = layer
+struct RbPackStackArgs {
+  RefP p[RBX_MAXL];
+  float* out[RBX_MAXL];
+  unsigned* flags[RBX_MAXL];
+};
+__global__ void __launch_bounds__(256) rb_pack_stack_kernel(VGeo g, RbGeo q, RbPackStackArgs a) {
+  constexpr size_t KA = (((sizeof(VGeo) + 7) & ~(size_t)7) + sizeof(RbGeo) + 7) & ~(size_t)7;
+  const int l = blockIdx.y;
+  const RefP& p = vg_karg_ref<RefP>(KA + offsetof(RbPackStackArgs, p) + (size_t)l * sizeof(RefP));
+  float* out = l == 0 ? a.out[0] : l == 1 ? a.out[1] : l == 2 ? a.out[2] : a.out[3];
+  unsigned* flags = l == 0 ? a.flags[0] : l == 1 ? a.flags[1] : l == 2 ? a.flags[2] : a.flags[3];
+  rb_pack_body(g, q, p, out, flags);
 }
 
 // dpre of the slots no tile covers (wholly padded 16-slot tiles behind a group's last unit) must read as zero in the
@@ -284,6 +302,15 @@ int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hip
   // image is a multiple of 64 floats); the x-side images follow densely from q.UXA
   const long long blocks = (q.total + 255) / 256;
   hipLaunchKernelGGL(rb_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, g, q, p, img, q.S > 1 ? zero_flags : nullptr);
+  return (int)hipGetLastError();
+}
+
+int launch_rb_pack_stack(const VGeo& g, const RbGeo& q, int L, const RefP* p, float* const* img, unsigned* const* zero_flags, hipStream_t s) {
+  if (q.total >= (1LL << 30) || L > RBX_MAXL) return -3;
+  RbPackStackArgs a;
+  memset(&a, 0, sizeof(a));
+  for (int l = 0; l < L; ++l) a.p[l] = p[l], a.out[l] = img[l], a.flags[l] = zero_flags[l];
+  hipLaunchKernelGGL(rb_pack_stack_kernel, dim3((unsigned)((q.total + 255) / 256), (unsigned)L), dim3(256), 0, s, g, q, a);
   return (int)hipGetLastError();
 }
 

@@ -67,6 +67,7 @@ class Adam(torch.optim.Optimizer):
             self._flat = {}
         gs = self._flat.get(gi)
         if gs is None:
+            self._step_cache = None   # (new moment buffers: the remembered argument blocks point at the old ones)
             ps = group["params"]
             dev = ps[0].device
             total, offs, sidx = 0, {}, {}
@@ -114,6 +115,23 @@ class Adam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         lib = _lib.lib()
+        # The step's launches are a pure function of the addresses involved and the groups' hyper-parameters: when neither has changed
+        # since the last step (the usual case: backward hands the same allocator blocks back, step after step) the argument blocks
+        # built then are used again - the Python below costs 2-3x the launch it prepares (host path: tools/probes/host_path.py).
+        key = []
+        for group in self.param_groups:
+            key.append((group["lr"], group["betas"], group["eps"], group["weight_decay"]))
+            for p in group["params"]:
+                g = p.grad
+                key.append(None if g is None else (p.data_ptr(), g.data_ptr(), g.is_contiguous()))
+        key = tuple(key)
+        cached = self.__dict__.get("_step_cache")
+        if cached is not None and cached[0] == key and all(k[2] for k in key if k is not None and len(k) == 3):
+            for args, live in cached[1]:
+                with _lib.on_device(live[0].device):
+                    _lib.check(lib.vmlmf_adam_step_ex(*args[:-1], _lib.raw_stream(live[0].device)))
+                _bump_versions(live)
+            return loss
         # every launch of the step first (tensor lists of every group), then FIRST on the first and LAST on the last of them: one
         # verdict on the step's gradients for all of them (include/vmlmf_hip.h: vmlmf_adam_step_ex)
         calls = []
@@ -130,16 +148,20 @@ class Adam(torch.optim.Optimizer):
             for tl in _tensor_lists(pairs, [gs["offs"][p] for p in live], [gs["sidx"][p] for p in live]):
                 calls.append((tl, gs, group, live, pairs))   # pairs: the .contiguous() copies live until their launch is issued
         guard = getattr(self, "_guard", None)
+        kept = []
         for ci, (tl, gs, group, live, _keep) in enumerate(calls):
             dev = live[0].device
             b1, b2 = group["betas"]
             flags = (_lib.ADAM_FIRST if ci == 0 else 0) | (_lib.ADAM_LAST if ci == len(calls) - 1 else 0)
+            args = (ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(), gs["steps"].data_ptr(), float(group["lr"]), float(b1),
+                    float(b2), float(group["eps"]), float(group["weight_decay"]), None if guard is None else guard.data_ptr(), flags,
+                    _lib.raw_stream(dev))
             with _lib.on_device(dev):
-                _lib.check(lib.vmlmf_adam_step_ex(ctypes.byref(tl), gs["m"].data_ptr(), gs["v"].data_ptr(), gs["steps"].data_ptr(),
-                                                  float(group["lr"]), float(b1), float(b2), float(group["eps"]),
-                                                  float(group["weight_decay"]), None if guard is None else guard.data_ptr(), flags,
-                                                  _lib.raw_stream(dev)))
+                _lib.check(lib.vmlmf_adam_step_ex(*args))
             _bump_versions(live)
+            kept.append((args + (tl,), live))   # (tl keeps the struct byref points at alive; the stream is taken anew at every step)
+        # (only steps whose gradients were all contiguous are remembered: a .contiguous() copy has a new address every step anyway)
+        self._step_cache = (key, [(a[:-1], live) for a, live in kept], [a[-1] for a, _ in kept])
         return loss
 
 
