@@ -1237,11 +1237,68 @@ static int rbx_stack_backward(const StackPlan& S, const vmlmf_stack_layer* ly, c
   }
   HeadBwd hb;
   memset(&hb, 0, sizeof(hb));
-  for (int l = L - 1; l >= 0; --l) {   // the batched half of every layer: weight-gradient products, their sum, the reference layouts
+  // the batched half of every layer: weight-gradient products (per layer: the ring kernel fills the chip), then ONE launch that sums
+  // every layer's partial blocks and ONE that writes every layer's reference-layout gradients
+  const bool ring = g_wring != 0 && wgrad_ring_ok(S.g[0]) && (g_wring > 0 || (long long)S.g[0].T * S.g[0].B >= 1024);
+  if (!ring) {
+    for (int l = L - 1; l >= 0; --l) {
+      const float* xl = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
+      if ((rc = backward_tail(S.g[l], S.lay[l], ly[l].params, ly[l].grads, xl, ly[l].y, ly[l].h0, (const float*)ly[l].reserve,
+                              ws + S.ws_layer[l], hb, s)) != 0)
+        return rc;
+    }
+    return 0;
+  }
+  ReduceCounts wcs[RBX_MAXL];
+  const float* wparts[RBX_MAXL];
+  float* cgs[RBX_MAXL];
+  const float* ccgs[RBX_MAXL];
+  RefP rps[RBX_MAXL];
+  RefG ogs[RBX_MAXL];
+  for (int l = L - 1; l >= 0; --l) {
     const float* xl = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
-    if ((rc = backward_tail(S.g[l], S.lay[l], ly[l].params, ly[l].grads, xl, ly[l].y, ly[l].h0, (const float*)ly[l].reserve,
-                            ws + S.ws_layer[l], hb, s)) != 0)
-      return rc;
+    float* wl = ws + S.ws_layer[l];
+    const WghArgs wh = wgrad_args(S.lay[l], xl, ly[l].y, ly[l].h0, (const float*)ly[l].reserve, wl);
+    int nc[3] = {0, 0, 0};
+    {
+      Scope sc(5, s);
+      const int rr = launch_wgrad_ring(S.g[l], wh, device_cus(), nc, s);
+      if (rr == -3) {   // no LDS / instantiation for the ring on this device: the per-layer path for every layer from here
+        for (int k = l; k >= 0; --k) {
+          const float* xk = k == 0 ? x : (ly[k - 1].drop != nullptr ? ly[k - 1].drop->y_dropped : ly[k - 1].y);
+          if ((rc = backward_tail(S.g[k], S.lay[k], ly[k].params, ly[k].grads, xk, ly[k].y, ly[k].h0, (const float*)ly[k].reserve,
+                                  ws + S.ws_layer[k], hb, s)) != 0)
+            return rc;
+        }
+        // (the layers above l: their blocks are formed, finish them one by one)
+        for (int k = L - 1; k > l; --k) {
+          {
+            Scope sc6(6, s);
+            if ((rc = hip_fail(launch_reduce(S.g[k], wparts[k], cgs[k], nullptr, s, wcs[k]), "reduce")) != 0) return rc;
+          }
+          Scope sc7(7, s);
+          if ((rc = hip_fail(launch_finish(S.g[k], rps[k], cgs[k], ogs[k], hb, s, health_word(s)), "finish")) != 0) return rc;
+        }
+        return 0;
+      }
+      if ((rc = hip_fail(rr, "wgrad")) != 0) return rc;
+    }
+    wcs[l] = ReduceCounts{{nc[0], nc[1], nc[2]}};
+    wparts[l] = wl + S.lay[l].b_wpart, cgs[l] = wl + S.lay[l].b_cgrad, ccgs[l] = cgs[l];
+    rps[l] = to_refp(ly[l].params);
+    const vmlmf_grads* gr = ly[l].grads;
+    RefG& og = ogs[l];
+    og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
+    og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
+    for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
+  }
+  {
+    Scope sc(6, s);
+    if ((rc = hip_fail(launch_reduce_stack(L, S.g, wparts, cgs, s, wcs), "reduce")) != 0) return rc;
+  }
+  {
+    Scope sc(7, s);
+    if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb, s, health_word(s)), "finish")) != 0) return rc;
   }
   return 0;
 }

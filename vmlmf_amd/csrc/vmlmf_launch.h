@@ -317,7 +317,8 @@ int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 // the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)
 int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
-int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
+int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s,
+                        const ReduceCounts* wc = nullptr);   // wc: per layer, the chunk counts of a wgrad_ring_kernel launch (or NULL)
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
                         hipStream_t s, unsigned* health = nullptr);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
 

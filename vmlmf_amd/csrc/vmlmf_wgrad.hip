@@ -251,12 +251,14 @@ struct ReduceStack {
   VGeo g[WF_MAXL];
   const float* P[WF_MAXL];
   float* cg[WF_MAXL];
+  ReduceCounts wc[WF_MAXL];   // (all zero: g.nchunk blocks hold every region - the wavefront stacks; else wgrad_ring_kernel's per-product counts)
 };
 __global__ void __launch_bounds__(256) reduce_cg_stack_kernel(ReduceStack S) {   // grid.y = layer
   const VGeo& g = vg_karg_ref<VGeo>(offsetof(ReduceStack, g) + (size_t)blockIdx.y * sizeof(VGeo));
   const float* P = vg_karg_ref<const float*>(offsetof(ReduceStack, P) + (size_t)blockIdx.y * sizeof(float*));
   float* cg = vg_karg_ref<float*>(offsetof(ReduceStack, cg) + (size_t)blockIdx.y * sizeof(float*));
-  reduce_cg_body(g, P, cg);
+  const ReduceCounts wc = vg_karg_ref<ReduceCounts>(offsetof(ReduceStack, wc) + (size_t)blockIdx.y * sizeof(ReduceCounts));
+  reduce_cg_body(g, P, cg, wc);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -359,12 +361,14 @@ int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s) 
   return (int)hipGetLastError();
 }
 
-int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s) {
+int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s, const ReduceCounts* wc) {
+  static_assert(sizeof(ReduceStack) <= 4096, "kernel-argument segment");
   ReduceStack S;
   memset(&S, 0, sizeof(S));
   long long pch = 0;
   for (int l = 0; l < L; ++l) {
     S.g[l] = g[l], S.P[l] = wpart[l], S.cg[l] = cgrad[l];
+    if (wc != nullptr) S.wc[l] = wc[l];
     pch = g[l].PCH > pch ? g[l].PCH : pch;
   }
   hipLaunchKernelGGL(reduce_cg_stack_kernel, dim3((unsigned)((pch + 255) / 256), L), dim3(256), 0, s, S);
