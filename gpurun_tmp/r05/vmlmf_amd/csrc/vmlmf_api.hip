@@ -693,7 +693,7 @@ int vmlmf_seq_forward(const vmlmf_desc* d, const vmlmf_params* p, const float* x
 int vmlmf_seq_forward_packed(const vmlmf_desc* d, const vmlmf_params* p, const float* x, const float* h0,
                              const float* c0, float* y, float* hT, float* cT, void* reserve, void* workspace,
                              size_t workspace_bytes, void* stream, const void* packed) {
-  vmlmf_extra ex = {};   // every field the caller does not set is a null pointer (drop, ce, ...)
+  vmlmf_extra ex;
   ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_forward_ex(d, p, x, h0, c0, y, hT, cT, reserve, workspace, workspace_bytes, stream, &ex);
 }
@@ -873,7 +873,7 @@ int vmlmf_seq_backward_packed(const vmlmf_desc* d, const vmlmf_params* p, const 
                               const float* dhT, const float* dcT, float* dx, float* dh0, float* dc0,
                               const vmlmf_grads* gr, void* workspace, size_t workspace_bytes, void* stream,
                               const void* packed) {
-  vmlmf_extra ex = {};   // every field the caller does not set is a null pointer (drop, ce, ...)
+  vmlmf_extra ex;
   ex.packed = packed, ex.head = nullptr, ex.ce = nullptr;
   return vmlmf_seq_backward_ex(d, p, x, h0, c0, y, reserve, dy, dhT, dcT, dx, dh0, dc0, gr, workspace, workspace_bytes, stream, &ex);
 }
@@ -1026,17 +1026,8 @@ namespace {
 // launch either way
 const bool g_wf_bwd = []() { const char* e = getenv("VMLMF_WF_BWD"); return e == nullptr || e[0] != '0'; }();
 
-// VMLMF_RBX=0 / vmlmf_tune("rbx", 0): clustered layers are never stacked into one launch (the caller chains them; A/B runs)
-int g_rbx = []() { const char* e = getenv("VMLMF_RBX"); return e ? atoi(e) : 1; }();
-// the stacks' finishing launch sums the partial blocks itself (no reduce launch): 0 = never (default: measured no faster - two PTB
-// group layers at 32 rows 0.710 ms with, 0.702 without, same box; the repeated block sums of the d(ex) / d(eh) rows cost what the
-// launch saves), -1 = the clustered stacks, 1 = the wavefront stacks too.  VMLMF_FFB / vmlmf_tune("ffb"); parity-tested both ways
-int g_ffb = []() { const char* e = getenv("VMLMF_FFB"); return e ? atoi(e) : 0; }();
-
 struct StackPlan {
   int L;
-  bool rbx;    // the clustered form (vmlmf_rbx.hip): every layer on clusters of workgroups, all layers in one launch per direction
-  RbGeo q;     // ... its geometry (all layers alike)
   VGeo g[WF_MAXL];
   VPack P[WF_MAXL];
   WfPack W;
@@ -1050,55 +1041,6 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
   if (L < 1 || L > WF_MAXL) return fail(VMLMF_E_UNSUPPORTED, "stack: 1..4 layers");
   StackPlan& S = *out;
   S.L = L;
-  S.rbx = false;
-  {   // layers on clusters of workgroups (factors beyond one CU): the clustered form, or nothing
-    RbGeo q0;
-    vmlmf_desc d0 = ly[0].desc;
-    VGeo g0;
-    if (d0.dtype == VMLMF_DT_F32 && make_geo(&d0, &g0, &q0) == 0 && g0.generic && g0.rb > 1) {
-      if (!g_rbx) return fail(VMLMF_E_UNSUPPORTED, "stack: the clustered form is switched off (VMLMF_RBX=0)");
-      if (L < 2 && g_rbx != 2) return fail(VMLMF_E_UNSUPPORTED, "stack: a single clustered layer runs as vmlmf_seq_forward");
-      if (L > RBX_MAXL) return fail(VMLMF_E_UNSUPPORTED, "stack: at most four clustered layers");
-      for (int l = 0; l < L; ++l) {
-        RbGeo ql;
-        vmlmf_desc dd = ly[l].desc;
-        const int rc = make_geo(&dd, &S.g[l], &ql);
-        if (rc != 0) return rc;
-        const VGeo& g = S.g[l];
-        if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.I != g0.I || g.rw != g0.rw || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G ||
-            g.time_major != g0.time_major || g.training != g0.training || dd.dtype != VMLMF_DT_F32 || g.rb != g0.rb)
-          return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, sizes, ranks, layout and training flag");
-        if (g.I != g.H || !g.time_major || g.sxT != g.syT || g.sxB != g.syB)
-          return fail(VMLMF_E_UNSUPPORTED, "stack (clustered form): time-major layers with input_size == hidden_size");
-      }
-      // live rows per workgroup: the fewest (4, 8, 16) with which the clusters of ALL layers are co-resident, one workgroup per CU
-      const int cus = device_cus();
-      bool found = false;
-      for (int rows = 4; rows <= 16 && !found; rows *= 2) {
-        RbGeo q;
-        if (!rb_geometry(g0, g0.rb, &q, rows, 1) || !rbx_supported(g0, q)) continue;
-        if ((long long)L * q.nrb * q.S > cus) continue;
-        S.q = q, found = true;
-      }
-      if (!found)
-        return fail(VMLMF_E_UNSUPPORTED, "stack (clustered form): V3 / V4 layers with w_rank 17..32 whose clusters are co-resident for all layers "
-                                         "(L x ceil(B / 16) x 16 workgroups <= CUs)");
-      S.rbx = true;
-      S.flag_words = 0;
-      memset(&S.W, 0, sizeof(S.W));
-      long long o = 0;
-      S.ws_flag = 0;
-      for (int l = 0; l < L; ++l) {
-        S.P[l] = vg_pack_layout(S.g[l], S.q.total, 0);
-        S.lay[l] = make_layout(S.g[l], S.P[l], S.q);
-        const long long per = S.lay[l].f_total > S.lay[l].b_total ? S.lay[l].f_total : S.lay[l].b_total;
-        S.ws_layer[l] = o, o += align64(per);
-        S.ws_dx[l] = o, o += align64(l > 0 ? (long long)g0.T * g0.B * g0.H : 0);
-      }
-      S.ws_total = o;
-      return 0;
-    }
-  }
   for (int l = 0; l < L; ++l) {
     RbGeo q;
     // dtype bf16 on a stack: below the batch where the bf16-MFMA row blocks pay (4096 rows: DESIGN.md section 4.8) the wavefront
@@ -1147,175 +1089,7 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
   S.ws_total = o;
   return 0;
 }
-// ---- the clustered form (vmlmf_rbx.hip)
-static int rbx_drop(const vmlmf_dropout* dr, bool forward, DropArgs* out) {
-  memset(out, 0, sizeof(*out));
-  if (dr == nullptr) return 0;
-  if (!(dr->p >= 0.f && dr->p < 1.f)) return fail(VMLMF_E_BADARG, "dropout: p must be in [0, 1)");
-  if (dr->state == nullptr || (forward && dr->y_dropped == nullptr)) return fail(VMLMF_E_BADARG, "dropout: null state / y_dropped");
-  out->state = reinterpret_cast<const unsigned long long*>(dr->state), out->yd = forward ? dr->y_dropped : nullptr;
-  out->thresh = drop_thresh(dr->p), out->scale = 1.f / (1.f - dr->p), out->site = dr->site;
-  return 0;
-}
-
-static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, const float* x, float* ws, hipStream_t s) {
-  const int L = S.L;
-  const bool training = S.g[0].training != 0;
-  int rc;
-  RbxFwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.status = status_word(s), a.L = L;
-  RefP rps[RBX_MAXL];
-  float* packs[RBX_MAXL];
-  float* imgs[RBX_MAXL];
-  unsigned* fflags[RBX_MAXL];
-  for (int l = 0; l < L; ++l) {
-    const VGeo& g = S.g[l];
-    if ((rc = check_params(g, ly[l].params)) != 0) return rc;
-    if (ly[l].y == nullptr) return fail(VMLMF_E_BADARG, "stack: null y");
-    if (training && ly[l].reserve == nullptr) return fail(VMLMF_E_BADARG, "stack: training forward needs the layers' reserve buffers");
-    float* rs = (float*)ly[l].reserve;
-    const Layout& Lr = S.lay[l];
-    float* wl = ws + S.ws_layer[l];
-    float* pack = training ? rs + Lr.r_pack : wl + Lr.f_pack;
-    rps[l] = to_refp(ly[l].params), packs[l] = pack, imgs[l] = pack + S.P[l].RB, fflags[l] = reinterpret_cast<unsigned*>(wl + Lr.f_flag);
-    RbxLayerF& w = a.l[l];
-    if ((rc = rbx_drop(ly[l].drop, true, &w.drop)) != 0) return rc;
-    // the layer's input: x, or the rows of the layer below (their dropped copy under dropout)
-    w.x = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
-    w.EH = pack + S.P[l].EH, w.EXT = pack + S.P[l].EXT, w.BBT = pack + S.P[l].BBT, w.img = pack + S.P[l].RB;
-    w.h0 = ly[l].h0, w.c0 = ly[l].c0, w.y = ly[l].y, w.hT = ly[l].hT, w.cT = ly[l].cT;
-    w.gates = training ? rs + Lr.r_gates : nullptr, w.cs = training ? rs + Lr.r_cs : nullptr;
-    w.Qs = training ? rs + Lr.r_Qs : nullptr, w.qx = training ? rs + Lr.r_qx : nullptr;
-    w.xq = wl + Lr.f_xq, w.flag = reinterpret_cast<unsigned*>(wl + Lr.f_flag);
-    w.pflag = l > 0 ? reinterpret_cast<unsigned*>(ws + S.ws_layer[l - 1] + S.lay[l - 1].f_flag) : nullptr;
-    w.pub = l < L - 1 ? 1 : 0;
-  }
-  {   // every layer's parameter images in two launches (pack_kernel's for all layers, the clusters' MFMA operand images for all
-      // layers; the second also clears the forward launch's epoch words)
-    Scope sc(0, s);
-    WfPack W0;
-    memset(&W0, 0, sizeof(W0));
-    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s), "pack")) != 0) return rc;
-    if ((rc = hip_fail(launch_rb_pack_stack(S.g[0], S.q, L, rps, imgs, fflags, s), "rb_pack")) != 0) return rc;
-  }
-  Scope sc(2, s);
-  return hip_fail(launch_rbx_fwd(S.g[0], S.q, a, s), "rbx_fwd");
-}
-
-static int rbx_stack_backward(const StackPlan& S, const vmlmf_stack_layer* ly, const float* x, const float* dy, float* dx, float* ws,
-                              hipStream_t s) {
-  const int L = S.L;
-  int rc;
-  for (int l = 0; l < L; ++l) {
-    if ((rc = check_params(S.g[l], ly[l].params)) != 0) return rc;
-    if ((rc = check_pointers(S.g[l], ly[l].grads, "grads")) != 0) return rc;
-    if (ly[l].y == nullptr || ly[l].reserve == nullptr) return fail(VMLMF_E_BADARG, "stack: null y / reserve");
-  }
-  RbxBwdArgs a;
-  memset(&a, 0, sizeof(a));
-  a.status = status_word(s), a.L = L;
-  float* dpres[RBX_MAXL];
-  unsigned* flags[RBX_MAXL];
-  for (int l = 0; l < L; ++l) {
-    const Layout& Lr = S.lay[l];
-    const float* rs = (const float*)ly[l].reserve;
-    const float* pack = rs + Lr.r_pack;
-    float* wl = ws + S.ws_layer[l];
-    RbxLayerB& w = a.l[L - 1 - l];   // launch position 0 is the top layer: the producer comes first in the grid
-    if ((rc = rbx_drop(ly[l].drop, false, &w.drop)) != 0) return rc;
-    w.gates = rs + Lr.r_gates, w.cs = rs + Lr.r_cs, w.EH = pack + S.P[l].EH, w.EXT = pack + S.P[l].EXT, w.img = pack + S.P[l].RB;
-    w.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
-    w.dhT = ly[l].dhT, w.dcT = ly[l].dcT, w.dh0 = ly[l].dh0, w.dc0 = ly[l].dc0;
-    w.dpre = wl + Lr.b_dpre, w.dQs = wl + Lr.b_dQs, w.dqx = wl + Lr.b_dqx;
-    w.dx = l == 0 ? dx : ws + S.ws_dx[l];
-    w.xq = wl + Lr.b_xq, w.flag = reinterpret_cast<unsigned*>(wl + Lr.b_flag);
-    w.pflag = l < L - 1 ? reinterpret_cast<unsigned*>(ws + S.ws_layer[l + 1] + S.lay[l + 1].b_flag) : nullptr;
-    w.pub = l > 0 ? 1 : 0;
-    dpres[l] = wl + Lr.b_dpre, flags[l] = reinterpret_cast<unsigned*>(wl + Lr.b_flag);
-  }
-  {
-    Scope sc(3, s);
-    if ((rc = hip_fail(launch_rbx_zero(S.g[0], S.q, L, dpres, flags, s), "rbx_zero")) != 0) return rc;
-    if ((rc = hip_fail(launch_rbx_bwd(S.g[0], S.q, a, s), "rbx_bwd")) != 0) return rc;
-  }
-  HeadBwd hb;
-  memset(&hb, 0, sizeof(hb));
-  // the batched half of every layer: weight-gradient products (per layer: the ring kernel fills the chip), then ONE launch that sums
-  // every layer's partial blocks and ONE that writes every layer's reference-layout gradients
-  const bool ring = g_wring != 0 && wgrad_ring_ok(S.g[0]) && (g_wring > 0 || (long long)S.g[0].T * S.g[0].B >= 1024);
-  if (!ring) {
-    for (int l = L - 1; l >= 0; --l) {
-      const float* xl = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
-      if ((rc = backward_tail(S.g[l], S.lay[l], ly[l].params, ly[l].grads, xl, ly[l].y, ly[l].h0, (const float*)ly[l].reserve,
-                              ws + S.ws_layer[l], hb, s)) != 0)
-        return rc;
-    }
-    return 0;
-  }
-  ReduceCounts wcs[RBX_MAXL];
-  const float* wparts[RBX_MAXL];
-  float* cgs[RBX_MAXL];
-  const float* ccgs[RBX_MAXL];
-  RefP rps[RBX_MAXL];
-  RefG ogs[RBX_MAXL];
-  for (int l = L - 1; l >= 0; --l) {
-    const float* xl = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
-    float* wl = ws + S.ws_layer[l];
-    const WghArgs wh = wgrad_args(S.lay[l], xl, ly[l].y, ly[l].h0, (const float*)ly[l].reserve, wl);
-    int nc[3] = {0, 0, 0};
-    {
-      Scope sc(5, s);
-      const int rr = launch_wgrad_ring(S.g[l], wh, device_cus(), nc, s);
-      if (rr == -3) {   // no LDS / instantiation for the ring on this device: the per-layer path for every layer from here
-        for (int k = l; k >= 0; --k) {
-          const float* xk = k == 0 ? x : (ly[k - 1].drop != nullptr ? ly[k - 1].drop->y_dropped : ly[k - 1].y);
-          if ((rc = backward_tail(S.g[k], S.lay[k], ly[k].params, ly[k].grads, xk, ly[k].y, ly[k].h0, (const float*)ly[k].reserve,
-                                  ws + S.ws_layer[k], hb, s)) != 0)
-            return rc;
-        }
-        // (the layers above l: their blocks are formed, finish them one by one)
-        for (int k = L - 1; k > l; --k) {
-          {
-            Scope sc6(6, s);
-            if ((rc = hip_fail(launch_reduce(S.g[k], wparts[k], cgs[k], nullptr, s, wcs[k]), "reduce")) != 0) return rc;
-          }
-          Scope sc7(7, s);
-          if ((rc = hip_fail(launch_finish(S.g[k], rps[k], cgs[k], ogs[k], hb, s, health_word(s)), "finish")) != 0) return rc;
-        }
-        return 0;
-      }
-      if ((rc = hip_fail(rr, "wgrad")) != 0) return rc;
-    }
-    wcs[l] = ReduceCounts{{nc[0], nc[1], nc[2]}};
-    wparts[l] = wl + S.lay[l].b_wpart, cgs[l] = wl + S.lay[l].b_cgrad, ccgs[l] = cgs[l];
-    rps[l] = to_refp(ly[l].params);
-    const vmlmf_grads* gr = ly[l].grads;
-    RefG& og = ogs[l];
-    og.dia_x = gr->dia_x, og.dia_h = gr->dia_h, og.u_x = gr->u_x, og.v_x = gr->v_x, og.b_x = gr->b_x;
-    og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
-    for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
-  }
-  if (g_ffb != 0 && finish_from_blocks_ok(S.g[0])) {   // the finishing launch sums the (few) partial blocks itself
-    Scope sc(7, s);
-    return hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb, s, health_word(s), wparts, wcs), "finish");
-  }
-  {
-    Scope sc(6, s);
-    if ((rc = hip_fail(launch_reduce_stack(L, S.g, wparts, cgs, s, wcs), "reduce")) != 0) return rc;
-  }
-  {
-    Scope sc(7, s);
-    if ((rc = hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb, s, health_word(s)), "finish")) != 0) return rc;
-  }
-  return 0;
-}
 }  // namespace
-
-int vmlmf_stack_dropout_fused(int L, const vmlmf_stack_layer* layers) {
-  StackPlan S;
-  return stack_plan(L, layers, &S) == 0 && S.rbx ? 1 : 0;
-}
 
 int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_bytes, size_t* workspace_bytes) {
   StackPlan S;
@@ -1340,12 +1114,6 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
   hipStream_t s = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const bool training = S.g[0].training != 0;
-  if (S.rbx) {
-    if (head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack (clustered form): no classifier head");
-    return rbx_stack_forward(S, ly, x, ws, s);
-  }
-  for (int l = 0; l < L; ++l)
-    if (ly[l].drop != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: dropout inside the launches only on the clustered form (vmlmf_stack_dropout_fused)");
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L, a.c.status = status_word(s);
@@ -1413,10 +1181,6 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     hb_top.W = head->weight, hb_top.dl = head->dlogits, hb_top.hlast = ly[L - 1].y + (size_t)(gt.T - 1) * gt.syT, hb_top.ldh = gt.syB;
     hb_top.dW = head->dweight, hb_top.db = head->dbias, hb_top.C = head->classes;
   }
-  if (S.rbx) {
-    if (head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack (clustered form): no classifier head");
-    return rbx_stack_backward(S, ly, x, dy, dx, ws, s);
-  }
   const bool wave = g_wf_bwd;
   if (!wave && head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: the classifier rides on the wavefront backward only (VMLMF_WF_BWD=0 is an A/B switch)");
   if (wave) {
@@ -1475,12 +1239,6 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       Scope sc(5, s);
       if ((rc = hip_fail(launch_wgrad_h_stack(L, S.g, wh, s), "wgrad")) != 0) return rc;
     }
-    bool ffb = g_ffb > 0;   // (wavefront stacks: 48 - 64 blocks per layer; on only when asked for - measured: DESIGN.md)
-    for (int l = 0; l < L; ++l) ffb = ffb && finish_from_blocks_ok(S.g[l]);
-    if (ffb) {
-      Scope sc(7, s);
-      return hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb_top, s, health_word(s), wparts, nullptr), "finish");
-    }
     {
       Scope sc(6, s);
       if ((rc = hip_fail(launch_reduce_stack(L, S.g, wparts, cgs, s), "reduce")) != 0) return rc;
@@ -1533,9 +1291,7 @@ int vmlmf_check_status(void) { return take_status(); }
 int vmlmf_tune(const char* key, int value) {
   if (key == nullptr) return fail(VMLMF_E_BADARG, "tune: null key");
   const std::string k(key);
-  if (k == "rbx") g_rbx = value;
-  else if (k == "ffb") g_ffb = value;
-  else if (k == "rb") g_rb_mode = value;
+  if (k == "rb") g_rb_mode = value;
   else if (k == "rec3") g_rec3 = value;
   else if (k == "test_wride_spin") g_wride_spin = value < 1 ? WRIDE_SPIN_DEFAULT : value;
   else if (k == "inrow") g_inrow = value;
@@ -1559,9 +1315,7 @@ int vmlmf_tune(const char* key, int value) {
 int vmlmf_tune_get(const char* key, int* value) {
   if (key == nullptr || value == nullptr) return fail(VMLMF_E_BADARG, "tune_get: null pointer");
   const std::string k(key);
-  if (k == "rbx") *value = g_rbx;
-  else if (k == "ffb") *value = g_ffb;
-  else if (k == "rb") *value = g_rb_mode;
+  if (k == "rb") *value = g_rb_mode;
   else if (k == "rec3") *value = g_rec3;
   else if (k == "inrow") *value = g_inrow;
   else if (k == "adam_guard") *value = g_adam_guard;

@@ -121,7 +121,6 @@ int generic_dqx_dx(const VGeo& g, const GenericBuf& w, hipStream_t s);
 // qx = x U_x over all rows of a large time-major layer
 int generic_qx(const VGeo& g, const float* x, const float* UXP, float* qx, hipStream_t s);
 
-constexpr int RBX_MAXL = 4;   // layers of a clustered stack (vmlmf_rbx.hip)
 // row-block MFMA recurrent kernels (vmlmf_rb.hip)
 struct RbIo {
   const float *gx, *EH, *h0, *c0, *img, *dy, *dhT, *dcT;
@@ -133,56 +132,9 @@ struct RbIo {
   DropArgs drop;      // dropout of the layer's output (state == nullptr: none): forward writes drop.yd, backward masks dy
 };
 // false: no instantiation covers the layer with S splits.  rows = live batch rows per workgroup (16, 8 or 4; 0 = automatic)
-// xf = 1: with the x-side images and exchange tiles of the stacked form (vmlmf_rbx.inc); false when the layer is not covered by it
-bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0, int xf = 0);
-
-// ---- clustered layers stacked in ONE launch per direction (vmlmf_rbx.inc): the layer loop of the LM network (vmlmf_lm.py:437-439)
-// for layers too large for one CU.  Every layer keeps its own clusters (RbGeo, all layers alike) and forms its x side itself - the x
-// ranks qx = x U_x are NPX more tiles of its exchange, the expansion a third MFMA product - so layer l + 1 needs nothing of layer l
-// but the rows y_l[t] (their dropped copy under dropout), which it takes from L2 a few steps behind: a member reads the 16 units of
-// its own tiles, written by the SAME member index of the layer below, whose epoch word says when they are complete.  Backward: the
-// same with dx_l[t] going down.  Needs L x (row blocks) x S workgroups co-resident (one per CU).
-struct RbxLayerF {
-  const float *x, *EH, *EXT, *BBT, *h0, *c0, *img;
-  float *y, *hT, *cT, *gates, *cs, *Qs, *qx;
-  float* xq;               // this layer's exchange tiles
-  unsigned* flag;          // ... and epoch words (+ error word behind them)
-  const unsigned* pflag;   // epoch words of the layer below (its y is this layer's x), or NULL: x is complete before the launch
-  int pub, pad;            // pub: a layer above consumes y during the launch (write-through stores + a final epoch)
-  DropArgs drop;           // dropout of this layer's output (state == nullptr: none); the layer above reads drop.yd then
-};
-struct RbxLayerB {
-  const float *gates, *cs, *dy, *dhT, *dcT, *EH, *EXT, *img;
-  float *dpre, *dQs, *dqx, *dx, *dh0, *dc0;
-  float* xq;
-  unsigned* flag;
-  const unsigned* pflag;   // epoch words of the layer ABOVE (its dx is this layer's dy), or NULL
-  int pub, pad;            // pub: the layer below consumes dx during the launch
-  DropArgs drop;           // dy is the gradient of the dropped copy: multiplied by the regenerated factors
-};
-struct RbxFwdArgs {
-  unsigned* status;
-  int L, bpl;              // layers; workgroups per layer (a multiple of 8)
-  RbxLayerF l[RBX_MAXL];   // launch position 0 = the bottom layer
-};
-struct RbxBwdArgs {
-  unsigned* status;
-  int L, bpl;
-  RbxLayerB l[RBX_MAXL];   // launch position 0 = the TOP layer (the producer comes first in the grid)
-};
-struct RbxZeroArgs {
-  float* dpre[RBX_MAXL];
-  unsigned* flags[RBX_MAXL];
-};
-bool rbx_supported(const VGeo& g, const RbGeo& q);   // an instantiation exists
-int launch_rbx_fwd(const VGeo& g, const RbGeo& q, const RbxFwdArgs& a, hipStream_t s);
-int launch_rbx_bwd(const VGeo& g, const RbGeo& q, const RbxBwdArgs& a, hipStream_t s);
-// dpre of the padded slots of every layer zeroed and the backward launch's epoch words cleared, one launch for the stack
-int launch_rbx_zero(const VGeo& g, const RbGeo& q, int L, float* const* dpre, unsigned* const* flags, hipStream_t s);
+bool rb_geometry(const VGeo& g, int S, RbGeo* out, int rows = 0);
 int launch_rb_pack(const VGeo& g, const RbGeo& q, const RefP& p, float* img, hipStream_t s, unsigned* zero_flags = nullptr);
 int launch_rb_fwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
-// rb_pack_kernel for every layer of a clustered stack (all layers share the geometry) in one launch
-int launch_rb_pack_stack(const VGeo& g, const RbGeo& q, int L, const RefP* p, float* const* img, unsigned* const* zero_flags, hipStream_t s);
 int launch_rb_bwd(const VGeo& g, const RbGeo& q, const RbIo& io, hipStream_t s);
 
 // every launcher returns hipGetLastError() of its launch, or VMLMF_E_UNSUPPORTED (-3) when no
@@ -317,13 +269,9 @@ int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 // the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)
 int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
-int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s,
-                        const ReduceCounts* wc = nullptr);   // wc: per layer, the chunk counts of a wgrad_ring_kernel launch (or NULL)
-// wpart (+ wc, as launch_reduce_stack): finish straight from the partial blocks - no reduce launch in front (finish_from_blocks_ok layers)
-bool finish_from_blocks_ok(const VGeo& g);
+int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s);
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
-                        hipStream_t s, unsigned* health = nullptr, const float* const* wpart = nullptr,
-                        const ReduceCounts* wc = nullptr);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
+                        hipStream_t s, unsigned* health = nullptr);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

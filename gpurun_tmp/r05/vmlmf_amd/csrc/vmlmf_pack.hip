@@ -721,39 +721,8 @@ __device__ __forceinline__ void finish_head(const VGeo& g, const HeadBwd& hd, co
     }
   }
 }
-// Element (accumulator a, unit n) of the canonical gradients straight from the weight-gradient kernels' partial blocks: the inverse of
-// reduce_cg_scatter (vmlmf_wgrad.hip) and the same fixed-order sum over the blocks (vg_block_sum) - reduce_cg_kernel and finish_kernel
-// as ONE launch for the stacks, whose block counts are small (round 6).  Layers with I <= H and without the x-fold.
-__device__ __forceinline__ float finish_cg_from_blocks(const VGeo& g, const float* __restrict__ P, const ReduceCounts& wc, int a, const int n) {
-  const int KX = g.KX, KH = g.KH, GK = g.G * KH, NT = g.NT, slot = vg_slot(g, n);
-  const int MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
-  const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
-  const long long o2 = (long long)NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p, oe = o3 + (long long)MT3 * 32 * NB3p;
-  long long e;
-  int cnt = wc.c[0] == 0 ? g.nchunk : wc.c[0];
-  if (a < 4 * KX) {                 // va_vx(k, j)
-    const int k = a / KX, j = a - k * KX;
-    e = (long long)(slot * 4 + k) * NB1p + j;
-  } else if ((a -= 4 * KX) < 4 * KH) {   // va_vc(k, rr)
-    const int k = a / KH, rr = a - k * KH;
-    e = (long long)(slot * 4 + k) * NB1p + KX + (g.flat ? (k >= 2 ? KH : 0) : 0) + rr;
-  } else if ((a -= 4 * KH) < KH) {  // va_uc(rr)
-    const int rr = a, s_ = (g.G == 2 && rr >= g.off1) ? 1 : 0, dest = (n / g.Hg - s_ + g.G) % g.G;
-    e = o2 + (long long)n * NB2p + dest * KH + rr;
-    if (wc.c[0] != 0) cnt = wc.c[1];
-  } else if ((a -= KH) < KX) {      // va_ux(r)
-    e = o3 + (long long)n * NB3p + a;
-    if (wc.c[0] != 0) cnt = wc.c[2];
-  } else {                          // va_eh / va_ex / va_b (k)
-    a -= KX;
-    e = oe + (long long)(a >> 2) * NT * 4 + slot * 4 + (a & 3);
-  }
-  return vg_block_sum(P, g.PCH, e, 0, cnt);
-}
-
 __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const float* __restrict__ cg, const RefG& o, const HeadBwd& hd,
-                                            const long long nbody, unsigned* health, const float* __restrict__ P = nullptr,
-                                            const ReduceCounts wc = ReduceCounts{{0, 0, 0}}) {
+                                            const long long nbody, unsigned* health) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
   auto put = [&](float* dst, float v) { finish_put(dst, v, health); };
   {
@@ -763,7 +732,7 @@ __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const 
       return;
     }
   }
-  auto CG = [&](int a, int n) { return P != nullptr ? finish_cg_from_blocks(g, P, wc, a, n) : cg[(size_t)a * NT + vg_slot(g, n)]; };
+  auto CG = [&](int a, int n) { return cg[(size_t)a * NT + vg_slot(g, n)]; };
   const long long n_ux = (long long)I * rw, n_vx = 4LL * H * rw, n_dx = I, n_dh = H, n_b = 4LL * H;
   const long long n_uh0 = (long long)H * g.ru0, n_vh0 = 4LL * H * g.ru0;
   const long long n_uh1 = g.G == 2 ? (long long)H * g.ru1 : 0, n_vh1 = g.G == 2 ? 4LL * H * g.ru1 : 0;
@@ -1022,9 +991,6 @@ struct FinishLayer {
   const float* cg;
   long long nbody;
   HeadBwd hd;   // classifier gradients ride with the top layer (C = 0 elsewhere)
-  const float* P;    // or: the partial blocks themselves (cg unused): no reduce launch in front of this one
-  ReduceCounts wc;
-  int pad;
 };
 struct FinishStack {
   FinishLayer l[WF_MAXL];
@@ -1033,7 +999,7 @@ struct FinishStack {
 __global__ void __launch_bounds__(256) finish_stack_kernel(FinishStack S) {   // grid.y = layer (wavefront path; no classifier)
   const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
   if ((long long)blockIdx.x * 256 >= f.nbody && f.hd.C <= 0) return;
-  finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody, vg_karg_ref<unsigned*>(offsetof(FinishStack, health)), f.P, f.wc);
+  finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody, vg_karg_ref<unsigned*>(offsetof(FinishStack, health)));
 }
 
 static long long finish_elements(const VGeo& g) {
@@ -1043,9 +1009,8 @@ static long long finish_elements(const VGeo& g) {
   return (n + 255) / 256 * 256;   // the classifier's elements start on a workgroup boundary
 }
 
-bool finish_from_blocks_ok(const VGeo& g) { return !g.foldx && g.I <= g.H; }
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
-                        hipStream_t s, unsigned* health, const float* const* wpart, const ReduceCounts* wc) {
+                        hipStream_t s, unsigned* health) {
   static_assert(sizeof(FinishStack) <= 4096, "kernel-argument segment");
   FinishStack S;
   memset(&S, 0, sizeof(S));
@@ -1053,11 +1018,6 @@ int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const*
   long long nmax = 0;
   for (int l = 0; l < L; ++l) {
     S.l[l].g = g[l], S.l[l].p = p[l], S.l[l].o = out[l], S.l[l].cg = cgrad[l], S.l[l].nbody = finish_elements(g[l]);
-    if (wpart != nullptr) {
-      if (!finish_from_blocks_ok(g[l])) return -3;
-      S.l[l].P = wpart[l];
-      if (wc != nullptr) S.l[l].wc = wc[l];
-    }
     long long n = S.l[l].nbody;
     if (l == L - 1 && hd_top.C > 0) {
       S.l[l].hd = hd_top;

@@ -1,0 +1,3 @@
+// rec_bwd_kernel instantiations for padded hidden rank 32
+#include "vmlmf_rec_bwd.inc"
+int launch_rec_bwd_kh32(const VGeo& g, const BwdArgs& a, hipStream_t s) { return bwd_launch_kh<32>(g, a, s); }

@@ -1,0 +1,4 @@
+// wavefront kernel instantiations for padded rank 24 (one translation unit per rank: parallel build)
+#include "vmlmf_wave.inc"
+int launch_wf_fwd_k24(const VGeo& g, const WfFwdArgs& a, hipStream_t s) { return wf_fwd_dispatch<24>(g, a, s); }
+int launch_wf_bwd_k24(const VGeo& g, const WfBwdArgs& a, hipStream_t s) { return wf_bwd_dispatch<24>(g, a, s); }
