@@ -819,7 +819,7 @@ def main():
             raise KeyError(dom)
 
         b256 = strong and rows_gpu == 256
-        for name in (("r05_pmc_traffic_b256.json", "r04_pmc_traffic_b256.json") if b256 else ()) + ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in (("r06_pmc_traffic_b256.json", "r05_pmc_traffic_b256.json", "r04_pmc_traffic_b256.json") if b256 else ()) + ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_zz4_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = prof_entry(pmc["kernels"])["hbm_bytes_per_launch"]
@@ -828,7 +828,7 @@ def main():
             except (OSError, KeyError, ValueError):
                 pass
         try:   # SQ counters of the same command (two --pmc passes), per launch of the dominant kernel
-            util_file = next(f for f in ((("r05_pmc_util_b256.json", "r04_pmc_util_b256.json") if b256 else ()) + ("r05_pmc_util.json", "r04_pmc_util.json", "r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json"))
+            util_file = next(f for f in ((("r06_pmc_util_b256.json", "r05_pmc_util_b256.json", "r04_pmc_util_b256.json") if b256 else ()) + ("r06_pmc_util.json", "r05_pmc_util.json", "r04_pmc_util.json", "r03_pmc_util.json", "r02_zz4_pmc_util.json", "r02_pmc_util.json"))
                              if os.path.exists(os.path.join(ROOT, "profiles", f)))
             u = prof_entry(json.load(open(os.path.join(ROOT, "profiles", util_file)))["kernels"])["derived"]
             util = {k: u.get(k) for k in ("valu_active_frac", "mfma_busy_frac", "wait_frac", "issue_stall_frac",
@@ -927,6 +927,9 @@ def main():
                          "note": "fp32: MFMA peak == vector peak on gfx950; the kernel is a 2T-long dependent "
                                  "chain on 64 of 256 CUs (one batch row per CU), see DESIGN.md"},
             "kernels_us": kern,
+            "kernels_us_region": "EAGER launches bracketed by HIP event pairs in an untimed breakdown pass - not the replayed hipGraph `value` / "
+                                 "`ms_per_step` come from (a graph node cannot be bracketed), so they need not add up to ms_per_step; "
+                                 "roofline.launch_us is from the eager timed region too (its fraction is the conservative one)",
             "allreduce_ms": None if allreduce_ms is None else round(allreduce_ms, 4),
             "allreduce_bytes": 4 * reducer.numel() if collective else 0,
             "adam_ms": round(adam_ms, 4),

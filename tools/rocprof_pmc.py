@@ -12,7 +12,7 @@ OURS = ("pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "rec3
         "reduce_cg_kernel", "finish2_kernel", "finish_kernel", "adam_fused_kernel", "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel",
         "adam_kernel", "wf_fwd_kernel", "wf_bwd_kernel", "pack_stack_kernel", "wgrad_mfma_stack_kernel",
         "reduce_cg_stack_kernel", "finish_stack_kernel", "rb_fwd_kernel", "rb_bwd_kernel", "rb_pack_kernel",
-        "xexp_mfma_kernel", "gemm_skinny_kernel")
+        "xexp_mfma_kernel", "gemm_skinny_kernel", "rbx_fwd_kernel", "rbx_bwd_kernel", "rbx_zero_kernel", "rb_pack_stack_kernel")
 
 
 def per_kernel(db, counter):
