@@ -189,6 +189,8 @@ def test_the_product_library_stays_pruned():
     template parameters' names in its kernel symbols."""
     import subprocess
     size = os.path.getsize(_lib.LIB_PATH)
-    assert size < 9_000_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
+    # (round 5: 8.92 MB; round 6 adds the clustered-stack kernels - rbx_fwd / rbx_bwd for the PTB group and plain layers, the stack-wide
+    #  pack and zero launches: + 0.2 MB of product code)
+    assert size < 9_300_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
     out = subprocess.run(["strings", "-n", "12", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "VMLMF_R4_ABL" not in out and "VMLMF_WRIDE_DRY" not in out

@@ -392,3 +392,59 @@ def test_config_e_layer_at_full_size_drop_equals_the_undropped_layer_times_the_f
     assert torch.equal(yd, y * F) and torch.equal(hTd, hT) and torch.equal(cTd, cT)
     for a, b in zip(gd, gu):
         assert torch.equal(a, b)
+
+
+@gpu
+@pytest.mark.parametrize("L,B,T,H,rw,ru,p", [(2, 6, 5, 32, 8, 8, 0.5), (3, 9, 7, 100, 16, 16, 0.25), (2, 128, 6, 256, 24, 24, 0.5), (2, 5, 1, 64, 8, 16, 0.5)],
+                         ids=lambda v: str(v))
+def test_dropout_between_the_layers_of_a_wavefront_stack_vs_oracle(L, B, T, H, rw, ru, p):
+    """Round 6 (verdict r5 item 7): nn.Dropout(p) behind every layer of a stack the WAVEFRONT launches run (vmlmf_lm.py:437-439 with hidden
+    sizes up to 256): the loader wave of a layer forms the step's factors, its storer writes the dropped copy the layer above reads, the
+    backward multiplies dy by the same factors - against the fp64 oracle with the factors (identity columns: one-group layers)
+    multiplied in; outputs, carried states, dx, dh0 / dc0 and every parameter gradient."""
+    from hip_util import ORDER, assert_out, assert_grad
+    from vmlmf_amd import functional as F, _lib
+    variant = O.V3
+    cfg = (variant, 1, rw, (ru,), True, _lib.DT_F32)
+    assert F._stack_plan(cfg, L, B, T, H, H, True) is not None and F.stack_takes_dropout(cfg, L, B, T, H, H, True)
+    Ps = [O.make_params(variant, H, H, rw, ru, seed=71 + l, scale=0.1) for l in range(L)]
+    r = np.random.Generator(np.random.PCG64(12))
+    x = (0.5 * r.standard_normal((T, B, H))).astype(np.float32)
+    h0 = (0.3 * r.standard_normal((L, B, H))).astype(np.float32)
+    c0 = (0.3 * r.standard_normal((L, B, H))).astype(np.float32)
+    dy = r.standard_normal((T, B, H)).astype(np.float32)
+    dhT = r.standard_normal((L, B, H)).astype(np.float32)
+    dcT = r.standard_normal((L, B, H)).astype(np.float32)
+    snap = _state(SEED, 23)
+    names = ORDER[variant]
+    params = [[torch.tensor(np.asarray(P[k]), device="cuda").requires_grad_(True) for k in names] for P in Ps]
+    xg, h0g, c0g = (torch.tensor(a, device="cuda").requires_grad_(True) for a in (x, h0, c0))
+    out = F.vmlmf_stack(variant, xg, params, rw, [ru], g=1, time_major=True, h0=h0g, c0=c0g, drops=[(p, snap, l + 1) for l in range(L)])
+    assert out is not None
+    yd, hs, cs = out
+    loss = (yd * torch.tensor(dy, device="cuda")).sum()
+    for l in range(L):
+        loss = loss + (hs[l] * torch.tensor(dhT[l], device="cuda")).sum() + (cs[l] * torch.tensor(dcT[l], device="cuda")).sum()
+    loss.backward()
+    Fs = [O.dropout_factors(SEED, 23, l + 1, T * B, H, p).reshape(T, B, H) for l in range(L)]
+    assert all(abs((f == 0).mean() - p) < 0.06 for f in Fs)
+    f64 = torch.float64
+    Pt = [O.to_torch(P, dtype=f64, requires_grad=True) for P in Ps]
+    xt, h0t, c0t = (torch.tensor(a, dtype=f64, requires_grad=True) for a in (x, h0, c0))
+    cur, lossr, hr, cr = xt, 0.0, [], []
+    for l in range(L):
+        cur, hT, cT = O.literal_sequence(variant, Pt[l], cur, h0t[l], c0t[l], time_major=True)
+        cur = cur * torch.tensor(Fs[l], dtype=f64)
+        hr.append(hT), cr.append(cT)
+        lossr = lossr + (hT * torch.tensor(dhT[l], dtype=f64)).sum() + (cT * torch.tensor(dcT[l], dtype=f64)).sum()
+    (lossr + (cur * torch.tensor(dy, dtype=f64)).sum()).backward()
+    assert_out(yd.detach().cpu().numpy(), cur.detach().numpy(), "wf.drop.y_dropped")
+    for l in range(L):
+        assert_out(hs[l].detach().cpu().numpy(), hr[l].detach().numpy(), f"wf.drop.hT[{l}]")
+        assert_out(cs[l].detach().cpu().numpy(), cr[l].detach().numpy(), f"wf.drop.cT[{l}]")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "wf.drop.dx")
+    assert_grad(h0g.grad.cpu().numpy(), h0t.grad.numpy(), "wf.drop.dh0")
+    assert_grad(c0g.grad.cpu().numpy(), c0t.grad.numpy(), "wf.drop.dc0")
+    for l in range(L):
+        for k, p_ in zip(names, params[l]):
+            assert_grad(p_.grad.cpu().numpy(), Pt[l][k].grad.numpy(), f"wf.drop.layer{l}.{k}")

@@ -180,6 +180,10 @@ int env_pos(const char* name, int dflt) {
   const int v = atoi(e);
   return v >= 1 ? v : dflt;
 }
+int env_int(const char* name, int dflt) {   // any integer (switches with a -1 / 0 / 1 meaning)
+  const char* e = getenv(name);
+  return e == nullptr ? dflt : atoi(e);
+}
 const int g_wchunks = env_pos("VMLMF_WCHUNKS", 64);
 const int g_rc = env_pos("VMLMF_RC", 0);   // dqx_dx rows per workgroup (A/B); 0 = derived from the row count
 const int g_wmin = env_pos("VMLMF_WMIN", 64);   // config C (3072 rows): 0.2546 ms at 32 or 48, 0.2428 at 64, 0.243 at 96
@@ -1024,14 +1028,20 @@ int vmlmf_seq_backward_ex(const vmlmf_desc* d, const vmlmf_params* p, const floa
 namespace {
 // VMLMF_WF_BWD=0: the stack's backward chains the per-layer kernels (A/B runs and bring-up); the forward is the wavefront
 // launch either way
-const bool g_wf_bwd = []() { const char* e = getenv("VMLMF_WF_BWD"); return e == nullptr || e[0] != '0'; }();
+const bool g_wf_bwd = env_int("VMLMF_WF_BWD", 1) != 0;
 
+// (No lambdas in the initialisers of this block: this unnamed namespace is reopened INSIDE the file's extern "C" block, and hipcc numbers
+//  the lambdas of a namespace per enclosing linkage specification - "(anonymous namespace)::{lambda()#2}" here got the same mangled name
+//  as lambda #2 of the first block at the top of the file, and ONE body served both: the switches below came up with another switch's
+//  default whatever the environment said.  Found in round 6 through a run-time flag that read 1 with nothing set; VMLMF_WF_BWD had been
+//  answered by VMLMF_RB's lambda since round 2.)
 // VMLMF_RBX=0 / vmlmf_tune("rbx", 0): clustered layers are never stacked into one launch (the caller chains them; A/B runs)
-int g_rbx = []() { const char* e = getenv("VMLMF_RBX"); return e ? atoi(e) : 1; }();
-// the stacks' finishing launch sums the partial blocks itself (no reduce launch): 0 = never (default: measured no faster - two PTB
-// group layers at 32 rows 0.710 ms with, 0.702 without, same box; the repeated block sums of the d(ex) / d(eh) rows cost what the
-// launch saves), -1 = the clustered stacks, 1 = the wavefront stacks too.  VMLMF_FFB / vmlmf_tune("ffb"); parity-tested both ways
-int g_ffb = []() { const char* e = getenv("VMLMF_FFB"); return e ? atoi(e) : 0; }();
+int g_rbx = env_int("VMLMF_RBX", 1);
+// the stacks' finishing launch sums the partial blocks itself (no reduce launch): 0 = never (default: measured slower - config C's
+// finish_stack_kernel 25.5 us against reduce 8.1 + finish 6.2, the repeated block sums of the d(ex) / d(eh) rows; two PTB group
+// layers at 32 rows 0.710 ms with, 0.702 without), -1 = the clustered stacks, 1 = the wavefront stacks too.  VMLMF_FFB /
+// vmlmf_tune("ffb"); parity-tested both ways
+int g_ffb = env_int("VMLMF_FFB", 0);
 
 struct StackPlan {
   int L;
@@ -1314,7 +1324,8 @@ static int rbx_stack_backward(const StackPlan& S, const vmlmf_stack_layer* ly, c
 
 int vmlmf_stack_dropout_fused(int L, const vmlmf_stack_layer* layers) {
   StackPlan S;
-  return stack_plan(L, layers, &S) == 0 && S.rbx ? 1 : 0;
+  if (stack_plan(L, layers, &S) != 0) return 0;
+  return (S.rbx || (S.g[0].G == 1 && g_wf_bwd)) ? 1 : 0;   // the clustered form; the wavefront launches for one-group layers
 }
 
 int vmlmf_stack_query(int L, const vmlmf_stack_layer* layers, size_t* reserve_bytes, size_t* workspace_bytes) {
@@ -1345,7 +1356,8 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
     return rbx_stack_forward(S, ly, x, ws, s);
   }
   for (int l = 0; l < L; ++l)
-    if (ly[l].drop != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: dropout inside the launches only on the clustered form (vmlmf_stack_dropout_fused)");
+    if (ly[l].drop != nullptr && S.g[0].G != 1)
+      return fail(VMLMF_E_UNSUPPORTED, "stack: dropout inside the wavefront launches for one-group layers (vmlmf_stack_dropout_fused)");
   WfFwdArgs a;
   memset(&a, 0, sizeof(a));
   a.c.flag = reinterpret_cast<unsigned*>(ws + S.ws_flag), a.c.L = L, a.c.status = status_word(s);
@@ -1362,7 +1374,9 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
     float* pack = training ? rs + Lr.r_pack : ws + S.ws_layer[l] + Lr.f_pack;
     rps[l] = to_refp(ly[l].params), packs[l] = pack;
     WfFwdLayer& w = a.l[l];
-    w.x = l == 0 ? x : ly[l - 1].y;
+    // the layer's input: x, or the rows of the layer below - their dropped copy under dropout (vmlmf_lm.py:438-439)
+    w.x = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
+    if ((rc = rbx_drop(ly[l].drop, true, &a.drop[l])) != 0) return rc;
     w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
     const bool mixed = g.KH != g.KX;   // both sides at the wider padded rank: re-laid images in the WF region
     const float* wf = pack + S.P[l].WF;
@@ -1418,6 +1432,8 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     return rbx_stack_backward(S, ly, x, dy, dx, ws, s);
   }
   const bool wave = g_wf_bwd;
+  for (int l = 0; l < L; ++l)
+    if (!wave && ly[l].drop != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: dropout rides on the wavefront backward only (VMLMF_WF_BWD=0 is an A/B switch)");
   if (!wave && head != nullptr) return fail(VMLMF_E_UNSUPPORTED, "stack: the classifier rides on the wavefront backward only (VMLMF_WF_BWD=0 is an A/B switch)");
   if (wave) {
     WfBwdArgs a;
@@ -1431,6 +1447,8 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       const float* pack = rs + Lr.r_pack;
       float* wl = ws + S.ws_layer[l];
       WfBwdLayer& w = a.l[L - 1 - l];   // launch position 0 is the top layer
+      if ((rc = rbx_drop(ly[l].drop, false, &a.drop[L - 1 - l])) != 0) return rc;
+      if (ly[l].drop != nullptr && S.g[0].G != 1) return fail(VMLMF_E_UNSUPPORTED, "stack: dropout inside the wavefront launches for one-group layers");
       w.gates = rs + Lr.r_gates, w.cs = rs + Lr.r_cs;
       w.dy = l == L - 1 ? dy : ws + S.ws_dx[l + 1];
       w.dhT = ly[l].dhT, w.dcT = ly[l].dcT, w.dh0 = ly[l].dh0, w.dc0 = ly[l].dc0;
@@ -1461,7 +1479,8 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       const float* rs = (const float*)ly[l].reserve;
       float* wl = ws + S.ws_layer[l];
       WghArgs& w = wh[l];
-      w.dpre = wl + Lr.b_dpre, w.x = l == 0 ? x : ly[l - 1].y, w.y = ly[l].y, w.h0 = ly[l].h0, w.qx = rs + Lr.r_qx, w.dqx = wl + Lr.b_dqx;
+      w.dpre = wl + Lr.b_dpre, w.x = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
+      w.y = ly[l].y, w.h0 = ly[l].h0, w.qx = rs + Lr.r_qx, w.dqx = wl + Lr.b_dqx;
       w.Qs = rs + Lr.r_Qs, w.dQs = wl + Lr.b_dQs, w.wpart = wl + Lr.b_wpart;
       wparts[l] = wl + Lr.b_wpart, cgs[l] = wl + Lr.b_cgrad, ccgs[l] = wl + Lr.b_cgrad;
       rps[l] = to_refp(ly[l].params);

@@ -297,15 +297,21 @@ struct WfCommon {
   unsigned* status;                 // host-visible status word (or NULL)
   int L, pad;
 };
+// drop[pos]: nn.Dropout behind the layer at launch position pos (vmlmf_lm.py:438-439; state == nullptr: none), round 6.  Forward: the
+// layer's loader wave forms the factors of a step (one Philox call covers the row's NT columns: lane l the quad l), its storer writes
+// y AND the dropped copy drop.yd (what the layer above / the caller reads).  Backward: the loader forms the same factors beside the
+// tape, the compute waves multiply the incoming dy.  Kept apart from the layer blocks: only those two roles read it.
 struct WfFwdArgs {
   WfCommon c;
   WfFwdLayer l[WF_MAXL];
   HeadFwd hd;   // classifier on the top layer's final hidden state (C = 0: none)
+  DropArgs drop[WF_MAXL];
 };
 struct WfBwdArgs {
   WfCommon c;
   WfBwdLayer l[WF_MAXL];
   HeadBwd hd;
+  DropArgs drop[WF_MAXL];
 };
 bool wf_supported(const VGeo& g);   // an instantiation exists for the layer's (rank, waves)
 WfPack wf_pack_layout(const VGeo& g);
