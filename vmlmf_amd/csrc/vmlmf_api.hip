@@ -1206,7 +1206,7 @@ static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, co
     Scope sc(0, s);
     WfPack W0;
     memset(&W0, 0, sizeof(W0));
-    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s), "pack")) != 0) return rc;
+    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s, true), "pack")) != 0) return rc;
     if ((rc = hip_fail(launch_rb_pack_stack(S.g[0], S.q, L, rps, imgs, fflags, s), "rb_pack")) != 0) return rc;
   }
   Scope sc(2, s);

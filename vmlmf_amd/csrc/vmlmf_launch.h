@@ -318,7 +318,7 @@ WfPack wf_pack_layout(const VGeo& g);
 // every layer's parameter images (pack_kernel's + the rotated ones at PACK + VPack::WF) in one launch; zero0 / zero1:
 // progress words to clear (the forward's and the backward's), or NULL
 int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const WfPack& W, float* const* pack, unsigned* zero0,
-                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s);
+                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, bool slim = false);   // slim: EH / EXT / BBT only
 int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 // the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)

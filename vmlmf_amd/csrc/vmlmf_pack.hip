@@ -62,8 +62,10 @@ __device__ __forceinline__ float dot_ex(const VGeo& g, const RefP& p, int n, int
   return p.dia_x[n] - half_wave_sum(acc);
 }
 
+// clo / chi: the copy elements [clo, chi) only (chi < 0: all of them, up to L.RB) - the clustered stacks read of this kernel's images
+// nothing but EH / EXT (dot elements) and BBT
 __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VPack& L, const PackDots& D, const int ncopy,
-                                          float* __restrict__ out, const int bid) {
+                                          float* __restrict__ out, const int bid, const int clo = 0, const int chi = -1) {
   const int NT = g.NT;
   if (bid >= ncopy) {   // ---- dot elements: 8 per workgroup ----
     const int l32 = threadIdx.x & 31;
@@ -104,8 +106,8 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
   const int lane = threadIdx.x & 63;
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
-  const int total = (int)L.RB, stride = ncopy * 256;   // the RB region behind it belongs to rb_pack_kernel
-  for (int e = bid * 256 + threadIdx.x; e < total; e += stride) {
+  const int total = chi < 0 ? (int)L.RB : chi, stride = ncopy * 256;   // the RB region behind it belongs to rb_pack_kernel
+  for (int e = clo + bid * 256 + threadIdx.x; e < total; e += stride) {
     float v = 0.f;
     if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
       const int le = e - (int)L.VE;
@@ -339,7 +341,7 @@ struct PackStackLayer {
   VPack L;
   WfPack W;
   PackDots D;
-  int ncopy, ndot, nwf, pad;
+  int ncopy, ndot, nwf, clo, chi, pad;
   float* out;
 };
 struct PackStackArgs {
@@ -359,12 +361,12 @@ __global__ void __launch_bounds__(256) pack_stack_kernel(PackStackArgs a) {
         for (int i = bid * 256 + (int)threadIdx.x; i < a.nzero[z]; i += nthr) a.zero[z][i] = 0u;
   }
   const int npk = ly.ncopy + ly.ndot;
-  if (bid < npk) pack_body(ly.g, ly.p, ly.L, ly.D, ly.ncopy, ly.out, bid);
+  if (bid < npk) pack_body(ly.g, ly.p, ly.L, ly.D, ly.ncopy, ly.out, bid, ly.clo, ly.chi);
   else if (bid < npk + ly.nwf) wf_pack_body(ly.g, ly.p, ly.W, ly.out + ly.L.WF, bid - npk, ly.nwf);
 }
 
 int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const WfPack& W, float* const* pack, unsigned* zero0,
-                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s) {
+                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, bool slim) {
   static_assert(sizeof(PackStackArgs) <= 4096, "kernel-argument segment");
   static_assert(sizeof(PackStackLayer) % 8 == 0, "layer blocks are read as dwords at a multiple of their size");
   PackStackArgs a;
@@ -375,6 +377,11 @@ int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const
     PackStackLayer& y = a.l[l];
     y.g = g[l], y.p = p[l], y.L = P[l], y.W = W, y.out = pack[l];
     pack_counts(g[l], P[l], y.D, y.ncopy, y.ndot);
+    y.clo = 0, y.chi = -1;
+    if (slim) {   // EH / EXT come from the dot workgroups; of the copy elements only BBT is read (vmlmf_rbx.hip)
+      y.clo = (int)P[l].BBT, y.chi = (int)P[l].UD;
+      y.ncopy = (y.chi - y.clo + 255) / 256;
+    }
     y.nwf = (int)((W.total + 255) / 256);
     if (y.nwf > 256) y.nwf = 256;
     const int n = y.ncopy + y.ndot + y.nwf;

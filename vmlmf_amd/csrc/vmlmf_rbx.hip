@@ -246,13 +246,21 @@ __global__ void __launch_bounds__(256) rbx_fwd_kernel(VGeo g, RbGeo q, RbxFwdArg
       if (t > 0) store_tape(t - 1);
       fetch_x(t + 1);
     };
+#if defined(RBX_ABL) && (RBX_ABL & 1)
+    rb_cluster_sum<NMT>(X, S, rbi, sidx, (unsigned)(t + 1), wave, lane, full, wave_sum, c < q.rbl, q.tgcode, grp, G, others);
+#else
     rb_cluster_sum<NMTX>(X, S, rbi, sidx, (unsigned)(t + 1), wave, lane, full, wave_sum, c < q.rbl, q.tgcode, grp, G, others);
+#endif
     f32x4v qs[NQ], qxs[NPX];
     const int mq0 = FLAT ? 0 : grp * NP;   // first M-tile of the vector(s) this wave's gates read
 #pragma unroll
     for (int i = 0; i < NQ; ++i) qs[i] = *reinterpret_cast<const f32x4v*>(full + (size_t)(mq0 + i) * 256 + lane * 4);
 #pragma unroll
     for (int mx = 0; mx < NPX; ++mx) qxs[mx] = *reinterpret_cast<const f32x4v*>(full + (size_t)(NMT + mx) * 256 + lane * 4);
+#if defined(RBX_ABL) && (RBX_ABL & 1)
+#pragma unroll
+    for (int mx = 0; mx < NPX; ++mx) qxs[mx] = qxa[mx];
+#endif
     // Q[t] and qx[t] for the weight gradients: wave w of member 0 stores the tiles m = w, w + 4, ...
     if (train && sidx == 0) {
       for (int m = wave; m < NMTX; m += RB_WAVES) {
@@ -284,8 +292,12 @@ __global__ void __launch_bounds__(256) rbx_fwd_kernel(VGeo g, RbGeo q, RbxFwdArg
 #pragma unroll
     for (int mx = 0; mx < NPX; ++mx)
       if (16 * mx < g.KX) {   // (wave-uniform)
+#if defined(RBX_ABL) && (RBX_ABL & 2)
+        acc[mx] += qxs[mx];
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k) acc[k] = rb_dot<false>(vxa[k][mx], qxs[mx], acc[k]);
+#endif
       }
 #pragma unroll
     for (int mv = 0; mv < NP; ++mv)
@@ -510,8 +522,12 @@ __global__ void __launch_bounds__(256) rbx_bwd_kernel(VGeo g, RbGeo q, RbxBwdArg
     for (int k = 0; k < 4; ++k) {
 #pragma unroll
       for (int mv = 0; mv < NP; ++mv) qa[FLAT ? (k >> 1) : 0][mv] = rb_dot<false>(vb[k][mv], dp[k], qa[FLAT ? (k >> 1) : 0][mv]);
+#if defined(RBX_ABL) && (RBX_ABL & 2)
+      qxa[k & 1] += dp[k];
+#else
 #pragma unroll
       for (int mx = 0; mx < NPX; ++mx) qxa[mx] = rb_dot<false>(vxb[k][mx], dp[k], qxa[mx]);
+#endif
     }
     float* pw = part + ((size_t)(buf * RB_WAVES + wave) * NMTX) * 256;
 #pragma unroll
@@ -539,12 +555,20 @@ __global__ void __launch_bounds__(256) rbx_bwd_kernel(VGeo g, RbGeo q, RbxBwdArg
       if (t < T - 1) store_dx(t + 1);
       fetch_tape(t - 1);
     };
+#if defined(RBX_ABL) && (RBX_ABL & 1)
+    rb_cluster_sum<NMT>(X, S, rbi, sidx, (unsigned)(T - t), wave, lane, full, wave_sum, c < q.rbl, 0u, 0, 1, others);
+#else
     rb_cluster_sum<NMTX>(X, S, rbi, sidx, (unsigned)(T - t), wave, lane, full, wave_sum, c < q.rbl, 0u, 0, 1, others);
+#endif
     f32x4v qs[NMU], dqs[NPX];
 #pragma unroll
     for (int u = 0; u < NMU; ++u) qs[u] = *reinterpret_cast<const f32x4v*>(full + (size_t)q.mlist[grp][u] * 256 + lane * 4);
 #pragma unroll
     for (int mx = 0; mx < NPX; ++mx) dqs[mx] = *reinterpret_cast<const f32x4v*>(full + (size_t)(NMT + mx) * 256 + lane * 4);
+#if defined(RBX_ABL) && (RBX_ABL & 1)
+#pragma unroll
+    for (int mx = 0; mx < NPX; ++mx) dqs[mx] = qxa[mx];
+#endif
     if (sidx == 0) {   // dQ[t], dqx[t] for the weight gradients
       for (int m = wave; m < NMTX; m += RB_WAVES) {
         const f32x4v s = *reinterpret_cast<const f32x4v*>(full + (size_t)m * 256 + lane * 4);
