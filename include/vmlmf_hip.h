@@ -130,6 +130,11 @@ const char *vmlmf_last_error(void);
  *   "wring"         the batched weight-gradient products of large layers (thread slots >= 256, fp32 tapes, time-major contiguous x / y)
  *                   with their operands streamed through an LDS ring (wgrad_ring_kernel): -1 (default) for the layers of the
  *                   step-wise / clustered recurrences with >= 1024 rows, 0 never, 1 wherever the kernel takes the layer
+ *   "rbx"           1 (default): vmlmf_stack_* runs two to four clustered layers (hidden units beyond one CU, e.g. the PTB layers) in one
+ *                   launch per direction while every layer's clusters are co-resident; 0: never (the caller chains the layers);
+ *                   2: a single such layer takes that form too (measurements).  VMLMF_RBX in the environment
+ *   "ffb"           0 (default): behind the clustered stack's backward, reduce_cg_stack_kernel + finish_stack_kernel; 1: one finishing
+ *                   launch that sums the partial blocks itself (measured slower; kept parity-tested).  VMLMF_FFB
  *   "test_wride_spin"  looks a riding worker takes before it gives up (tests of the failure path; 0 = the production bound)
  */
 int vmlmf_tune(const char *key, int value);

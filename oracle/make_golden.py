@@ -263,6 +263,25 @@ def case_config_c(name="cfgC_v1_opp2"):
          G0=grads_of(rnn, P0, prefix="rnncells.0."), G1=grads_of(rnn, P1, prefix="rnncells.1."))
 
 
+def case_unequal_sizes(name="seq_v1_h128_h256"):
+    """MyLSTM with hidden_layer_sizes=[128, 256] (vmlmf.py:283-292: layer 1 reads 128 inputs), Opportunity's 77 features, fp32 reference."""
+    B, T, I, Hs, rw, ru = 32, 12, 77, [128, 256], 24, 24
+    P0 = O.make_params(O.V1, I, Hs[0], rw, ru, seed=13)
+    P1 = O.make_params(O.V1, Hs[0], Hs[1], rw, ru, seed=15)
+    x_np, _ = O.synthetic_batch(B, T, I, seed=2345, classes=18)
+    r = rng_of(5432)
+    dy = r.standard_normal((B, T, Hs[1])).astype(np.float32)
+    rnn = MyLSTM(I, hidden_layer_sizes=Hs, batch_first=True, w_rank=rw, u_ranks=[ru], cell=MyVMLMFCell)
+    load_into(rnn, P0, prefix="rnncells.0.")
+    load_into(rnn, P1, prefix="rnncells.1.")
+    x = torch.tensor(x_np, requires_grad=True)
+    y, hcat = rnn(x)
+    (y * torch.tensor(dy)).sum().backward()
+    save(name, meta=np.array([O.V1, B, T, I, Hs[0], Hs[1], rw, ru]), seeds=np.array([13, 15, 2345, 5432]),
+         y_s=y.detach().numpy()[:, ::4], hT=hcat.detach().numpy(), dx_s=x.grad.numpy()[::4],
+         G0=grads_of(rnn, P0, prefix="rnncells.0."), G1=grads_of(rnn, P1, prefix="rnncells.1."))
+
+
 def case_net_adam(name="cfgA_net_adam3"):
     """Net (MyLSTM + Linear(H,18)) at config A, 3 steps of the train.py:58-65 loop (Adam lr=.002, CE)."""
     B, T, I, H, rw, ru = 64, 128, 9, 180, 16, 16
@@ -412,6 +431,7 @@ CASES = {
     "cfgA_v5_uci": lambda n: case_config_a_novm(n, O.V5),
     "cfgA_v6_uci": lambda n: case_config_a_novm(n, O.V6),
     "cfgC_v1_opp2": lambda n: case_config_c(n),
+    "seq_v1_h128_h256": lambda n: case_unequal_sizes(n),
     "cfgA_net_adam3": lambda n: case_net_adam(n),
     # BASELINE config E shape, one MyVMLSTMGroup layer at the only batch the reference executes (40)
     "cfgE_v4_b40": lambda n: case_lm_seq(n, O.V4, 40, 35, 650, 32, [32, 32], 51, scale=0.05, full=False, xscale=0.05),

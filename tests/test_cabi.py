@@ -152,7 +152,10 @@ def test_stack_query_host_logic():
     assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == 0                    # group cells: two rank blocks
     assert query(2, 8, 5, 20, 360, 8, 8, variant=_lib.V2_GROUP_CELL, g=2)[0] == _lib.E_UNSUPPORTED   # ... within four waves of units
     assert query(2, 8, 5, 64, 64, 8, 8, variant=_lib.V4_LM_GROUP, g=2)[0] in (_lib.E_UNSUPPORTED, _lib.E_SHAPE)   # the flat LM layout: not covered
-    assert query(2, 8, 5, 20, 64, 8, 8, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED            # unequal hidden sizes
+    assert query(2, 8, 5, 20, 64, 8, 8, H_upper=72, I_upper=64)[0] == 0               # unequal hidden sizes (round 6): the widest layer's geometry
+    assert query(2, 8, 5, 20, 64, 8, 8, H_upper=320, I_upper=64)[0] == _lib.E_UNSUPPORTED           # ... which must fit four waves of units
+    assert query(2, 8, 5, 20, 64, 8, 16, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED           # ... one padded rank on both sides
+    assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED   # ... one group
     assert query(2, 8, 5, 20, 64, 8, 8, I_upper=48)[0] == _lib.E_SHAPE                # layer 1 does not read layer 0's width
     assert b"stack" in lib.vmlmf_last_error()
 
@@ -165,13 +168,18 @@ def test_every_documented_kernel_switch_is_accepted():
     keys = re.findall(r'^ \*   "([a-z0-9_]+)"', block, flags=re.M)
     assert {"rb", "wride", "inrow", "wring", "adam_guard"} <= set(keys), keys
     defaults = {"rb": -1, "rb_min_batch": 0, "rb_cluster": 0, "rb_rows": 0, "rec3": 6, "wride": 1, "inrow": -1, "adam_guard": 1,
-                "clear_health": 0, "wring": -1, "test_wride_spin": 0, "direct": 1, "finish2": 1}
+                "clear_health": 0, "wring": -1, "test_wride_spin": 0, "direct": 1, "finish2": 1, "rbx": 1, "ffb": 0}
     lib = _lib.lib()
+    import ctypes
     for k in keys:
         assert k in defaults, f"header documents {k}: add its default here"
         g0 = lib.vmlmf_tune_generation()
+        was = ctypes.c_int(0)
+        readable = lib.vmlmf_tune_get(k.encode(), ctypes.byref(was)) == 0
         assert lib.vmlmf_tune(k.encode(), defaults[k]) == 0, (k, lib.vmlmf_last_error())
         assert lib.vmlmf_tune_generation() == g0 + 1
+        if readable:      # leave the process as it was (rb_min_batch's 0 means 1: the next test's plans would change)
+            assert lib.vmlmf_tune(k.encode(), was.value) == 0
     assert lib.vmlmf_tune(b"no_such_switch", 1) == _lib.E_BADARG
     # the measured-no-gain forms of round 4 left the product library (tools/experiments/*.patch): their switches are gone with them
     for k in (b"inrow_rows", b"rb_wgrad", b"rb_xfold"):
@@ -180,7 +188,6 @@ def test_every_documented_kernel_switch_is_accepted():
     assert lib.vmlmf_tune(b"wride", 0) == 0 and _lib.tune_get("wride") == 0
     assert lib.vmlmf_tune(b"wride", 1) == 0 and _lib.tune_get("wride") == (0 if os.environ.get("VMLMF_WRIDE") == "0" else 1)
     assert lib.vmlmf_tune(b"rec3", 7) == 0 and _lib.tune_get("rec3") == 7 and lib.vmlmf_tune(b"rec3", 6) == 0
-    import ctypes
     assert lib.vmlmf_tune_get(b"no_such_switch", ctypes.byref(ctypes.c_int(0))) == _lib.E_BADARG
 
 
@@ -194,3 +201,66 @@ def test_the_product_library_stays_pruned():
     assert size < 9_300_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
     out = subprocess.run(["strings", "-n", "12", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "VMLMF_R4_ABL" not in out and "VMLMF_WRIDE_DRY" not in out
+
+
+def _stack_layers(variant, L, B, T, H, rw, ru, g):
+    layers = (_lib.StackLayer * L)()
+    for l in range(L):
+        layers[l].desc = _lib.make_desc(variant, B, T, H, H, rw, ru, g=g, time_major=True, training=True)
+    return layers
+
+
+def test_clustered_stacks_are_planned_where_all_clusters_are_co_resident():
+    """Round 6 (vmlmf_stack_*, ABI 12; host-only): PTB-sized layers (vmlmf_lm.py:53-174 / 178-280) are stacked into one launch per direction
+    while L x ceil(B / rows) x 16 workgroups fit the device (256 CUs assumed without a GPU): two layers up to 128 rows, three up to 80;
+    beyond that - and for a single layer - VMLMF_E_UNSUPPORTED (the caller chains the layers); such stacks take dropout inside."""
+    lib = _lib.lib()
+    rb = (ctypes.c_size_t * 4)()
+    wb = ctypes.c_size_t()
+
+    def query(variant, L, B, ru, g, H=650):
+        layers = _stack_layers(variant, L, B, 35, H, 32, ru, g)
+        rc = lib.vmlmf_stack_query(L, ctypes.addressof(layers), ctypes.addressof(rb), ctypes.addressof(wb))
+        return rc, lib.vmlmf_stack_dropout_fused(L, ctypes.addressof(layers))
+
+    for B in (7, 32, 64, 128):
+        assert query(_lib.V4_LM_GROUP, 2, B, [32, 32], 2) == (0, 1), B
+        assert query(_lib.V3_LM, 2, B, [32], 1) == (0, 1), B
+    assert query(_lib.V4_LM_GROUP, 2, 256, [32, 32], 2)[0] == _lib.E_UNSUPPORTED
+    assert query(_lib.V4_LM_GROUP, 3, 128, [32, 32], 2)[0] == _lib.E_UNSUPPORTED
+    assert query(_lib.V3_LM, 3, 80, [32], 1) == (0, 1)
+    assert query(_lib.V3_LM, 1, 32, [32], 1)[0] == _lib.E_UNSUPPORTED
+    assert rb[0] > 0 and wb.value > 0
+    # small layers: the wavefront form; one-group stacks take dropout inside its launches too, two-group stacks do not
+    assert query(_lib.V3_LM, 2, 32, [16], 1, H=128)[1] == 1
+    layers = (_lib.StackLayer * 2)()
+    for l in range(2):
+        layers[l].desc = _lib.make_desc(_lib.V2_GROUP_CELL, 16, 8, 64, 64, 8, [8, 8], g=2, training=True)
+    assert lib.vmlmf_stack_query(2, ctypes.addressof(layers), ctypes.addressof(rb), ctypes.addressof(wb)) == 0
+    assert lib.vmlmf_stack_dropout_fused(2, ctypes.addressof(layers)) == 0
+    # the switch that keeps clustered layers chained
+    _lib.tune("rbx", 0)
+    try:
+        assert query(_lib.V4_LM_GROUP, 2, 32, [32, 32], 2)[0] == _lib.E_UNSUPPORTED
+    finally:
+        _lib.tune("rbx", 1)
+    assert query(_lib.V4_LM_GROUP, 2, 32, [32, 32], 2)[0] == 0
+
+
+def test_the_run_time_switches_follow_the_environment():
+    """Round 6: the switches defined inside the extern "C" block came up with other switches' defaults (mangled lambda names shared with the
+    top-of-file block).  A fresh process must see what the environment says."""
+    import subprocess
+    import sys
+    code = ("import ctypes; from vmlmf_amd import _lib; l = _lib.lib(); v = ctypes.c_int(); out = []\n"
+            "for k in (b'rbx', b'ffb', b'rb', b'inrow'):\n"
+            "    l.vmlmf_tune_get(k, ctypes.byref(v)); out.append(v.value)\n"
+            "print(out)")
+    env = dict(os.environ, VMLMF_RBX="7", VMLMF_FFB="-1", VMLMF_RB="0", VMLMF_INROW="1", PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().splitlines()[-1] == "[7, -1, 0, 1]", r.stdout
+    env = {k: v for k, v in os.environ.items() if not k.startswith("VMLMF_")}
+    env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert r.stdout.strip().splitlines()[-1] == "[1, 0, -1, -1]", r.stdout

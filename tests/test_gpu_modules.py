@@ -74,6 +74,28 @@ def test_config_c_two_layer_mylstm_vs_reference():
             assert_grad(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, f"layer{li}.{k}")
 
 
+def test_two_layers_of_different_sizes_vs_reference():
+    """MyLSTM(hidden_layer_sizes=[128, 256]) on the default launch policy (one wavefront launch per direction since round 6)
+    against the imported reference's vectors."""
+    d = load_golden("seq_v1_h128_h256")
+    _, B, T, I, H0, H1, rw, ru = (int(v) for v in d["meta"])
+    rnn = MyLSTM(I, hidden_layer_sizes=[H0, H1], batch_first=True, w_rank=rw, u_ranks=[ru], cell=MyVMLMFCell)
+    load_cell(rnn.rnncells[0], O.make_params(O.V1, I, H0, rw, ru, seed=int(d["seeds"][0])))
+    load_cell(rnn.rnncells[1], O.make_params(O.V1, H0, H1, rw, ru, seed=int(d["seeds"][1])))
+    rnn = rnn.to(DEV)
+    x_np, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][2]), classes=18)
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][3]))).standard_normal((B, T, H1)).astype(np.float32)
+    x = torch.tensor(x_np, device=DEV, requires_grad=True)
+    y, hcat = rnn(x)
+    (y * torch.tensor(dy, device=DEV)).sum().backward()
+    assert_out(y.detach().cpu().numpy()[:, ::4], d["y_s"], "y")
+    assert_out(hcat.detach().cpu().numpy(), d["hT"], "hT")
+    assert_grad(x.grad.cpu().numpy()[::4], d["dx_s"], "dx")
+    for li, G in ((0, d["G0"]), (1, d["G1"])):
+        for k, v in G.items():
+            assert_grad(getattr(rnn.rnncells[li], k).grad.cpu().numpy(), v, f"layer{li}.{k}")
+
+
 def test_lm_state_carry_two_minibatches_vs_reference():
     d = load_golden("lm_v3_carry")
     _, B, T, H, _, rw, ru = (int(v) for v in d["meta"])

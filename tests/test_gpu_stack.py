@@ -82,6 +82,89 @@ def test_stack_matches_chained_layers(L, B, T, I, H, r, kind):
         assert err <= 1e-4 * scale + 1e-6, (name, err, scale)
 
 
+UNEQUAL = [
+    # B, T, I, hidden_layer_sizes, rank, cell      (a VMLMF cell needs input_size <= hidden_size, vmlmf.py:94: sizes cannot shrink)
+    (8, 5, 12, [40, 64], 8, "vm"),
+    (128, 24, 77, [128, 256], 24, "vm"),           # BASELINE configs[2]'s shape with a narrower bottom layer
+    (5, 7, 20, [64, 100, 180], 16, "vm"),          # three sizes, the middle one no multiple of 64
+    (9, 6, 24, [72, 130], 16, "lmf"),
+    (33, 9, 30, [64, 64, 192], 32, "vm"),
+    (6, 1, 10, [24, 200], 8, "vm"),
+    (300, 3, 16, [128, 129], 16, "vm"),
+]
+
+
+@pytest.mark.parametrize("B,T,I,Hs,r,kind", UNEQUAL)
+def test_stack_of_layers_of_different_hidden_sizes(B, T, I, Hs, r, kind):
+    """MyLSTM builds any hidden_layer_sizes (vmlmf.py:283-292: layer i reads hidden_layer_sizes[i - 1]); round 6: such a stack rides
+    the wavefront launches too, every layer on the widest layer's thread-slot geometry - against the chained per-layer calls."""
+    import vmlmf_amd
+    from vmlmf_amd import functional as F
+    torch.manual_seed(77 + B + len(Hs))
+    L = len(Hs)
+    cell = {"vm": vmlmf_amd.MyVMLMFCell, "lmf": vmlmf_amd.MyLSTMCell}[kind]
+    model = vmlmf_amd.MyLSTM(I, hidden_layer_sizes=Hs, batch_first=True, w_rank=r, u_ranks=r, cell=cell).cuda()
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.5)
+    x = torch.randn(B, T, I, device="cuda")
+    gy = torch.randn(B, T, Hs[-1], device="cuda")
+    gh = torch.randn(B, sum(Hs), device="cuda")
+    ref = _run(model, x, "0", (gy, gh))
+    got = _run(model, x, "1", (gy, gh))
+    cfg = model.rnncells[0].kernel_cfg()
+    assert F._stack_plan((cfg["variant"], cfg["g"], r, (r,), False, 0), L, B, T, I, tuple(Hs), True) is not None
+    for a, b, what in ((got[0], ref[0], "y"), (got[1], ref[1], "hidden"), (got[2], ref[2], "dx")):
+        scale = float(b.abs().max()) + 1e-12
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, scale), what
+    assert set(got[3]) == set(ref[3])
+    for name, gref in ref[3].items():
+        scale = float(gref.abs().max()) + 1e-12
+        err = float((got[3][name] - gref).abs().max())
+        assert err <= 1e-4 * scale + 1e-6, (name, err, scale)
+
+
+def test_unequal_stack_with_the_classifier_against_the_fp64_oracle():
+    """Net(layer_sizes=[128, 256]) (vmlmf.py:330-355: Linear(256, 18) on the top layer's last step) through the default launch
+    policy against the literal fp64 restatement chained layer by layer: logits, dx, every gradient of both layers and the head."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [os.path.join(os.path.dirname(here), "oracle"), here]
+    import vmlmf_oracle as O
+    import vmlmf_amd
+    from hip_util import ORDER, assert_grad, assert_out
+    B, T, I, Hs, r = 64, 16, 77, [128, 256], 24
+    torch.manual_seed(9)
+    net = vmlmf_amd.Net(I, layer_sizes=Hs, w_rank=r, u_rank=[r], model=vmlmf_amd.MyLSTM, cell=vmlmf_amd.MyVMLMFCell).cuda()
+    with torch.no_grad():
+        net.lin.weight.mul_(10.0)
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = rng.standard_normal((B, T, I)).astype(np.float32)
+    tgt = rng.integers(0, 18, B)
+    xg = torch.tensor(x, device="cuda").requires_grad_(True)
+    logits = net(xg)
+    vmlmf_amd.cross_entropy(logits, torch.tensor(tgt, device="cuda")).backward()
+    torch.cuda.synchronize()
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    cur, Pts = xt, []
+    for cell in net.rnn.rnncells:
+        named = dict(cell.named_parameters())
+        Pt = O.to_torch({k: named[k].detach().cpu().numpy() for k in ORDER[O.V1]}, dtype=torch.float64, requires_grad=True)
+        Pts.append((named, Pt))
+        cur, _, _ = O.literal_sequence(O.V1, Pt, cur, None, None, time_major=False)
+    W = net.lin.weight.detach().cpu().double().requires_grad_(True)
+    b = net.lin.bias.detach().cpu().double().requires_grad_(True)
+    lr = cur[:, -1] @ W.t() + b
+    torch.nn.functional.cross_entropy(lr, torch.tensor(tgt)).backward()
+    assert_out(logits.detach().cpu().numpy(), lr.detach().numpy(), "logits")
+    assert_grad(xg.grad.cpu().numpy(), xt.grad.numpy(), "dx")
+    assert_grad(net.lin.weight.grad.cpu().numpy(), W.grad.numpy(), "lin.weight")
+    assert_grad(net.lin.bias.grad.cpu().numpy(), b.grad.numpy(), "lin.bias")
+    for l, (named, Pt) in enumerate(Pts):
+        for k in ORDER[O.V1]:
+            assert_grad(named[k].grad.cpu().numpy(), Pt[k].grad.numpy(), "layer %d %s" % (l, k))
+
+
 def test_stack_inference_matches_training_forward():
     import vmlmf_amd
     torch.manual_seed(5)

@@ -171,6 +171,26 @@ def test_config_a_unified_fp64_vs_reference():
     grad_close(G, d["G"], "cfgA")
 
 
+def test_two_layers_of_different_sizes_literal_fp64_vs_reference():
+    """MyLSTM(hidden_layer_sizes=[128, 256]) (vmlmf.py:283-314): the literal restatement chained layer by layer, fp64, against the
+    imported reference's fp32 vectors."""
+    d = load_golden("seq_v1_h128_h256")
+    _, B, T, I, H0, H1, rw, ru = (int(v) for v in d["meta"])
+    P0 = O.to_torch(O.make_params(O.V1, I, H0, rw, ru, seed=int(d["seeds"][0])), dtype=torch.float64, requires_grad=True)
+    P1 = O.to_torch(O.make_params(O.V1, H0, H1, rw, ru, seed=int(d["seeds"][1])), dtype=torch.float64, requires_grad=True)
+    x_np, _ = O.synthetic_batch(B, T, I, seed=int(d["seeds"][2]), classes=18)
+    dy = np.random.Generator(np.random.PCG64(int(d["seeds"][3]))).standard_normal((B, T, H1)).astype(np.float32)
+    x = torch.tensor(x_np, dtype=torch.float64, requires_grad=True)
+    y0, h0, _ = O.literal_sequence(O.V1, P0, x, None, None, time_major=False)
+    y1, h1, _ = O.literal_sequence(O.V1, P1, y0, None, None, time_major=False)
+    (y1 * torch.tensor(dy, dtype=torch.float64)).sum().backward()
+    close(y1.detach()[:, ::4], d["y_s"], 2e-5, 1e-4, "y")
+    close(torch.cat([h0, h1], -1).detach(), d["hT"], 2e-5, 1e-4, "hT")
+    close(x.grad[::4], d["dx_s"], 5e-5, 1e-4, "dx")
+    grad_close({k: v.grad.numpy() for k, v in P0.items()}, d["G0"], "layer 0")
+    grad_close({k: v.grad.numpy() for k, v in P1.items()}, d["G1"], "layer 1")
+
+
 @pytest.mark.parametrize("name", ["cfgA_v5_uci", "cfgA_v6_uci"])
 def test_config_a_comparison_cells_unified_fp64_vs_reference(name):
     """The two cells without vm (plain low-rank LSTM, group ablation) at the UCI-HAR shape."""

@@ -284,8 +284,10 @@ class MyLSTM(nn.Module):
         # every layer in one wavefront launch per direction when the stack is covered (same cell type and sizes above the
         # first layer; include/vmlmf_hip.h: vmlmf_stack_*); a classifier rides on the top layer's workgroups
         cells = list(self.rnncells)
+        # (hidden sizes may differ from layer to layer, vmlmf.py:283-292: the library decides what its launches cover - a VMLMF cell needs
+        #  input_size <= hidden_size, so the sizes of such a stack never shrink)
         if (x.is_cuda and all(type(c) is type(cells[0]) and hasattr(c, "kernel_cfg") for c in cells)
-                and len(set(self.hidden_layer_sizes)) == 1 and getattr(cells[0], "low_rank", True)):
+                and getattr(cells[0], "low_rank", True)):
             cfg = cells[0].kernel_cfg()
             cfg.pop("pack_cache", None)
             if all({k: v for k, v in c.kernel_cfg().items() if k != "pack_cache"} == cfg for c in cells[1:]):

@@ -234,7 +234,9 @@ int g_inrow = []() { const char* e = getenv("VMLMF_INROW"); return e ? atoi(e) :
 int g_wring = []() { const char* e = getenv("VMLMF_WRING"); return e ? atoi(e) : -1; }();
 
 // ---- geometry ----
-int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
+// force_W: at least this many waves of hidden units per group (a stack whose layers differ in hidden_size runs every layer on the
+// widest one's thread-slot geometry: the surplus slots are padding, as the slots behind a hidden size that is no multiple of 64 are)
+int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr, int force_W = 0) {
   if (d == nullptr) return fail(VMLMF_E_BADARG, "null descriptor");
   VGeo g;
   memset(&g, 0, sizeof(g));
@@ -270,6 +272,7 @@ int make_geo(const vmlmf_desc* d, VGeo* out, RbGeo* rbout = nullptr) {
   if (g.ru0 < 1 || (g.G == 2 && g.ru1 < 1)) return fail(VMLMF_E_BADARG, "u_ranks must be positive");
   g.Hg = g.H / g.G;
   g.W = (g.Hg + 63) / 64;
+  if (force_W > g.W) g.W = force_W;
   g.NW = g.G * g.W;
   g.NT = g.NW * 64;
   g.off1 = vg_pad8(g.ru0);
@@ -1109,6 +1112,18 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
       return 0;
     }
   }
+  // layers of a stack may differ in hidden_size (MyLSTM builds any hidden_layer_sizes, vmlmf.py:283-292; a VMLMF cell needs input_size
+  // <= hidden_size, vmlmf.py:94, so the sizes cannot shrink): every layer then runs on the widest layer's wave count
+  int Wmax = 0;
+  for (int l = 0; l < L; ++l) {
+    RbGeo q;
+    VGeo gl;
+    vmlmf_desc dd = ly[l].desc;
+    if (dd.dtype == VMLMF_DT_BF16) dd.dtype = VMLMF_DT_F32;
+    const int rc = make_geo(&dd, &gl, &q);
+    if (rc != 0) return rc;
+    Wmax = gl.W > Wmax ? gl.W : Wmax;
+  }
   for (int l = 0; l < L; ++l) {
     RbGeo q;
     // dtype bf16 on a stack: below the batch where the bf16-MFMA row blocks pay (4096 rows: DESIGN.md section 4.8) the wavefront
@@ -1121,7 +1136,7 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
       if (dd.B >= 4096) return fail(VMLMF_E_UNSUPPORTED, "stack: dtype bf16 at 4096 rows and more runs the row-block bf16-MFMA kernels layer by layer");
       dd.dtype = VMLMF_DT_F32;
     }
-    const int rc = make_geo(&dd, &S.g[l], &q);
+    const int rc = make_geo(&dd, &S.g[l], &q, Wmax);
     if (rc != 0) return rc;
     if (bt) {
       const int K = wf_width(S.g[l]);
@@ -1135,10 +1150,12 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
                                        "<= 24, or 32 with at most three waves; fp32)");
     if (l > 0) {
       const VGeo& g0 = S.g[0];
-      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.H != g0.H || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G || g.rw != g0.rw || g.bt != g0.bt ||
-          g.time_major != g0.time_major || g.training != g0.training)
-        return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, H, ranks, layout and training flag");
-      if (g.I != g.H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: input_size must equal hidden_size");
+      if (g.variant != g0.variant || g.B != g0.B || g.T != g0.T || g.KH != g0.KH || g.KX != g0.KX || g.ru0 != g0.ru0 || g.ru1 != g0.ru1 || g.G != g0.G || g.rw != g0.rw || g.bt != g0.bt ||
+          g.time_major != g0.time_major || g.training != g0.training || g.W != g0.W)
+        return fail(VMLMF_E_UNSUPPORTED, "stack: layers must agree in variant, B, T, ranks, layout and training flag");
+      if (g.I != S.g[l - 1].H) return fail(VMLMF_E_SHAPE, "stack: layer l > 0 reads the layer below: its input_size must equal that layer's hidden_size");
+      if (g.H != g0.H && (g.bt || g.G != 1 || g.KH != g.KX))
+        return fail(VMLMF_E_UNSUPPORTED, "stack: layers of different hidden sizes: one-group layers, fp32 tapes, equal padded ranks on both sides");
     }
   }
   S.W = wf_pack_layout(S.g[0]);
@@ -1152,7 +1169,7 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
     S.lay[l] = make_layout(S.g[l], S.P[l], q0);
     const long long per = S.lay[l].f_total > S.lay[l].b_total ? S.lay[l].f_total : S.lay[l].b_total;
     S.ws_layer[l] = o, o += align64(per);
-    S.ws_dx[l] = o, o += align64(l > 0 ? (long long)S.g[0].T * S.g[0].B * S.g[0].H : 0);   // dx of layer l = dy of layer l - 1
+    S.ws_dx[l] = o, o += align64(l > 0 ? (long long)S.g[0].T * S.g[0].B * S.g[l].I : 0);   // dx of layer l = dy of layer l - 1
   }
   S.ws_total = o;
   return 0;
@@ -1378,6 +1395,7 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
     w.x = l == 0 ? x : (ly[l - 1].drop != nullptr ? ly[l - 1].drop->y_dropped : ly[l - 1].y);
     if ((rc = rbx_drop(ly[l].drop, true, &a.drop[l])) != 0) return rc;
     w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
+    w.syT = g.syT, w.syB = g.syB, w.H = g.H, w.Hg = g.Hg;
     const bool mixed = g.KH != g.KX;   // both sides at the wider padded rank: re-laid images in the WF region
     const float* wf = pack + S.P[l].WF;
     w.VE = mixed ? wf + S.W.VE : pack + S.P[l].VE, w.VXT = mixed ? wf + S.W.VXK : pack + S.P[l].VXT;
@@ -1461,6 +1479,7 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
       w.dx = l == 0 ? dx : ws + S.ws_dx[l];
       w.want_dx = w.dx != nullptr ? 1 : 0;
       w.sxT = g.sxT, w.sxB = g.sxB, w.I = g.I;
+      w.syT = g.syT, w.syB = g.syB, w.H = g.H, w.Hg = g.Hg;
     }
     {
       Scope sc(3, s);
@@ -1567,7 +1586,7 @@ int vmlmf_tune(const char* key, int value) {
   else if (k == "direct") g_direct = value;
   else if (k == "finish2") g_finish2 = value;
   else if (k == "wride") g_wride_tripped.store(value != 0 ? 0 : 1);   // 0: stand-alone weight-gradient kernel; 1: ride again (where VMLMF_WRIDE allows)
-  else if (k == "rb_min_batch") g_rb_minB = value < 1 ? 1 : value;
+  else if (k == "rb_min_batch") g_rb_minB = value < 0 ? 0 : value;   // (0 = never, the default)
   else if (k == "rb_cluster") g_rb_S = value < 0 ? 0 : value;
   else if (k == "rb_rows") g_rb_rows = value < 0 ? 0 : value;
   else return fail(VMLMF_E_BADARG, "tune: unknown key " + k);

@@ -282,7 +282,9 @@ struct WfFwdLayer {
   const float *h0, *c0;
   float *y, *hT, *cT, *gates, *cs, *Qs, *qx;
   long long sxT, sxB;
-  int I, pad;
+  long long syT, syB;               // strides of this layer's y (round 6: layers of a stack may differ in hidden_size)
+  int I, H;                         // input_size, hidden_size of THIS layer
+  int Hg, pad;                      // hidden units per group
 };
 struct WfBwdLayer {
   const float *gates, *cs, *dy, *dhT, *dcT;
@@ -290,7 +292,9 @@ struct WfBwdLayer {
   const float *VR, *VRX;            // wf_pack_kernel images
   float *dpre, *dQs, *dqx, *dx, *dh0, *dc0;
   long long sxT, sxB;               // strides of dx (= the layer's x)
+  long long syT, syB;               // strides of dy (= the layer's y)
   int I, want_dx;
+  int H, Hg;                        // hidden_size, units per group of THIS layer
 };
 struct WfCommon {
   unsigned* flag;                   // [L - 1][B][WF_FLAG_STRIDE] progress words, then the error word

@@ -399,7 +399,9 @@ _STACK_CACHE = {}
 
 
 def _stack_plan(cfg, L, B, T, I, H, training):
-    key = (cfg, L, B, T, I, H, training, _lib.lib().vmlmf_tune_generation())
+    """H: the layers' hidden size, or one per layer (round 6: MyLSTM builds any hidden_layer_sizes, vmlmf.py:283-292)."""
+    Hs = tuple(H) if isinstance(H, (list, tuple)) else (int(H),) * L
+    key = (cfg, L, B, T, I, Hs, training, _lib.lib().vmlmf_tune_generation())
     if key in _STACK_CACHE:
         return _STACK_CACHE[key]
     variant, g, w_rank, u_ranks, time_major, dtype = cfg
@@ -408,7 +410,7 @@ def _stack_plan(cfg, L, B, T, I, H, training):
         layers = (_lib.StackLayer * L)()
         descs = []
         for l in range(L):
-            d = _lib.make_desc(variant, B, T, I if l == 0 else H, H, w_rank, u_ranks, g=g, time_major=time_major,
+            d = _lib.make_desc(variant, B, T, I if l == 0 else Hs[l - 1], Hs[l], w_rank, u_ranks, g=g, time_major=time_major,
                                training=training, dtype=dtype)
             layers[l].desc = d
             descs.append(d)
@@ -454,15 +456,17 @@ class VmlmfStackFn(torch.autograd.Function):
             T, B, I = x.shape
         else:
             B, T, I = x.shape
-        H = _hidden_size(variant, params[:nper])
+        Hs = tuple(_hidden_size(variant, params[l * nper:(l + 1) * nper]) for l in range(L))
         training = bool(any(ctx.needs_input_grad))
-        plan = _stack_plan(cfg, L, B, T, I, H, training)
+        plan = _stack_plan(cfg, L, B, T, I, Hs, training)
         if plan is None:
             raise RuntimeError("vmlmf_amd: this stack is not covered by the wavefront kernels (vmlmf_stack_supported)")
         descs, rbytes, wbytes = plan
         dev = x.device
-        ys = [torch.empty((T, B, H) if time_major else (B, T, H), device=dev, dtype=torch.float32) for _ in range(L)]
-        hc = torch.empty((2, L, B, H), device=dev, dtype=torch.float32)
+        ys = [torch.empty((T, B, Hs[l]) if time_major else (B, T, Hs[l]), device=dev, dtype=torch.float32) for l in range(L)]
+        # final states of every layer: one allocation when the layers are alike (what the LM carries), one per layer otherwise
+        hc = [torch.empty((2, B, Hs[l]), device=dev, dtype=torch.float32) for l in range(L)] if len(set(Hs)) > 1 else \
+            list(torch.empty((L, 2, B, Hs[0]), device=dev, dtype=torch.float32).unbind(0))
         reserves = [torch.empty(rbytes[l], device=dev, dtype=torch.uint8) if training else None for l in range(L)]
         ws = _workspace(dev, wbytes)
         h0c = None if h0 is None else h0.contiguous()      # initial states of every layer, (L, B, H), or None = zeros
@@ -480,7 +484,7 @@ class VmlmfStackFn(torch.autograd.Function):
                 dr = _lib.Dropout(float(drops[l][0]), int(drops[l][2]), drops[l][1].data_ptr(), yds[l].data_ptr())
                 keep.append(dr)
                 ly.drop = ctypes.pointer(dr)
-            ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[0, l].data_ptr(), hc[1, l].data_ptr()
+            ly.y, ly.hT, ly.cT = ys[l].data_ptr(), hc[l][0].data_ptr(), hc[l][1].data_ptr()
             ly.reserve = None if reserves[l] is None else reserves[l].data_ptr()
             ly.h0 = None if h0c is None else h0c[l].data_ptr()
             ly.c0 = None if c0c is None else c0c[l].data_ptr()
@@ -506,7 +510,7 @@ class VmlmfStackFn(torch.autograd.Function):
             ctx.save_for_backward(x, *ys, *reserves, *params, *([hw] if hw is not None else []),
                                   *([h0c] if h0c is not None else []), *([c0c] if c0c is not None else []), *dsaved)
         top = ys[-1] if yds[-1] is None else yds[-1]
-        return (top,) + tuple(hc[0, l] for l in range(L)) + tuple(hc[1, l] for l in range(L)) + (logits,)
+        return (top,) + tuple(hc[l][0] for l in range(L)) + tuple(hc[l][1] for l in range(L)) + (logits,)
 
     @staticmethod
     def backward(ctx, dy, *dstates):
@@ -603,8 +607,13 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     ur = tuple(u_ranks) if isinstance(u_ranks, (list, tuple)) else (int(u_ranks),)
     cfg = (variant, g, int(w_rank), ur, bool(time_major), dt)
     T, B = (x.shape[0], x.shape[1]) if time_major else (x.shape[1], x.shape[0])
-    H = _hidden_size(variant, layer_params[0])
-    xwave = x.shape[2] <= 16 and H <= 192 and g == 1       # (vg_xwave_ok of the C side: <= 3 waves of units, one group)
+    Hs = tuple(_hidden_size(variant, ps) for ps in layer_params)
+    H = Hs[0]
+    if len(set(Hs)) > 1:
+        if h0 is not None or c0 is not None or drops is not None:
+            return None     # (carried states / dropout: the LM's stacks, whose layers are alike)
+        H = Hs
+    xwave = x.shape[2] <= 16 and Hs[0] <= 192 and g == 1       # (vg_xwave_ok of the C side: <= 3 waves of units, one group)
     if mode != "1" and L == 1 and (xwave or T > 96):
         return None          # (a single layer with a narrow input already forms its x side inside the recurrent kernel; with a wide
                              #  one the x-team's per-step cost overtakes the two launches it saves at T ~ 128:
@@ -625,7 +634,7 @@ def vmlmf_stack(variant, x, layer_params, w_rank, u_ranks, g=1, time_major=False
     flat = [p for ps in layer_params for p in ps]
     hw, hb = (None, None) if head is None else head
     ops = torch_ops()
-    if ops is not None and h0 is None and c0 is None and dt == _lib.DT_F32 and drops is None:      # (initial states, the bf16 tape, dropout: the ctypes form below)
+    if ops is not None and h0 is None and c0 is None and dt == _lib.DT_F32 and drops is None and len(set(Hs)) == 1:      # (initial states, the bf16 tape, dropout, unequal sizes: the ctypes form below)
         y, hT, cT, logits = ops.stack(x, flat, L, variant, int(w_rank), list(ur), int(g), bool(time_major), hw, hb)
         out = (y, list(hT.unbind(0)), list(cT.unbind(0)))
         return out + (logits,) if head is not None else out
