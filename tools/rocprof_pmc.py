@@ -10,7 +10,7 @@ import sys
 
 OURS = ("pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "rec3_fwd_kernel", "rec3_bwd_kernel", "rec4_bwd_kernel", "reduce_cg_many_kernel", "nll_grad_kernel", "nll_finish_kernel", "embed_bwd_kernel", "adam_gate_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "wgrad_ring_kernel",
         "reduce_cg_kernel", "finish2_kernel", "finish_kernel", "adam_fused_kernel", "head_fwd_kernel", "head_bwd_kernel", "ce_fwd_kernel", "ce_bwd_kernel",
-        "adam_kernel", "wf_fwd_kernel", "wf_bwd_kernel", "pack_stack_kernel", "wgrad_mfma_stack_kernel",
+        "adam_kernel", "wf_fwd_kernel", "wf_bwd_kernel", "pack_stack_kernel", "wgrad_mfma_stack_kernel", "wgrad4_stack_kernel",
         "reduce_cg_stack_kernel", "finish_stack_kernel", "rb_fwd_kernel", "rb_bwd_kernel", "rb_pack_kernel",
         "xexp_mfma_kernel", "gemm_skinny_kernel", "rbx_fwd_kernel", "rbx_bwd_kernel", "rbx_zero_kernel", "rb_pack_stack_kernel")
 

@@ -1032,6 +1032,8 @@ namespace {
 // VMLMF_WF_BWD=0: the stack's backward chains the per-layer kernels (A/B runs and bring-up); the forward is the wavefront
 // launch either way
 const bool g_wf_bwd = env_int("VMLMF_WF_BWD", 1) != 0;
+// VMLMF_PACK_SLIM=0: the stack's pack launch produces every image of pack_kernel (A/B; the chained backward needs them anyway)
+const bool g_pack_slim = env_int("VMLMF_PACK_SLIM", 1) != 0;
 
 // (No lambdas in the initialisers of this block: this unnamed namespace is reopened INSIDE the file's extern "C" block, and hipcc numbers
 //  the lambdas of a namespace per enclosing linkage specification - "(anonymous namespace)::{lambda()#2}" here got the same mangled name
@@ -1158,6 +1160,14 @@ static int stack_plan(int L, const vmlmf_stack_layer* ly, StackPlan* out) {
         return fail(VMLMF_E_UNSUPPORTED, "stack: layers of different hidden sizes: one-group layers, fp32 tapes, equal padded ranks on both sides");
     }
   }
+  {   // the batched weight-gradient launch of these stacks holds one workgroup per CU: few enough chunks for one round (vmlmf_wgrad4.hip)
+    const int rc2 = wgrad4_chunk_rows(L, S.g, device_cus());
+    if (rc2 > 0)
+      for (int l = 0; l < L; ++l) {
+        const int TB = S.g[l].T * S.g[l].B;
+        S.g[l].RC2 = rc2, S.g[l].nchunk = (TB + rc2 - 1) / rc2;
+      }
+  }
   S.W = wf_pack_layout(S.g[0]);
   long long o = 0;
   S.flag_words = ((long long)(L > 1 ? L - 1 : 0) * S.g[0].B + 1) * WF_FLAG_STRIDE;
@@ -1223,7 +1233,7 @@ static int rbx_stack_forward(const StackPlan& S, const vmlmf_stack_layer* ly, co
     Scope sc(0, s);
     WfPack W0;
     memset(&W0, 0, sizeof(W0));
-    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s, true), "pack")) != 0) return rc;
+    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, W0, packs, nullptr, 0, nullptr, 0, s, PACK_CLUSTERED), "pack")) != 0) return rc;
     if ((rc = hip_fail(launch_rb_pack_stack(S.g[0], S.q, L, rps, imgs, fflags, s), "rb_pack")) != 0) return rc;
   }
   Scope sc(2, s);
@@ -1410,7 +1420,8 @@ int vmlmf_stack_forward(int L, const vmlmf_stack_layer* ly, const float* x, cons
     unsigned* z0 = L > 1 ? reinterpret_cast<unsigned*>(ws + S.ws_flag) : nullptr;
     unsigned* z1 = (L > 1 && training) ? reinterpret_cast<unsigned*>((float*)ly[0].reserve + S.lay[0].r_total) : nullptr;
     Scope sc(0, s);
-    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, S.W, packs, z0, (int)S.flag_words, z1, (int)S.flag_words, s), "pack")) != 0) return rc;
+    if ((rc = hip_fail(launch_pack_stack(L, S.g, rps, S.P, S.W, packs, z0, (int)S.flag_words, z1, (int)S.flag_words, s,
+                                            (g_wf_bwd && g_pack_slim) ? PACK_WAVEFRONT : PACK_ALL), "pack")) != 0) return rc;
   }
   {
     Scope sc(2, s);

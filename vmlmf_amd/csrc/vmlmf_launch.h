@@ -322,11 +322,17 @@ WfPack wf_pack_layout(const VGeo& g);
 // every layer's parameter images (pack_kernel's + the rotated ones at PACK + VPack::WF) in one launch; zero0 / zero1:
 // progress words to clear (the forward's and the backward's), or NULL
 int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const WfPack& W, float* const* pack, unsigned* zero0,
-                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, bool slim = false);   // slim: EH / EXT / BBT only
+                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, int images = 0);
+// `images`: which of pack_kernel's images the launch produces (the dot elements EH / EXI / EXT and the rotated WF region always)
+enum { PACK_ALL = 0, PACK_CLUSTERED = 1, PACK_WAVEFRONT = 2 };   // slim: EH / EXT / BBT only
 int launch_wf_fwd(const VGeo& g, const WfFwdArgs& a, hipStream_t s);
 int launch_wf_bwd(const VGeo& g, const WfBwdArgs& a, hipStream_t s);
 // the batched half of the backward of every layer of a stack, one launch each (grid.z / grid.y = layer)
 int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s);
+struct AtbStack;   // (vmlmf_atb.inc) the layers' geometry + argument blocks of a weight-gradient launch over a stack
+// vmlmf_wgrad4.hip: four interleaved column tiles per wave; -3 when the stack is outside its envelope (the caller launches wgrad_mfma_stack_kernel)
+int launch_wgrad4_stack(int L, const VGeo* g, const WghArgs* w, const AtbStack& S, hipStream_t s);
+int wgrad4_chunk_rows(int L, const VGeo* g, int cus);   // rows per chunk for a stack that kernel will take; 0: not its stack
 int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* const* cgrad, hipStream_t s,
                         const ReduceCounts* wc = nullptr);   // wc: per layer, the chunk counts of a wgrad_ring_kernel launch (or NULL)
 // wpart (+ wc, as launch_reduce_stack): finish straight from the partial blocks - no reduce launch in front (finish_from_blocks_ok layers)

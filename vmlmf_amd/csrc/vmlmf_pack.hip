@@ -62,10 +62,15 @@ __device__ __forceinline__ float dot_ex(const VGeo& g, const RefP& p, int n, int
   return p.dia_x[n] - half_wave_sum(acc);
 }
 
-// clo / chi: the copy elements [clo, chi) only (chi < 0: all of them, up to L.RB) - the clustered stacks read of this kernel's images
-// nothing but EH / EXT (dot elements) and BBT
+// PackRanges: the copy elements of up to three ranges [lo, hi) only (n == 0: all of them, up to L.RB).  The clustered stacks read of
+// this kernel's images nothing but EH / EXT (dot elements) and BBT; the wavefront launches VE, UE, UXO, VXT, BBT (and the dot elements)
+// beside their own rotated images - the rest (two thirds of the elements: the step-wise path's dense matrices, the rotated images of the
+// per-layer kernels) is not produced for them.
+struct PackRanges {
+  int n, lo[3], hi[3], pad;
+};
 __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VPack& L, const PackDots& D, const int ncopy,
-                                          float* __restrict__ out, const int bid, const int clo = 0, const int chi = -1) {
+                                          float* __restrict__ out, const int bid, const PackRanges& R = PackRanges{0, {0, 0, 0}, {0, 0, 0}, 0}) {
   const int NT = g.NT;
   if (bid >= ncopy) {   // ---- dot elements: 8 per workgroup ----
     const int l32 = threadIdx.x & 31;
@@ -106,8 +111,11 @@ __device__ __forceinline__ void pack_body(const VGeo& g, const RefP& p, const VP
   const int lane = threadIdx.x & 63;
   const int got = __builtin_amdgcn_update_dpp(0, lane, 0x121, 0xf, 0xf, true);  // row_ror:1 on lane ids
   const int sgn = (((got - lane) & 15) == 1) ? 1 : -1;
-  const int total = chi < 0 ? (int)L.RB : chi, stride = ncopy * 256;   // the RB region behind it belongs to rb_pack_kernel
-  for (int e = clo + bid * 256 + threadIdx.x; e < total; e += stride) {
+  const int stride = ncopy * 256;
+  const int n0 = R.n > 0 ? R.hi[0] - R.lo[0] : (int)L.RB;   // (the RB region behind L.RB belongs to rb_pack_kernel)
+  const int n1 = R.n > 1 ? n0 + R.hi[1] - R.lo[1] : n0, total = R.n > 2 ? n1 + R.hi[2] - R.lo[2] : n1;
+  for (int ve = bid * 256 + threadIdx.x; ve < total; ve += stride) {
+    const int e = R.n == 0 ? ve : (ve < n0 ? R.lo[0] + ve : (ve < n1 ? R.lo[1] + (ve - n0) : R.lo[2] + (ve - n1)));
     float v = 0.f;
     if (e < L.UR) {  // VE[(k*KH+rr)][slot] = vc(n,k,rr)
       const int le = e - (int)L.VE;
@@ -341,7 +349,8 @@ struct PackStackLayer {
   VPack L;
   WfPack W;
   PackDots D;
-  int ncopy, ndot, nwf, clo, chi, pad;
+  int ncopy, ndot, nwf, pad;
+  PackRanges R;
   float* out;
 };
 struct PackStackArgs {
@@ -361,12 +370,12 @@ __global__ void __launch_bounds__(256) pack_stack_kernel(PackStackArgs a) {
         for (int i = bid * 256 + (int)threadIdx.x; i < a.nzero[z]; i += nthr) a.zero[z][i] = 0u;
   }
   const int npk = ly.ncopy + ly.ndot;
-  if (bid < npk) pack_body(ly.g, ly.p, ly.L, ly.D, ly.ncopy, ly.out, bid, ly.clo, ly.chi);
+  if (bid < npk) pack_body(ly.g, ly.p, ly.L, ly.D, ly.ncopy, ly.out, bid, ly.R);
   else if (bid < npk + ly.nwf) wf_pack_body(ly.g, ly.p, ly.W, ly.out + ly.L.WF, bid - npk, ly.nwf);
 }
 
 int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const WfPack& W, float* const* pack, unsigned* zero0,
-                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, bool slim) {
+                      int nzero0, unsigned* zero1, int nzero1, hipStream_t s, int images) {
   static_assert(sizeof(PackStackArgs) <= 4096, "kernel-argument segment");
   static_assert(sizeof(PackStackLayer) % 8 == 0, "layer blocks are read as dwords at a multiple of their size");
   PackStackArgs a;
@@ -377,10 +386,21 @@ int launch_pack_stack(int L, const VGeo* g, const RefP* p, const VPack* P, const
     PackStackLayer& y = a.l[l];
     y.g = g[l], y.p = p[l], y.L = P[l], y.W = W, y.out = pack[l];
     pack_counts(g[l], P[l], y.D, y.ncopy, y.ndot);
-    y.clo = 0, y.chi = -1;
-    if (slim) {   // EH / EXT come from the dot workgroups; of the copy elements only BBT is read (vmlmf_rbx.hip)
-      y.clo = (int)P[l].BBT, y.chi = (int)P[l].UD;
-      y.ncopy = (y.chi - y.clo + 255) / 256;
+    const VPack& Q = P[l];
+    if (images == PACK_CLUSTERED) {   // EH / EXT come from the dot workgroups; of the copy elements only BBT is read (vmlmf_rbx.hip)
+      y.R.n = 1, y.R.lo[0] = (int)Q.BBT, y.R.hi[0] = (int)Q.UD;
+    } else if (images == PACK_WAVEFRONT) {   // VE | UE, the gap behind EH | UXO, the gap behind EXI | VXT, the gap behind EXT, BBT
+      // (UXP - I x KX elements between EXI and VXT - goes along: cheaper than a fourth select per element)
+      y.R.n = 3;
+      y.R.lo[0] = (int)Q.VE, y.R.hi[0] = (int)Q.UR;
+      y.R.lo[1] = (int)Q.UE, y.R.hi[1] = (int)Q.VRX;
+      y.R.lo[2] = (int)Q.UXO, y.R.hi[2] = (int)Q.UD;
+    }
+    if (y.R.n > 0) {
+      int n = 0;
+      for (int i = 0; i < y.R.n; ++i) n += y.R.hi[i] - y.R.lo[i];
+      y.ncopy = (n + 255) / 256;
+      if (y.ncopy > 2048) y.ncopy = 2048;
     }
     y.nwf = (int)((W.total + 255) / 256);
     if (y.nwf > 256) y.nwf = 256;

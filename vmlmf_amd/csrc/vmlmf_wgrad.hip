@@ -140,15 +140,10 @@ template <int NBT1, int NBT2, int NS>
 __global__ void __launch_bounds__(256 * NS) wgrad_mfma_kernel(VGeo g, AtbArgs a) {
   wgrad_body<NBT1, NBT2, NS>(g, a);
 }
-// the layers of a stack in one launch (grid.z = layer; wavefront path, vmlmf_wave.inc)
-struct AtbStack {
-  VGeo g[WF_MAXL];
-  AtbArgs a[WF_MAXL];
-};
 template <int NBT1, int NBT2, int NS>
 __global__ void __launch_bounds__(256 * NS) wgrad_mfma_stack_kernel(AtbStack S) {
   const VGeo& g = vg_karg_ref<VGeo>(offsetof(AtbStack, g) + (size_t)blockIdx.z * sizeof(VGeo));
-  const AtbArgs& a = vg_karg_ref<AtbArgs>(offsetof(AtbStack, a) + (size_t)blockIdx.z * sizeof(AtbArgs));
+  const AtbArgs a = atb_stack_args(S);
   wgrad_body<NBT1, NBT2, NS>(g, a);
 }
 
@@ -351,6 +346,10 @@ int launch_wgrad_h_stack(int L, const VGeo* g, const WghArgs* w, hipStream_t s) 
   }
   const int GK = g[0].G * g[0].KH, n1 = (vg_nb1(g[0]) + 31) / 32, n2 = (GK + 31) / 32;
   if (n1 > 2 || n2 > 2) return -3;   // (the stacks of the wavefront kernels: ranks <= 32, one group)
+  {
+    const int rc4 = launch_wgrad4_stack(L, g, w, S, s);   // four interleaved column tiles per wave (vmlmf_wgrad4.hip); -3: not this stack
+    if (rc4 != -3) return rc4;
+  }
   const dim3 grid((tasks + 3) / 4, g[0].nchunk, L);
   const int nm = n1 > n2 ? n1 : n2;
   const size_t lds = sizeof(float) * 4 * (16 * (size_t)nm + 3) * 64;
