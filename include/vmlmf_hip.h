@@ -268,8 +268,10 @@ int vmlmf_seq_backward_ex(const vmlmf_desc *d, const vmlmf_params *p, const floa
  * rank-space sums differs in the last bits).
  * Covered: 1..4 layers of V1, V2, V3, V5 or V6 (not the flat V4 layout) with equal B, T, H, ranks and layout, at most four
  * waves of hidden units (hidden_size <= 256; two groups: hidden_size / 2 <= 128), the wider of padded w_rank and (summed)
- * padded u_rank <= 24, or <= 32 with at most three waves of units, layer l > 0 with input_size == hidden_size.  Anything else: VMLMF_E_UNSUPPORTED from
- * vmlmf_stack_query() - the caller then chains the per-layer calls.
+ * padded u_rank <= 24, or <= 32 with at most three waves of units, layer l > 0 with input_size == the hidden_size of layer l - 1.
+ * Round 6: the layers may differ in hidden_size (MyLSTM builds any hidden_layer_sizes, vmlmf.py:283-292) - one-group layers with one
+ * padded rank on both sides and fp32 tapes; every layer then runs on the widest layer's thread-slot geometry.  Anything else:
+ * VMLMF_E_UNSUPPORTED from vmlmf_stack_query() - the caller then chains the per-layer calls.
  * Per layer: desc (training flag and shapes must agree across the stack), params, optional initial / final states, the
  * layer's output y (B,T,H or T,B,H; layer l's y is layer l+1's x) and its reserve (training).  Backward additionally:
  * gradients of the final states (or NULL), of the initial states (or NULL) and the parameter gradients. */
@@ -284,8 +286,8 @@ typedef struct vmlmf_stack_layer {
   float *dh0, *dc0;
   const vmlmf_grads *grads;
   const vmlmf_dropout *drop; /* ABI 12: dropout of this layer's output inside the stack's launches (vmlmf_lm.py:438-439), or NULL:
-                              * the layer above (and the caller, for the top layer) reads drop->y_dropped instead of y.  Only the
-                              * clustered form takes it (vmlmf_stack_dropout_fused) */
+                              * the layer above (and the caller, for the top layer) reads drop->y_dropped instead of y.  The clustered
+                              * form and the wavefront stacks of one-group layers take it (vmlmf_stack_dropout_fused) */
 } vmlmf_stack_layer;
 /* ABI 12 - a second form behind the same three entry points: layers too large for one CU (the PTB layers, hidden_size 650) run on
  * CLUSTERS of workgroups (vmlmf_seq_forward's row-block kernels); stacked, every layer keeps its own clusters inside ONE launch per
@@ -294,7 +296,7 @@ typedef struct vmlmf_stack_layer {
  * configuration, fp32, time-major, input_size == hidden_size for every layer, w_rank 17..32, as long as the clusters of all layers
  * are co-resident (L x ceil(B / rows) x 16 workgroups <= the device's CUs: up to 128 rows for two layers).  vmlmf_stack_query()
  * returns VMLMF_E_UNSUPPORTED otherwise.  No classifier head on this form. */
-/* 1: the layers' `drop` fields are honoured by this stack (the clustered form) */
+/* 1: the layers' `drop` fields are honoured by this stack (the clustered form; wavefront stacks of one-group layers) */
 int vmlmf_stack_dropout_fused(int L, const vmlmf_stack_layer *layers);
 /* sizes for the stack: reserve_bytes[l] per layer, one workspace for either direction */
 int vmlmf_stack_query(int L, const vmlmf_stack_layer *layers, size_t *reserve_bytes, size_t *workspace_bytes);

@@ -4,7 +4,7 @@
 # bench line, strong-scaling points on one GPU, every BASELINE config, LM steps, config E data-parallel lines (1 rank + 2-rank rehearsals),
 # rocprofv3 kernel stats of the headline / 256 rows / config C / config E layer / the clustered stack at 32 rows / LM steps, and the
 # PMC passes (SQ counters in two passes, FETCH_SIZE, WRITE_SIZE - each its own run, --kernel-trace only) for config A, 256 rows and
-# the config E kernels (clustered stack at 32 rows + the single layer at 256 rows).
+# config C and the config E kernels (clustered stack at 32 rows + the single layer at 256 rows).
 RN=${1:-r06}
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
@@ -44,6 +44,7 @@ pmc4 "" "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --n
 B256="python3 $R/bench.py --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extra"
 pmc4 "_b256" "python3 bench.py --global-batch 256 --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extra; 256 rows on one GPU (rec_fwd_kernel, rec4_bwd_kernel), $RN" $B256
 pmc4 "_config_e" "python3 tools/probes/run_e.py --nograph; one PTB group layer, B=256 T=35 (rb_fwd_kernel / rb_bwd_kernel on clusters of 16), $RN" python3 $R/tools/probes/run_e.py --nograph
+pmc4 "_config_c" "python3 tools/probes/run_c.py; config C (2 x 256, rank 24, B 128, T 24, fp32: wf_fwd_kernel / wf_bwd_kernel / wgrad4_stack_kernel), $RN" python3 $R/tools/probes/run_c.py
 pmc4 "_config_e_stack32" "python3 tools/probes/rbx_probe.py 32 --stacked-only; two PTB group layers at 32 rows in one launch per direction (rbx_fwd_kernel / rbx_bwd_kernel), $RN" python3 $R/tools/probes/rbx_probe.py 32 --stacked-only
 
 ks ks ${RN}_kernel_stats.csv "bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extra (config A; eager region + hipGraph replays + untimed breakdown pass), $RN: rocprofv3 --kernel-trace --stats" python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-extra
