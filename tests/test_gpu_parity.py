@@ -115,6 +115,8 @@ CASES = [
     (O.V3, 6, 5, 24, 24, 4, [6], True, True),
     (O.V4, 9, 4, 20, 20, 3, [4, 2], True, True),     # batch != 40 (the reference cannot run this)
     (O.V4, 40, 3, 72, 72, 8, [16, 16], True, True),
+    (O.V4, 63, 31, 10, 10, 9, [11, 4], False, False),  # a flat layer small enough for the x-fold (its backward was refused since round 5's pruning: found by tools/fuzz_parity.py, round 6)
+    (O.V4, 51, 35, 8, 8, 14, [5, 12], False, True),
     # 257..512 thread slots: the 8-wave instantiations of the persistent kernels
     (O.V1, 4, 5, 20, 300, 8, [16], False, True),     # 5 compute waves
     (O.V1, 3, 3, 9, 500, 16, [32], False, False),    # 8 compute waves, rank 32

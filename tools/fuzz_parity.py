@@ -92,12 +92,13 @@ def run_stack(c):
     """L like layers: vmlmf_stack on the GPU, the literal layers chained on the CPU (float64)."""
     r = np.random.Generator(np.random.PCG64(c["seed"]))
     v, L, B, T, I, H = c["v"], c["L"], c["B"], c["T"], c["I"], c["H"]
-    Ps = [O.make_params(v, I if l == 0 else H, H, c["rw"], c["ru"], seed=c["seed"] % 1000 + l) for l in range(L)]
+    Hs = c.get("Hs") or [H] * L          # (round 6: the layers of a stack may differ in hidden size; no initial states then)
+    Ps = [O.make_params(v, I if l == 0 else Hs[l - 1], Hs[l], c["rw"], c["ru"], seed=c["seed"] % 1000 + l) for l in range(L)]
     shp = (T, B, I) if c["tm"] else (B, T, I)
     x = r.standard_normal(shp).astype(np.float32)
-    dy = r.standard_normal(shp[:2] + (H,)).astype(np.float32)
+    dy = r.standard_normal(shp[:2] + (Hs[-1],)).astype(np.float32)
     st = None
-    if c["states"]:
+    if c["states"] and len(set(Hs)) == 1:
         st = [(0.5 * r.standard_normal((L, B, H))).astype(np.float32) for _ in range(2)]
     names = ORDER[v]
     rw, ru, g = ranks_of(v, Ps[0])
@@ -110,7 +111,7 @@ def run_stack(c):
     if out is None:
         raise NotCovered()
     y, hTs, cTs = out[:3]
-    dhT = r.standard_normal((L, B, H)).astype(np.float32)
+    dhT = [r.standard_normal((B, Hs[l])).astype(np.float32) for l in range(L)]
     loss = (y * torch.tensor(dy, device="cuda")).sum()
     for l in range(L):
         loss = loss + (hTs[l] * torch.tensor(dhT[l], device="cuda")).sum()
@@ -158,6 +159,11 @@ def draw_stack():
     else:
         c["I"] = min(c["I"], c["H"])
     c["B"], c["T"] = min(c["B"], 128), min(c["T"], 30)
+    if c["v"] in (O.V1, O.V5) and rng.random() < 0.35:      # growing hidden sizes (a VMLMF cell needs input_size <= hidden_size)
+        hs = sorted(int(min(256, max(c["I"] if c["v"] == O.V1 else 2, pick(2, 256, 0.2)))) for _ in range(c["L"]))
+        c["Hs"], c["H"] = hs, hs[0]
+        if c["v"] == O.V1:
+            c["I"] = min(c["I"], hs[0])
     return c
 
 
