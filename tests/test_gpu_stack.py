@@ -436,6 +436,45 @@ def test_stack_backward_switch_chains_the_per_layer_kernels():
         assert abs(a - b) <= 1e-4 * abs(b) + 1e-6
 
 
+def test_one_finishing_launch_against_the_two_it_replaces(tmp_path):
+    """finish_units_stack_kernel (round 6: a workgroup per hidden unit sums that unit's partial sums once - every accumulator's blocks in
+    reduce_cg_stack_kernel's order - and finishes its gradient entries with finish_body) against reduce_cg_stack_kernel + finish_stack_kernel
+    (VMLMF_FINISH_UNITS=0, read when the library loads): the block sums run in the same order and the finishing arithmetic is the same
+    function - every gradient, the classifier's too, bit for bit.  Three stacks: config C's shape through Net, layers of different sizes, the per-gate layout of MyLSTMCell."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys; sys.path[:0] = [%r]\n"
+        "import torch, vmlmf_amd\n"
+        "out = []\n"
+        "torch.manual_seed(5)\n"
+        "net = vmlmf_amd.Net(77, layer_sizes=[256, 256], w_rank=24, u_rank=[24], model=vmlmf_amd.MyLSTM, cell=vmlmf_amd.MyVMLMFCell).cuda()\n"
+        "x = torch.randn(128, 24, 77, device='cuda'); t = torch.randint(0, 18, (128,), device='cuda')\n"
+        "vmlmf_amd.cross_entropy(net(x), t).backward(); out += [p.grad.cpu() for p in net.parameters() if p.grad is not None]\n"
+        "m = vmlmf_amd.MyLSTM(20, hidden_layer_sizes=[64, 100, 180], batch_first=True, w_rank=16, u_ranks=16, cell=vmlmf_amd.MyVMLMFCell).cuda()\n"
+        "x = torch.randn(6, 7, 20, device='cuda', requires_grad=True)\n"
+        "y, h = m(x); (y.square().sum() + h.sum()).backward(); out += [p.grad.cpu() for p in m.parameters()] + [x.grad.cpu()]\n"
+        "m = vmlmf_amd.MyLSTM(24, hidden_layer_sizes=[72, 72], batch_first=True, w_rank=16, u_ranks=16, cell=vmlmf_amd.MyLSTMCell).cuda()\n"
+        "x = torch.randn(8, 5, 24, device='cuda', requires_grad=True)\n"
+        "y, h = m(x); (y.square().sum() + h.sum()).backward(); out += [p.grad.cpu() for p in m.parameters() if p.grad is not None] + [x.grad.cpu()]\n"
+        "torch.save(out, sys.argv[1])\n"
+    ) % (os.path.dirname(here),)
+    got = {}
+    for sw in ("1", "0"):
+        env = dict(os.environ)
+        env["VMLMF_STACK"] = "1"
+        env["VMLMF_FINISH_UNITS"] = sw
+        path = str(tmp_path / ("grads%s.pt" % sw))
+        r = subprocess.run([sys.executable, "-c", code, path], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got[sw] = torch.load(path)
+    assert len(got["1"]) == len(got["0"]) and len(got["1"]) > 30
+    for i, (a, b) in enumerate(zip(got["1"], got["0"])):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert torch.equal(a, b), i
+
+
 @pytest.mark.parametrize("variant_name,time_major", [("V1", False), ("V3", True), ("V5", False), ("V2", False), ("V6", False)])
 def test_stack_with_initial_states_against_the_fp64_oracle(variant_name, time_major):
     """The stack entry points with everything the per-layer calls take - initial states of every layer, gradients into

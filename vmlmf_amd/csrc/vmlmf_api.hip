@@ -1037,6 +1037,9 @@ namespace {
 const bool g_wf_bwd = env_int("VMLMF_WF_BWD", 1) != 0;
 // VMLMF_PACK_SLIM=0: the stack's pack launch produces every image of pack_kernel (A/B; the chained backward needs them anyway)
 const bool g_pack_slim = env_int("VMLMF_PACK_SLIM", 1) != 0;
+// VMLMF_FINISH_UNITS=0: behind a stack's weight-gradient launch, reduce_cg_stack_kernel + finish_stack_kernel instead of the one
+// finishing launch (A/B)
+const bool g_finish_units = env_int("VMLMF_FINISH_UNITS", 1) != 0;
 
 // (No lambdas in the initialisers of this block: this unnamed namespace is reopened INSIDE the file's extern "C" block, and hipcc numbers
 //  the lambdas of a namespace per enclosing linkage specification - "(anonymous namespace)::{lambda()#2}" here got the same mangled name
@@ -1336,6 +1339,14 @@ static int rbx_stack_backward(const StackPlan& S, const vmlmf_stack_layer* ly, c
     og.b_h = gr->b_h, og.u_h0 = gr->u_h[0], og.u_h1 = gr->u_h[1], og.v_h0 = gr->v_h[0], og.v_h1 = gr->v_h[1];
     for (int k = 0; k < 4; ++k) og.wg[k] = gr->w_gate[k], og.ug[k] = gr->u_gate[k], og.bg[k] = gr->b_gate[k];
   }
+  {   // one finishing launch where it covers the layers (one-group layers: the plain rank-32 PTB layers)
+    bool fu = g_finish_units;
+    for (int l = 0; l < L; ++l) fu = fu && finish_units_ok(S.g[l]);
+    if (fu) {
+      Scope sc(7, s);
+      return hip_fail(launch_finish_units_stack(L, S.g, rps, ogs, hb, s, health_word(s), wparts, wcs), "finish");
+    }
+  }
   if (g_ffb != 0 && finish_from_blocks_ok(S.g[0])) {   // the finishing launch sums the (few) partial blocks itself
     Scope sc(7, s);
     return hip_fail(launch_finish_stack(L, S.g, rps, ccgs, ogs, hb, s, health_word(s), wparts, wcs), "finish");
@@ -1526,6 +1537,14 @@ int vmlmf_stack_backward(int L, const vmlmf_stack_layer* ly, const float* x, con
     {
       Scope sc(5, s);
       if ((rc = hip_fail(launch_wgrad_h_stack(L, S.g, wh, s), "wgrad")) != 0) return rc;
+    }
+    {   // one finishing launch: a workgroup per hidden unit sums that unit's partial sums once and finishes its gradient entries
+      bool fu = g_finish_units;
+      for (int l = 0; l < L; ++l) fu = fu && finish_units_ok(S.g[l]);
+      if (fu) {
+        Scope sc(7, s);
+        return hip_fail(launch_finish_units_stack(L, S.g, rps, ogs, hb_top, s, health_word(s), wparts, nullptr), "finish");
+      }
     }
     bool ffb = g_ffb > 0;   // (wavefront stacks: 48 - 64 blocks per layer; on only when asked for - measured: DESIGN.md)
     for (int l = 0; l < L; ++l) ffb = ffb && finish_from_blocks_ok(S.g[l]);

@@ -339,7 +339,11 @@ int launch_reduce_stack(int L, const VGeo* g, const float* const* wpart, float* 
 bool finish_from_blocks_ok(const VGeo& g);
 int launch_finish_stack(int L, const VGeo* g, const RefP* p, const float* const* cgrad, const RefG* out, const HeadBwd& hd_top,
                         hipStream_t s, unsigned* health = nullptr, const float* const* wpart = nullptr,
-                        const ReduceCounts* wc = nullptr);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
+                        const ReduceCounts* wc = nullptr);
+// reduce_cg_stack_kernel + finish_stack_kernel as one launch (a workgroup per hidden unit: vmlmf_pack.hip); -3: not for these layers
+bool finish_units_ok(const VGeo& g);
+int launch_finish_units_stack(int L, const VGeo* g, const RefP* p, const RefG* out, const HeadBwd& hd_top, hipStream_t s,
+                              unsigned* health, const float* const* wpart, const ReduceCounts* wc);   // hd_top: classifier gradients ride with the top layer (C = 0: none)
 
 // register budget of the persistent kernels: which (KH, NT) pairs are instantiated
 bool rec_supported(const VGeo& g);

@@ -751,13 +751,14 @@ __device__ __forceinline__ void finish_head(const VGeo& g, const HeadBwd& hd, co
 // Element (accumulator a, unit n) of the canonical gradients straight from the weight-gradient kernels' partial blocks: the inverse of
 // reduce_cg_scatter (vmlmf_wgrad.hip) and the same fixed-order sum over the blocks (vg_block_sum) - reduce_cg_kernel and finish_kernel
 // as ONE launch for the stacks, whose block counts are small (round 6).  Layers with I <= H and without the x-fold.
-__device__ __forceinline__ float finish_cg_from_blocks(const VGeo& g, const float* __restrict__ P, const ReduceCounts& wc, int a, const int n) {
+// where accumulator a of unit n sits inside a partial block, and how many blocks hold it
+__device__ __forceinline__ long long finish_cg_locate(const VGeo& g, const ReduceCounts& wc, int a, const int n, int& cnt) {
   const int KX = g.KX, KH = g.KH, GK = g.G * KH, NT = g.NT, slot = vg_slot(g, n);
   const int MT2 = (g.H + 31) / 32, MT3 = (g.I + 31) / 32;
   const int NB1p = (vg_nb1(g) + 31) / 32 * 32, NB2p = (GK + 31) / 32 * 32, NB3p = (KX + 31) / 32 * 32;
   const long long o2 = (long long)NT * 4 * NB1p, o3 = o2 + (long long)MT2 * 32 * NB2p, oe = o3 + (long long)MT3 * 32 * NB3p;
   long long e;
-  int cnt = wc.c[0] == 0 ? g.nchunk : wc.c[0];
+  cnt = wc.c[0] == 0 ? g.nchunk : wc.c[0];
   if (a < 4 * KX) {                 // va_vx(k, j)
     const int k = a / KX, j = a - k * KX;
     e = (long long)(slot * 4 + k) * NB1p + j;
@@ -775,26 +776,37 @@ __device__ __forceinline__ float finish_cg_from_blocks(const VGeo& g, const floa
     a -= KX;
     e = oe + (long long)(a >> 2) * NT * 4 + slot * 4 + (a & 3);
   }
+  return e;
+}
+__device__ __forceinline__ float finish_cg_from_blocks(const VGeo& g, const float* __restrict__ P, const ReduceCounts& wc, int a, const int n) {
+  int cnt;
+  const long long e = finish_cg_locate(g, wc, a, n, cnt);
   return vg_block_sum(P, g.PCH, e, 0, cnt);
 }
 
+// cgu / e_in (finish_units_stack_kernel): the canonical gradients of ONE unit, [accumulator], summed over the blocks into LDS by the
+// caller, and the element to finish (an element of that unit); by default the element is the thread's global index
 __device__ __forceinline__ void finish_body(const VGeo& g, const RefP& p, const float* __restrict__ cg, const RefG& o, const HeadBwd& hd,
                                             const long long nbody, unsigned* health, const float* __restrict__ P = nullptr,
-                                            const ReduceCounts wc = ReduceCounts{{0, 0, 0}}) {
+                                            const ReduceCounts wc = ReduceCounts{{0, 0, 0}}, const float* cgu = nullptr,
+                                            const long long e_in = -1) {
   const int NT = g.NT, H = g.H, I = g.I, rw = g.rw, Hg = g.Hg;
   auto put = [&](float* dst, float v) { finish_put(dst, v, health); };
+  const long long e_lin = e_in >= 0 ? e_in : (long long)blockIdx.x * blockDim.x + threadIdx.x;
   {
-    const long long th = (long long)blockIdx.x * blockDim.x + threadIdx.x - nbody;
+    const long long th = e_lin - nbody;
     if (th >= 0) {
       finish_head(g, hd, th, health);
       return;
     }
   }
-  auto CG = [&](int a, int n) { return P != nullptr ? finish_cg_from_blocks(g, P, wc, a, n) : cg[(size_t)a * NT + vg_slot(g, n)]; };
+  auto CG = [&](int a, int n) {
+    return cgu != nullptr ? cgu[a] : (P != nullptr ? finish_cg_from_blocks(g, P, wc, a, n) : cg[(size_t)a * NT + vg_slot(g, n)]);
+  };
   const long long n_ux = (long long)I * rw, n_vx = 4LL * H * rw, n_dx = I, n_dh = H, n_b = 4LL * H;
   const long long n_uh0 = (long long)H * g.ru0, n_vh0 = 4LL * H * g.ru0;
   const long long n_uh1 = g.G == 2 ? (long long)H * g.ru1 : 0, n_vh1 = g.G == 2 ? 4LL * H * g.ru1 : 0;
-  long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long e = e_lin;
   if (g.foldx) {
     // x-fold: the accumulator rows va_vx(k, m), m < I, hold G[k][m](n) = sum_rows dpre[row][n][k] x[row][m].
     // du_x[m][r] = sum_{n,k} G[k][m](n) vx(n,k,r) - ...: one wave per element, fixed-order butterfly
@@ -1061,6 +1073,87 @@ __global__ void __launch_bounds__(256) finish_stack_kernel(FinishStack S) {   //
   const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
   if ((long long)blockIdx.x * 256 >= f.nbody && f.hd.C <= 0) return;
   finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody, vg_karg_ref<unsigned*>(offsetof(FinishStack, health)), f.P, f.wc);
+}
+
+static long long finish_elements(const VGeo& g);
+// ---------------------------------------------------------------------------------------------------
+// finish_units_stack_kernel (round 6): reduce_cg_stack_kernel + finish_stack_kernel as ONE launch.  A workgroup takes ONE hidden unit
+// of one layer: its NA canonical gradients (5 KX + 5 KH + 12 accumulators) are summed over the partial blocks - one accumulator per
+// thread, vg_block_sum's order: the bits of the two-launch path - into LDS, then every reference-layout gradient entry of that unit
+// (d(u_x) row n, the four d(v_x) and d(v_h) rows, d(u_h) row n, the biases, d(dia)) is one thread's finish_body() on those values.
+// (The first fused form - finish_stack_kernel reading the blocks itself, vmlmf_tune("ffb") - sums d(ex) / d(eh) once per rank: 25.5
+// us against 8.1 + 6.2.)  One-group layers without the x-fold, input_size <= hidden_size.  Workgroups behind the widest layer's
+// units: the classifier's gradients (top layer).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long finish_unit_element(const VGeo& g, const int n, int j) {
+  const int H = g.H, I = g.I, rw = g.rw, ru = g.ru0;
+  const long long n_ux = (long long)I * rw, n_vx = 4LL * H * rw, n_dx = I, n_dh = H, n_b = 4LL * H, n_uh0 = (long long)H * ru;
+  if (j < rw) return n < I ? (long long)n * rw + j : -1;                                   // d(u_x)[n][r]
+  j -= rw;
+  if (j < 4 * rw) {                                                                          // d(v_x): chunk / gate c, rank r
+    const int c = j / rw, r = j - c * rw;
+    return n_ux + (g.pergate ? ((long long)c * rw + r) * H + n : ((long long)c * H + n) * rw + r);
+  }
+  j -= 4 * rw;
+  if (j == 0) return n < I ? n_ux + n_vx + n : -1;                                           // d(dia_x)
+  if (j == 1) return n_ux + n_vx + n_dx + n;                                                 // d(dia_h)
+  j -= 2;
+  if (j < 4) return n_ux + n_vx + n_dx + n_dh + (long long)j * H + n;                        // biases of gate j
+  j -= 4;
+  const long long b0 = n_ux + n_vx + n_dx + n_dh + n_b;
+  if (j < ru) return b0 + (long long)n * ru + j;                                             // d(u_h)[n][r]
+  j -= ru;
+  if (j < 4 * ru) {
+    const int c = j / ru, r = j - c * ru;
+    return b0 + n_uh0 + (g.pergate ? ((long long)c * ru + r) * H + n : ((long long)c * H + n) * ru + r);
+  }
+  return -1;
+}
+constexpr int FU_T = 256;
+__global__ void __launch_bounds__(FU_T) finish_units_stack_kernel(FinishStack S, int hmax) {
+  __shared__ float cgs[5 * 32 + 5 * 32 + 12];
+  const FinishLayer& f = vg_karg_ref<FinishLayer>((size_t)blockIdx.y * sizeof(FinishLayer));
+  unsigned* health = vg_karg_ref<unsigned*>(offsetof(FinishStack, health));
+  const int n = (int)blockIdx.x, tid = (int)threadIdx.x;
+  if (n >= hmax) {   // the classifier's elements
+    if (f.hd.C > 0) finish_body(f.g, f.p, f.cg, f.o, f.hd, f.nbody, health, nullptr, ReduceCounts{{0, 0, 0}}, nullptr,
+                                f.nbody + (long long)(n - hmax) * FU_T + tid);
+    return;
+  }
+  if (n >= f.g.H) return;
+  // (one thread per accumulator, the blocks in reduce_cg_stack_kernel's order.  Measured at config C: 14.3 us against 8.2 + 7.3 for
+  //  the two launches it replaces; with every accumulator's blocks in four runs on four threads - 1024 threads a unit - 15.9: the
+  //  launch is not bound by the chain of a thread's loads but by reading 27 MB of partial blocks in 1 KB pieces)
+  const int NA = f.g.NA;
+  for (int a = tid; a < NA; a += FU_T) cgs[a] = finish_cg_from_blocks(f.g, f.P, f.wc, a, n);
+  __syncthreads();
+  const int nout = 5 * f.g.rw + 5 * f.g.ru0 + 6;
+  for (int j = tid; j < nout; j += FU_T) {
+    const long long e = finish_unit_element(f.g, n, j);
+    if (e >= 0) finish_body(f.g, f.p, f.cg, f.o, HeadBwd{}, f.nbody, health, nullptr, ReduceCounts{{0, 0, 0}}, cgs, e);
+  }
+}
+bool finish_units_ok(const VGeo& g) { return g.G == 1 && !g.foldx && g.I <= g.H && g.NA <= 332; }
+int launch_finish_units_stack(int L, const VGeo* g, const RefP* p, const RefG* out, const HeadBwd& hd_top, hipStream_t s,
+                              unsigned* health, const float* const* wpart, const ReduceCounts* wc) {
+  FinishStack S;
+  memset(&S, 0, sizeof(S));
+  S.health = health;
+  int hmax = 0;
+  long long nhead = 0;
+  for (int l = 0; l < L; ++l) {
+    if (!finish_units_ok(g[l])) return -3;
+    S.l[l].g = g[l], S.l[l].p = p[l], S.l[l].o = out[l], S.l[l].cg = nullptr, S.l[l].nbody = finish_elements(g[l]);
+    S.l[l].P = wpart[l];
+    if (wc != nullptr) S.l[l].wc = wc[l];
+    hmax = g[l].H > hmax ? g[l].H : hmax;
+    if (l == L - 1 && hd_top.C > 0) {
+      S.l[l].hd = hd_top;
+      nhead = 16 * ((long long)hd_top.C * g[l].H + hd_top.C);   // sixteen lanes per classifier output
+    }
+  }
+  hipLaunchKernelGGL(finish_units_stack_kernel, dim3((unsigned)(hmax + (nhead + FU_T - 1) / FU_T), L), dim3(FU_T), 0, s, S, hmax);
+  return (int)hipGetLastError();
 }
 
 static long long finish_elements(const VGeo& g) {
