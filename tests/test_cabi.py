@@ -197,8 +197,8 @@ def test_the_product_library_stays_pruned():
     import subprocess
     size = os.path.getsize(_lib.LIB_PATH)
     # (round 5: 8.92 MB; round 6 adds the clustered-stack kernels - rbx_fwd / rbx_bwd for the PTB group and plain layers, the stack-wide
-    #  pack and zero launches: + 0.2 MB of product code)
-    assert size < 9_300_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
+    #  pack and zero launches: + 0.2 MB of product code; wgrad4_stack_kernel's two instantiations and the one-launch finish: + 0.15 MB)
+    assert size < 9_400_000, f"libvmlmf_hip.so is {size / 1e6:.2f} MB"
     out = subprocess.run(["strings", "-n", "12", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "VMLMF_R4_ABL" not in out and "VMLMF_WRIDE_DRY" not in out
 
