@@ -377,7 +377,7 @@ def main():
                          "--batch-per-gpu say otherwise; its line is NOT the graded metric")
     ap.add_argument("--batch-per-gpu", type=int, default=0, help="config E: weak scaling with this many rows per GPU")
     ap.add_argument("--plain-layers", action="store_true", help="config E: MyVMLSTM layers instead of MyVMLSTMGroup")
-    ap.add_argument("--transport", choices=("auto", "cabi", "torch"), default="auto",
+    ap.add_argument("--transport", choices=("auto", "cabi", "torch", "p2p"), default="auto",
                     help="gradient all-reduce through the C ABI (vmlmf_flat_allreduce_group, RCCL) or torch.distributed "
                          "(backend nccl = RCCL).  auto: torch.distributed with more than one rank (the C-ABI communicator has "
                          "only ever run in a group of one: no multi-GPU box was available to the builder), the C ABI in the "

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VMLMF_ABI_VERSION 12
+#define VMLMF_ABI_VERSION 13
 #define VMLMF_MAX_G 2
 
 /* cell variants */
@@ -483,6 +483,29 @@ int vmlmf_comm_count(void *comm, int *ranks);
 int vmlmf_comm_destroy(void *comm);
 int vmlmf_flat_allreduce(void *buf, size_t n, int op, void *comm, void *stream);
 int vmlmf_flat_allreduce_group(int nbuf, void *const *bufs, const size_t *counts, int op, void *comm, void *stream);
+
+/*
+ * ABI 13.  One-shot peer-to-peer all-reduce of a SMALL flat fp32 buffer - the HAR network's 121 KiB of gradients between
+ * loss.backward() and optimizer.step() (train.py:64-65) - without a collective library: every rank writes
+ * its buffer into a slot of every peer's staging area (hipIpc-mapped device memory, one xGMI hop, all peers at once), raises one
+ * epoch word per peer, then sums the `world` slots of its own staging area in rank order (the same bits on every rank).  Two
+ * launches on the caller's stream (capturable: the epoch lives in device memory), no host work per step.
+ *   vmlmf_p2p_create    allocates this rank's staging area for buffers of up to max_floats floats (<= 4 Mi) and returns its IPC
+ *                       handle (VMLMF_P2P_HANDLE_BYTES); the caller carries the handles of all ranks to every rank (e.g. an
+ *                       all-gather over torch.distributed / MPI; rank order) and calls
+ *   vmlmf_p2p_connect   handles = world x VMLMF_P2P_HANDLE_BYTES bytes
+ *   vmlmf_p2p_allreduce in place, op VMLMF_SUM / VMLMF_AVG; buf 16-byte aligned, n <= max_floats.  Every rank must call it the same
+ *                       number of times.  A peer that never arrives (bounded wait) leaves NaN in buf and the next forward / backward
+ *                       entry point returns VMLMF_E_PROTOCOL.
+ * At most VMLMF_P2P_MAX_RANKS ranks (one node).  Exercised on hardware only with two processes on ONE device (one GPU per lease):
+ * RCCL (vmlmf_flat_allreduce*) stays the default transport of the package.
+ */
+#define VMLMF_P2P_HANDLE_BYTES 64
+#define VMLMF_P2P_MAX_RANKS 8
+int vmlmf_p2p_create(void **p2p, int rank, int world, size_t max_floats, unsigned char *handle_out);
+int vmlmf_p2p_connect(void *p2p, const unsigned char *handles);
+int vmlmf_p2p_allreduce(void *p2p, float *buf, size_t n, int op, void *stream);
+int vmlmf_p2p_destroy(void *p2p);
 
 /*
  * Instrumentation for bench.py (roofline leg).  vmlmf_profile_enable(mask): every launch of internal kernel

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "vmlmf_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(vmlmf_[a-z_]+)\s*\(", text)
+    names = re.findall(r"\b(vmlmf_[a-z0-9_]+)\s*\(", text)
     return sorted(set(names))
 
 
@@ -30,7 +30,7 @@ def test_library_loads_and_exports_every_symbol():
     for name in declared_functions():
         assert hasattr(handle, name), f"missing export {name}"
     lib = _lib.lib()
-    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 12
+    assert lib.vmlmf_abi_version() == _lib.ABI_VERSION == 13
     assert b"gfx950" in lib.vmlmf_build_info()
     assert [lib.vmlmf_kernel_name(k).decode() for k in range(_lib.NKERNELS)] == [
         "pack_kernel", "xproj_kernel", "rec_fwd_kernel", "rec_bwd_kernel", "dqx_dx_kernel", "wgrad_mfma_kernel", "reduce_cg_kernel",
@@ -158,6 +158,23 @@ def test_stack_query_host_logic():
     assert query(2, 8, 5, 20, 64, 8, 8, variant=_lib.V2_GROUP_CELL, g=2, H_upper=72, I_upper=64)[0] == _lib.E_UNSUPPORTED   # ... one group
     assert query(2, 8, 5, 20, 64, 8, 8, I_upper=48)[0] == _lib.E_SHAPE                # layer 1 does not read layer 0's width
     assert b"stack" in lib.vmlmf_last_error()
+
+
+def test_p2p_entry_points_validate_their_arguments():
+    """vmlmf_p2p_* (ABI 13; host-only part): rank / world / size limits are refused before anything touches a device, and the
+    entry points that take a handle refuse NULL."""
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    buf = (ctypes.c_ubyte * _lib.P2P_HANDLE_BYTES)()
+    assert lib.vmlmf_p2p_create(ctypes.byref(h), 0, _lib.P2P_MAX_RANKS + 1, 1000, buf) == _lib.E_BADARG
+    assert lib.vmlmf_p2p_create(ctypes.byref(h), 2, 2, 1000, buf) == _lib.E_BADARG            # rank >= world
+    assert lib.vmlmf_p2p_create(ctypes.byref(h), 0, 2, 0, buf) == _lib.E_UNSUPPORTED
+    assert lib.vmlmf_p2p_create(ctypes.byref(h), 0, 2, (1 << 22) + 1, buf) == _lib.E_UNSUPPORTED   # RCCL's job
+    assert b"small" in lib.vmlmf_last_error()
+    assert lib.vmlmf_p2p_create(None, 0, 2, 1000, buf) == _lib.E_BADARG
+    assert lib.vmlmf_p2p_connect(None, buf) == _lib.E_BADARG
+    assert lib.vmlmf_p2p_allreduce(None, None, 4, _lib.SUM, None) == _lib.E_BADARG
+    assert lib.vmlmf_p2p_destroy(None) == 0
 
 
 def test_every_documented_kernel_switch_is_accepted():

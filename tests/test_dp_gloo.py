@@ -49,7 +49,7 @@ class TiledToy(Toy):
         return torch.tanh(_FlatGradAffine.apply(x, self.a, self.b))
 
 
-def _worker(rank, world, port, op, out, tiled=False):
+def _worker(rank, world, port, op, out, tiled=False, transport="torch"):
     sys.path.insert(0, ROOT)
     from vmlmf_amd.dp import FlatGradAllReduce, broadcast_parameters, shard_batch
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
@@ -64,21 +64,22 @@ def _worker(rank, world, port, op, out, tiled=False):
     y = m(xs)
     loss = y.mean(dim=1).mean() if op == "avg" else y.mean(dim=1).sum()
     loss.backward()
-    red = FlatGradAllReduce(m.parameters(), op=op)
+    red = FlatGradAllReduce(m.parameters(), op=op, transport=transport)
     in_place = [flat is not None for flat, _ in red._spans([p.grad for p in m.parameters() if p.grad is not None])]
     red.reduce()
     if rank == 0:
         torch.save({"a": m.a.grad.clone(), "b": m.b.grad.clone(), "n": red.numel(), "a0": m.a.detach(),
                     "in_place": in_place, "staged": red.flat is not None, "collectives": red.last_collectives,
-                    "ranks": red.rccl_ranks()}, out)
+                    "ranks": red.rccl_ranks(), "transport": red.transport_used()}, out)
     dist.destroy_process_group()
 
 
-def _run(op, tmp_path, tiled=False):
+def _run(op, tmp_path, tiled=False, transport="torch"):
     out = str(tmp_path / f"dp_{op}_{int(tiled)}.pt")
-    port = 29500 + (os.getpid() % 2000) + (7 if tiled else 0)
-    mp.spawn(_worker, args=(2, port, op, out, tiled), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + (7 if tiled else 0) + (13 if transport != "torch" else 0)
+    mp.spawn(_worker, args=(2, port, op, out, tiled, transport), nprocs=2, join=True)
     got = torch.load(out)
+    assert got["transport"].startswith("torch.distributed:gloo")   # (CPU tensors: "p2p" / "cabi" fall back to the process group, on every rank alike)
     assert got["collectives"] == 1 and got["ranks"] == 2          # ONE all-reduce per step, over both ranks
     if tiled:      # both gradients live in one allocation (as a VMLMF layer's and its classifier's do): reduced where they are
         assert got["in_place"] == [True] and not got["staged"]
@@ -106,6 +107,12 @@ def test_sum_matches_global_batch_sum_loss(tmp_path):
 def test_gradients_sharing_a_flat_allocation_are_reduced_in_place(tmp_path):
     _run("avg", tmp_path, tiled=True)
     _run("sum", tmp_path, tiled=True)
+
+
+def test_the_peer_to_peer_transport_falls_back_on_cpu_tensors(tmp_path):
+    """FlatGradAllReduce(transport="p2p") (ABI 13: hipIpc staging areas) with CPU gradients: the exchange runs on the process group,
+    decided the same way on every rank - same results as the default transport."""
+    _run("avg", tmp_path, tiled=True, transport="p2p")
 
 
 def test_shard_batch_is_a_contiguous_partition():

@@ -65,6 +65,43 @@ def test_two_ranks_walk_the_lm_network_of_configs4():
     assert 8.0 < j["loss_per_token"] < 10.5                         # ln(10000) = 9.21 at random initialisation
 
 
+def test_two_processes_exchange_over_the_peer_to_peer_path():
+    """vmlmf_p2p_* (ABI 13; SURVEY section 8e: the one-shot exchange for the HAR network's 121 KiB of gradients, train.py:64-65):
+    two processes on this box's ONE GPU map each other's staging areas over hipIpc, write their buffers into them and sum in rank
+    order - every exchange bit-equal to the same buffers reduced over gloo, for buffer sizes that are no multiple of four, both
+    parities of the staging area, SUM and AVG, and through vmlmf_amd.dp.FlatGradAllReduce(transport="p2p")."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "LOCAL_WORLD_SIZE")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE="2", HSA_ENABLE_IPC_MODE_LEGACY="0", VMLMF_WRIDE="1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "p2p_worker.py")], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = []
+    try:
+        for p in procs:
+            outs.append(p.communicate(timeout=600))
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p, (out, err) in zip(procs, outs):
+        assert p.returncode == 0 and "P2P-OK 8" in out, out[-1000:] + err[-3000:]
+
+
+def test_two_ranks_walk_the_headline_bench_over_the_peer_to_peer_transport():
+    """`python bench.py --gpus 2 --transport p2p` (rehearsal: both ranks on GPU 0): the step's one exchange runs through vmlmf_p2p_* -
+    the gloo group only carries the handles - and both ranks end up with the same averaged gradient."""
+    j, err = _bench(["--gpus", "2", "--steps", "8", "--warmup", "3", "--transport", "p2p"])
+    c = j["config"]
+    assert j["n_gpus"] == 2 and "REHEARSAL" in j["data"]
+    assert c["allreduce_transport"].startswith("p2p"), c["allreduce_transport"]
+    assert c["collectives_per_step"] == 1 and c["exchange_ranks"] == 2 and "vmlmf_p2p_connect" in c["exchange_ranks_counted_by"]
+    assert c["reduced_grad_norm_equal_across_ranks"] is True
+    assert j["loss"] == j["loss"] and 0.0 < j["loss"] < 10.0 and j["value"] > 0
+
+
 def test_one_rank_self_tests_of_the_rccl_paths():
     """What one GPU can run of RCCL itself: the C-ABI communicator (ncclCommCount says 1) with the all-reduce eager and
     captured inside the hipGraph (`--graph-collective`), and the LM network's bucketed exchange on the C-ABI side stream."""

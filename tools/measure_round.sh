@@ -38,6 +38,8 @@ for bp in 128 64 32; do timeout 600 python bench.py --config E --batch-per-gpu $
 VMLMF_BENCH_REHEARSAL=1 timeout 600 python bench.py --config E --gpus 2 --steps 10 --warmup 3 > $O/rehearsal_config_e_2ranks.json 2>/dev/null < /dev/null
 VMLMF_BENCH_REHEARSAL=1 timeout 600 python bench.py --gpus 2 --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $O/rehearsal_plain2.json 2>/dev/null < /dev/null
 VMLMF_BENCH_REHEARSAL=1 timeout 600 python bench.py --gpus 2 --global-batch 512 --steps 30 --warmup 5 --no-cpu-baseline --no-extra > $O/rehearsal_strong2.json 2>/dev/null < /dev/null
+VMLMF_BENCH_REHEARSAL=1 timeout 600 python bench.py --gpus 2 --transport p2p --steps 50 --warmup 10 --no-cpu-baseline --no-extra > $O/rehearsal_p2p2.json 2>/dev/null < /dev/null
+timeout 300 python tools/probes/p2p_latency.py 2>/dev/null | tail -1 > $O/p2p_latency_world1.txt
 
 BENCH="python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extra"
 pmc4 "" "python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-graph --no-extra; config A (B=64 T=128 H=180 r=16), $RN" $BENCH

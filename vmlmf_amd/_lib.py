@@ -18,7 +18,7 @@ NKERNELS = 13
 HEAD_MAX_CLASSES = 32
 MAX_TENSORS = 48
 V1_CELL, V2_GROUP_CELL, V3_LM, V4_LM_GROUP, V5_LMF_CELL, V6_GROUP_NOVM = 1, 2, 3, 4, 5, 6
-ABI_VERSION = 12
+ABI_VERSION = 13
 GUARD_WORDS, GUARD_GO, GUARD_SKIPPED = 72, 64, 66
 ADAM_FIRST, ADAM_LAST = 1, 2
 DT_F32, DT_BF16 = 0, 1
@@ -26,6 +26,8 @@ DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 E_BADARG, E_SHAPE, E_UNSUPPORTED, E_WORKSPACE, E_COMM, E_PROTOCOL = -1, -2, -3, -4, -5, -6
 SUM, AVG = 0, 1
 COMM_ID_BYTES = 128
+P2P_HANDLE_BYTES = 64
+P2P_MAX_RANKS = 8
 
 _fp = ctypes.POINTER(ctypes.c_float)
 
@@ -147,6 +149,10 @@ SYMBOLS = {
     "vmlmf_comm_destroy": (_i, [_vp]),
     "vmlmf_flat_allreduce": (_i, [_vp, _sz, _i, _vp, _vp]),
     "vmlmf_flat_allreduce_group": (_i, [_i, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _i, _vp, _vp]),
+    "vmlmf_p2p_create": (_i, [ctypes.POINTER(_vp), _i, _i, _sz, _vp]),
+    "vmlmf_p2p_connect": (_i, [_vp, _vp]),
+    "vmlmf_p2p_allreduce": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "vmlmf_p2p_destroy": (_i, [_vp]),
     "vmlmf_profile_enable": (_i, [_i]),
     "vmlmf_profile_read": (_i, [_fp, ctypes.POINTER(ctypes.c_int32), _i]),
     "vmlmf_kernel_name": (ctypes.c_char_p, [_i]),

@@ -145,6 +145,7 @@ const char* status_text(unsigned code) {
     case VMLMF_ST_CLUSTER: return "a member of a row-block cluster never published its partial (outputs of that call are NaN)";
     case VMLMF_ST_WF_FWD: return "a layer of a wavefront forward launch never received the rows of the layer below (outputs are NaN)";
     case VMLMF_ST_WF_BWD: return "a layer of a wavefront backward launch never received the gradient rows of the layer above (gradients are NaN)";
+    case VMLMF_ST_P2P: return "a rank of the peer-to-peer all-reduce never wrote its buffer into this rank's staging area (the reduced buffer is NaN)";
   }
   return "unknown status code";
 }
@@ -586,6 +587,7 @@ int vmlmf_adam_guard_mode() { return g_adam_guard; }
 
 // error text for the other translation units of the C ABI (vmlmf_comm.cpp)
 int vmlmf_set_error(int code, const std::string& msg) { return fail(code, msg); }
+unsigned* vmlmf_status_word(void* stream) { return status_word((hipStream_t)stream); }   // (vmlmf_p2p.hip)
 
 extern "C" {
 

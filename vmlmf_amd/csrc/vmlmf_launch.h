@@ -65,7 +65,7 @@ constexpr int WR_PROG_STRIDE = 32;   // unsigned words between two rows' progres
                                      // every other step by 64+ workgroups: words sharing a line serialise at the memory side)
 // codes a kernel leaves in the host-visible status word when one of its bounded waits gives up (the results are NaN then); the
 // next C-ABI call on the device returns VMLMF_E_PROTOCOL (vmlmf_api.hip: take_status)
-constexpr unsigned VMLMF_ST_WRIDE = 1, VMLMF_ST_CLUSTER = 2, VMLMF_ST_WF_FWD = 3, VMLMF_ST_WF_BWD = 4;
+constexpr unsigned VMLMF_ST_WRIDE = 1, VMLMF_ST_CLUSTER = 2, VMLMF_ST_WF_FWD = 3, VMLMF_ST_WF_BWD = 4, VMLMF_ST_P2P = 5;
 __device__ __forceinline__ void vg_raise(unsigned* status, unsigned code) {
   if (status != nullptr) __hip_atomic_store(status, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }

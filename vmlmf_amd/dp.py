@@ -84,14 +84,75 @@ class CabiComm:
             self.handle = None
 
 
+class P2PExchange:
+    """The one-shot peer-to-peer all-reduce of the C ABI (include/vmlmf_hip.h, ABI 13: vmlmf_p2p_*; csrc/vmlmf_p2p.hip) for SMALL
+    flat buffers (the HAR network's 121 KiB between loss.backward() and optimizer.step(), train.py:64-65): every rank writes its
+    buffer into every peer's hipIpc-mapped staging area and sums its own area's slots in rank order - two launches on the compute
+    stream, no collective library.  torch.distributed only carries the 64-byte IPC handles, once (any backend: gloo works).
+    Like CabiComm, every rank takes the same sequence of collectives whatever fails locally, and a MIN all-reduce of "my side
+    is connected" decides for all: self.handle is None afterwards when any rank failed (self.error: the local reason)."""
+
+    def __init__(self, device, max_floats, group=None):
+        self.lib = _lib.lib()
+        self.device = torch.device(device)
+        self.handle, self.error, self.max_floats = None, None, int(max_floats)
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        self.world = world
+        h = ctypes.c_void_p()
+        mine = (ctypes.c_ubyte * _lib.P2P_HANDLE_BYTES)()
+        made = 0
+        try:
+            if world > _lib.P2P_MAX_RANKS:
+                raise RuntimeError(f"peer-to-peer exchange: at most {_lib.P2P_MAX_RANKS} ranks")
+            with _lib.on_device(self.device):
+                _lib.check(self.lib.vmlmf_p2p_create(ctypes.byref(h), rank, world, self.max_floats, mine))
+            made = 1
+        except Exception as e:      # noqa: BLE001 - decided collectively below
+            self.error = e
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (made, bytes(mine)), group=group)
+        ok = 0
+        if made and all(g[0] == 1 for g in gathered):
+            blob = b"".join(g[1] for g in gathered)
+            try:
+                with _lib.on_device(self.device):
+                    _lib.check(self.lib.vmlmf_p2p_connect(h, (ctypes.c_ubyte * len(blob)).from_buffer_copy(blob)))
+                ok = 1
+            except Exception as e:      # noqa: BLE001
+                self.error = e
+        flag = torch.tensor([ok], device=self.device if dist.get_backend(group) == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        if int(flag.item()) == 1:
+            self.handle = h
+        elif made:
+            self.lib.vmlmf_p2p_destroy(h)
+
+    def ranks(self):
+        return self.world
+
+    def all_reduce(self, tensors, op):
+        """In place, tensor by tensor (each <= max_floats floats, fp32, contiguous, 16-byte aligned), on torch's current stream."""
+        with _lib.on_device(self.device):
+            for t in tensors:
+                _lib.check(self.lib.vmlmf_p2p_allreduce(self.handle, t.data_ptr(), t.numel(), _lib.AVG if op == "avg" else _lib.SUM,
+                                                        _lib.raw_stream(self.device)))
+
+    def close(self):
+        if self.handle:
+            self.lib.vmlmf_p2p_destroy(self.handle)
+            self.handle = None
+
+
 class FlatGradAllReduce:
     """Owns a flat buffer covering the gradients of `params` (only those that can receive one)."""
 
     def __init__(self, params, op="avg", group=None, transport="torch"):
         """transport: "torch" = torch.distributed collectives (RCCL under backend "nccl", gloo in the CPU tests);
         "cabi" = the package's own RCCL entry points behind the C ABI (HIP tensors, backend "nccl" only; when the
-        communicator cannot be made on EVERY rank, all ranks fall back to "torch" together)."""
-        assert op in ("avg", "sum") and transport in ("torch", "cabi")
+        communicator cannot be made on EVERY rank, all ranks fall back to "torch" together); "p2p" = the one-shot peer-to-peer
+        exchange of the C ABI (P2PExchange: HIP tensors of at most 4 Mi floats each, any backend for the handle exchange; the same
+        collective fallback).  "torch" stays the default: the peer-to-peer path has never run across GPUs."""
+        assert op in ("avg", "sum") and transport in ("torch", "cabi", "p2p")
         self.op = op
         self.group = group
         self.transport = transport
@@ -135,6 +196,8 @@ class FlatGradAllReduce:
     def exchange_ranks(self):
         """(ranks, who counted them): RCCL's own ncclCommCount on the C-ABI transport; otherwise only the size of the
         torch.distributed group, labelled with its backend - over gloo no RCCL communicator exists at all."""
+        if isinstance(self._comm, P2PExchange):
+            return self._comm.ranks(), "vmlmf_p2p_connect (staging areas mapped: one per rank)"
         if self._comm is not None:
             return self._comm.ranks(), "ncclCommCount (RCCL communicator behind the C ABI)"
         if not dist.is_initialized():
@@ -142,7 +205,24 @@ class FlatGradAllReduce:
         return dist.get_world_size(self.group), f"torch.distributed.get_world_size (backend {dist.get_backend(self.group)})"
 
     def transport_used(self):
+        if isinstance(self._comm, P2PExchange):
+            return "p2p:vmlmf_p2p_allreduce(hipIpc staging, rank-order sum)"
         return "cabi:vmlmf_flat_allreduce_group(rccl)" if self._comm is not None else f"torch.distributed:{dist.get_backend(self.group) if dist.is_initialized() else 'none'}"
+
+    def _p2p(self, tensors):
+        """The peer-to-peer exchange, or None (CPU tensors / no process group / a buffer it does not take / creation failed somewhere).
+        Sized at the first reduce() for the largest buffer of that step."""
+        if self.transport != "p2p" or not dist.is_initialized() or tensors[0].device.type != "cuda":
+            return None
+        if not self._comm_tried:
+            self._comm_tried = True
+            ex = P2PExchange(tensors[0].device, max(t.numel() for t in tensors), self.group)
+            self._comm = ex if ex.handle else None
+            self._comm_error = ex.error
+        c = self._comm
+        if c is None or any(t.numel() > c.max_floats or t.dtype != torch.float32 or not t.is_contiguous() or t.data_ptr() % 16 for t in tensors):
+            return None
+        return c
 
     def _cabi(self, device, backend):
         """The C-ABI communicator, or None (wrong backend / CPU tensors / creation failed somewhere)."""
@@ -158,7 +238,7 @@ class FlatGradAllReduce:
     def _all_reduce(self, tensors, op, backend):
         """One collective launch for all `tensors`: on RCCL several all-reduces issued under the coalescing manager
         become one group call (the exchange is latency-bound: two launches would cost twice one)."""
-        comm = self._cabi(tensors[0].device, backend)
+        comm = self._p2p(tensors) if self.transport == "p2p" else self._cabi(tensors[0].device, backend)
         if comm is not None:
             comm.all_reduce(tensors, "avg" if op == dist.ReduceOp.AVG else "sum")
             return
