@@ -32,6 +32,22 @@ def main():
         torch.cuda.synchronize()
         assert torch.equal(buf.cpu(), ref), (n, op, float((buf.cpu() - ref).abs().max()))
         done += 1
+    # a run of back-to-back exchanges of random sizes without a host synchronisation in between (the parities alternate, a fast rank
+    # runs ahead of a slow one): checked at the end against gloo
+    soak = int(os.environ.get("VMLMF_P2P_SOAK", "200"))
+    sizes = torch.randint(1, 40000, (soak,), generator=torch.Generator().manual_seed(7)).tolist()   # (the same on both ranks)
+    bufs, refs = [], []
+    for n in sizes:
+        g = torch.randn(n, generator=gen)
+        bufs.append(g.to(dev))
+        refs.append(g)
+    for b in bufs:
+        ex.all_reduce([b], "sum")
+    torch.cuda.synchronize()
+    for b, r in zip(bufs, refs):
+        dist.all_reduce(r, op=dist.ReduceOp.SUM)
+        assert torch.equal(b.cpu(), r), b.numel()
+    done += 1
     ex.close()
     # through the gradient reducer of the data-parallel path: the parameters' gradients tile one flat allocation
     flat = torch.randn(5000, generator=gen).to(dev)
@@ -47,7 +63,7 @@ def main():
     assert red.transport_used().startswith("p2p"), red.transport_used()
     assert torch.equal(flat.cpu(), ref)
     assert red.exchange_ranks()[0] == world
-    print("P2P-OK", done + 1, flush=True)
+    print("P2P-OK", done + 1, flush=True)   # 7 single exchanges + the run + the reducer
     dist.destroy_process_group()
 
 

@@ -69,7 +69,8 @@ def test_two_processes_exchange_over_the_peer_to_peer_path():
     """vmlmf_p2p_* (ABI 13; SURVEY section 8e: the one-shot exchange for the HAR network's 121 KiB of gradients, train.py:64-65):
     two processes on this box's ONE GPU map each other's staging areas over hipIpc, write their buffers into them and sum in rank
     order - every exchange bit-equal to the same buffers reduced over gloo, for buffer sizes that are no multiple of four, both
-    parities of the staging area, SUM and AVG, and through vmlmf_amd.dp.FlatGradAllReduce(transport="p2p")."""
+    parities of the staging area, SUM and AVG, a run of 200 exchanges of random sizes without a host synchronisation in between, and
+    through vmlmf_amd.dp.FlatGradAllReduce(transport="p2p")."""
     import socket
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -87,7 +88,7 @@ def test_two_processes_exchange_over_the_peer_to_peer_path():
             if p.poll() is None:
                 p.kill()
     for p, (out, err) in zip(procs, outs):
-        assert p.returncode == 0 and "P2P-OK 8" in out, out[-1000:] + err[-3000:]
+        assert p.returncode == 0 and "P2P-OK 9" in out, out[-1000:] + err[-3000:]
 
 
 def test_two_ranks_walk_the_headline_bench_over_the_peer_to_peer_transport():
